@@ -1,0 +1,290 @@
+// Fused attention forward for head_dim 64 on gfx950 (fp16 in, fp32 softmax/accumulate, fp16 out).
+//
+// Replaces F.scaled_dot_product_attention at i2vgen-xl/pnp_utils.py:208-210 (spatial self-attention, and the
+// cross-attention of the same processor class) and :314-316 (temporal self-attention), *including* the PnP
+// query/key injection of :189-196 / :295-302: instead of copying the source branch's Q and K over the two target
+// branches, batch element i simply reads Q/K of element i % qk_mod (aliasing; no HBM copy).
+//
+// One kernel serves all three attention flavours through strided row addressing (see anyv2v_hip.h): spatial
+// tokens are contiguous, temporal sequences stride by H*W rows in the same channels-last matrix (no permute),
+// cross-attention K/V are shared by the F frames of a clip (kv_div).
+//
+// Structure (per the MI355X guide's 32x32 flash ladder): 256 threads = 4 waves x 32 query rows; KV tiles of 64.
+//   S^T = K Q^T   : v_mfma_f32_32x32x16_f16(a = K fragment, b = Q fragment): a lane owns ONE query column and 16
+//                   of the 32 keys -> row max / row sum are in-lane plus one cross-half shuffle.
+//   O^T = V^T P^T : a = V^T fragment (from a transposed LDS image), b = P fragment taken straight from the S^T
+//                   registers (exp'ed, packed to fp16): no LDS round trip for P, per-lane O rescale.
+// LDS: K tile [64 key][64 d], V^T tile [64 d][64 key-slot]; 16-byte chunks XOR-swizzled by (row>>1)&7 which is
+// conflict-free for the 32-row ds_read_b128 fragment pattern.  Keys inside a V^T row are permuted (bits 2<->3)
+// so that the 8 keys a lane needs for one MFMA K-step are one contiguous 16-byte read.
+// Next KV tile is prefetched global->registers while the current one is consumed (async-stage split, T14).
+#include "common.h"
+
+struct AttnK {
+    const half_t* Q;
+    const half_t* K;
+    const half_t* V;
+    half_t* O;
+    int ldq, ldk, ldv, ldo;
+    int batch, heads, Sq, Sk, inner;
+    long long q_outer, q_inner, q_seq, kv_outer, kv_inner, kv_seq;
+    int kv_div, qk_mod;
+    float scale_log2;
+    int q_tiles;
+    int head_dim;
+};
+
+__device__ __forceinline__ long long attn_row(long long i, int inner, long long so, long long si) {
+    return (i / inner) * so + (i % inner) * si;
+}
+
+__global__ __launch_bounds__(256) void flash_attn_d64_kernel(const AttnK p) {
+    __shared__ __attribute__((aligned(16))) char smem[16384];
+    char* const Ks = smem;
+    char* const VT = smem + 8192;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int qt = bid % p.q_tiles;
+    const int bh = bid / p.q_tiles;
+    const int h = bh % p.heads;
+    const int i = bh / p.heads;  // batch element
+
+    const int iq = p.qk_mod > 0 ? i % p.qk_mod : i;
+    const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
+    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
+    const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+
+    // ---- Q fragments (B operand of S^T): lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7]
+    const int q0 = qt * 128 + w * 32;
+    const bool wave_active = q0 < p.Sq;
+    const int qrow = q0 + l31;
+    h8 qf[4];
+    {
+        const int qr = qrow < p.Sq ? qrow : p.Sq - 1;
+        const half_t* qp = p.Q + (qbase + (long long)qr * p.q_seq) * p.ldq + h * 64 + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h8*)(qp + 16 * ks);
+    }
+
+    // ---- staging assignment
+    const int skey = tid >> 3;   // K: keys skey, skey + 32
+    const int sdc = tid & 7;     // 16-byte chunk along d
+    const int vk0 = 2 * (tid >> 3);  // V: keys vk0, vk0 + 1
+    h8 rk[2], rv[2];
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_tile = [&](int key0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = key0 + skey + 32 * t;
+            rk[t] = key < p.Sk ? *(const h8*)(p.K + (kbase + (long long)key * p.kv_seq) * p.ldk + h * 64 + sdc * 8) : zero8;
+            const int vkey = key0 + vk0 + t;
+            rv[t] = vkey < p.Sk ? *(const h8*)(p.V + (vbase + (long long)vkey * p.kv_seq) * p.ldv + h * 64 + sdc * 8) : zero8;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = skey + 32 * t;
+            *(h8*)(Ks + key * 128 + ((sdc ^ ((key >> 1) & 7)) << 4)) = rk[t];
+        }
+        // V^T: pack the two adjacent keys of this thread for each of its 8 d's
+        const int pos = (vk0 & ~12) | ((vk0 & 4) << 1) | ((vk0 & 8) >> 1);  // swap key bits 2 and 3
+        const int chunk = pos >> 3, within = pos & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = sdc * 8 + e;
+            h2 pr = {rv[0][e], rv[1][e]};
+            *(h2*)(VT + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4) + within * 2) = pr;
+        }
+    };
+
+    f16v oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float c = p.scale_log2;
+
+    const int ntiles = (p.Sk + 63) / 64;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int j = 0; j < ntiles; ++j) {
+        const bool has_next = j + 1 < ntiles;
+        if (has_next) load_tile((j + 1) * 64);
+        if (wave_active) {
+            // ---- S^T = K Q^T  (two 32-key blocks)
+            f16v sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                const int key = 32 * kb + l31;
+                const char* krow = Ks + key * 128;
+                const int fk = (key >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const h8 kf = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                }
+            }
+            // ---- mask the key tail, online softmax
+            const int key_base = j * 64 + 4 * hi;
+            float mx = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2);
+                    if (key >= p.Sk) sacc[kb][r] = -1e30f;
+                    mx = fmaxf(mx, sacc[kb][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f((m_run - m_new) * c);
+            const float mc = m_new * c;
+            m_run = m_new;
+            float psum = 0.f;
+            h8 pf[4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = exp2f(fmaf(sacc[kb][r], c, -mc));
+                    psum += pv;
+                    pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                oacc[0][r] *= alpha;
+                oacc[1][r] *= alpha;
+            }
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int d = 32 * db + l31;
+                const char* vrow = VT + d * 128;
+                const int fd = (d >> 1) & 7;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const h8 vf = *(const h8*)(vrow + (((2 * t + hi) ^ fd) << 4));
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t], oacc[db], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (has_next) store_tile();
+        __syncthreads();
+    }
+
+    if (wave_active && qrow < p.Sq) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        half_t* op = p.O + (obase + (long long)qrow * p.q_seq) * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[db][4 * g + e] * inv);
+                *(h4*)(op + 32 * db + 8 * g) = o;
+            }
+    } else if (wave_active) {
+        // keep the shuffle convergent for partially filled waves
+        (void)__shfl_xor(l_run, 32, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic reference kernel: one thread per (batch, head, query); any head_dim <= 64, any strides.
+__global__ void attn_naive_kernel(const AttnK p) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)p.batch * p.heads * p.Sq;
+    if (idx >= total) return;
+    const int s = (int)(idx % p.Sq);
+    const int h = (int)((idx / p.Sq) % p.heads);
+    const int i = (int)(idx / ((long long)p.Sq * p.heads));
+    const int D = p.head_dim;
+    const int iq = p.qk_mod > 0 ? i % p.qk_mod : i;
+    const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
+    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
+    const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    float q[64], o[64];
+    const half_t* qp = p.Q + (qbase + (long long)s * p.q_seq) * p.ldq + h * D;
+    for (int d = 0; d < D; ++d) {
+        q[d] = (float)qp[d];
+        o[d] = 0.f;
+    }
+    float m = -1e30f, l = 0.f;
+    const float c = p.scale_log2;
+    for (int k = 0; k < p.Sk; ++k) {
+        const half_t* kp = p.K + (kbase + (long long)k * p.kv_seq) * p.ldk + h * D;
+        float sc = 0.f;
+        for (int d = 0; d < D; ++d) sc += q[d] * (float)kp[d];
+        const float mn = fmaxf(m, sc);
+        const float a = exp2f((m - mn) * c);
+        const float pv = exp2f((sc - mn) * c);
+        const half_t* vp = p.V + (vbase + (long long)k * p.kv_seq) * p.ldv + h * D;
+        for (int d = 0; d < D; ++d) o[d] = o[d] * a + pv * (float)vp[d];
+        l = l * a + pv;
+        m = mn;
+    }
+    half_t* op = p.O + (obase + (long long)s * p.q_seq) * p.ldo + h * D;
+    const float inv = 1.0f / l;
+    for (int d = 0; d < D; ++d) op[d] = (half_t)(o[d] * inv);
+}
+
+static int fill(const AnyV2VAttnDesc* d, AttnK& k, int head_dim) {
+    AV_CHECK(d != nullptr, "attention: null descriptor");
+    AV_CHECK(d->Q && d->K && d->V && d->O, "attention: null pointer");
+    AV_CHECK(d->batch > 0 && d->heads > 0 && d->Sq > 0 && d->Sk > 0, "attention: bad sizes");
+    AV_CHECK(d->inner > 0 && d->kv_div > 0 && d->qk_mod >= 0, "attention: bad inner/kv_div/qk_mod");
+    k.Q = (const half_t*)d->Q;
+    k.K = (const half_t*)d->K;
+    k.V = (const half_t*)d->V;
+    k.O = (half_t*)d->O;
+    k.ldq = d->ldq; k.ldk = d->ldk; k.ldv = d->ldv; k.ldo = d->ldo;
+    k.batch = d->batch; k.heads = d->heads; k.Sq = d->Sq; k.Sk = d->Sk; k.inner = d->inner;
+    k.q_outer = d->q_outer; k.q_inner = d->q_inner; k.q_seq = d->q_seq;
+    k.kv_outer = d->kv_outer; k.kv_inner = d->kv_inner; k.kv_seq = d->kv_seq;
+    k.kv_div = d->kv_div; k.qk_mod = d->qk_mod;
+    k.scale_log2 = d->scale * 1.4426950408889634f;
+    k.q_tiles = (d->Sq + 127) / 128;
+    k.head_dim = head_dim;
+    return ANYV2V_OK;
+}
+
+static int launch_naive(const AttnK& k, hipStream_t s) {
+    const long long total = (long long)k.batch * k.heads * k.Sq;
+    hipLaunchKernelGGL(attn_naive_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, k);
+    return av_launch_status("attention_naive");
+}
+
+extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
+    AttnK k;
+    int rc = fill(d, k, 64);
+    if (rc != ANYV2V_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fast = !(d->flags & 1) && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0 &&
+                      av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) && av_aligned16(d->O);
+    if (!fast) return launch_naive(k, s);
+    const long long nwg = (long long)k.batch * k.heads * k.q_tiles;
+    AV_CHECK(nwg < (1ll << 31), "attention: grid too large");
+    hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nwg), dim3(256), 0, s, k);
+    return av_launch_status("flash_attn_d64");
+}
+
+extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream) {
+    AV_CHECK(head_dim > 0 && head_dim <= 64, "attention_small: head_dim must be in 1..64");
+    AttnK k;
+    int rc = fill(d, k, head_dim);
+    if (rc != ANYV2V_OK) return rc;
+    return launch_naive(k, (hipStream_t)stream);
+}

@@ -1,0 +1,423 @@
+// Gather-GEMM for gfx950: Linear / 1x1 conv, implicit-GEMM conv2d 3x3 (stride 1|2, optional folded nearest x2
+// upsample) and the temporal (3,1,1) conv, all over channels-last token matrices, fp16 in / fp32 MFMA
+// accumulate / fp16 out, with the bias / temb-broadcast / SiLU / GELU / GEGLU / residual epilogues fused.
+//
+// Replaces (reference = TIGER-AI-Lab/AnyV2V, i2vgen-xl/pnp_utils.py): conv1/conv2 :78,:107, time_emb_proj :81-88,
+// conv_shortcut :117-122, residual :124, attn.to_q/to_k/to_v :175,:182-183, attn.to_out[0] :216, and the
+// diffusers-0.26.3 Linear/Conv2d/Conv3d layers of I2VGenXLUNet behind pipeline_i2vgen_xl.py:1146.
+//
+// Tile: 128 x (NF*32) x 64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64 x NF*16 via
+// v_mfma_f32_16x16x32_f16 with SWAPPED operands (a = weight fragment, b = activation fragment) so that a lane
+// ends up with 4 consecutive output channels of one token -> 8-byte LDS writes in the epilogue and full-line
+// coalesced 16-byte global stores.  LDS tiles are [row][64 k] with the 16-byte chunk index XOR-swizzled by
+// (row & 7): conflict-free for ds_read_b128 fragment reads (MI355X guide, T2).  Double-buffered; the next
+// K-tile is fetched (registers or LDS-DMA) while the current one is multiplied; one barrier per K-tile.
+#include "common.h"
+
+enum { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_TEMPORAL = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3 };
+
+__device__ __attribute__((aligned(256))) half_t g_zero_line[128];  // 256 B of zeros: source for padded taps
+
+struct GemmK {
+    const half_t* A0;
+    const half_t* A1;
+    const half_t* W;
+    half_t* C;
+    const half_t* bias;
+    const half_t* rowvec;
+    const half_t* R;
+    const half_t* zeros;
+    int M, N, C0, C1, lda0, lda1, ldc, ldr, ldrv, rowvec_div;
+    int mode, Hi, Wi, Ho, Wo, stride, up, F, HW, act;
+    int taps, Ktot, nt0, nt1, tilesN;
+};
+
+struct RowInfo {
+    int base;  // linear/temporal: row m (or -1); conv2d: img * Hi * Wi
+    int y, x;  // conv2d: yo*stride-1, xo*stride-1 ; temporal: y = frame index
+};
+
+__device__ __forceinline__ RowInfo make_row(const GemmK& p, int m) {
+    RowInfo r;
+    if (m >= p.M) {
+        r.base = -1;
+        r.y = r.x = -(1 << 28);
+        return r;
+    }
+    if (p.mode == MODE_CONV2D) {
+        const int hw = p.Ho * p.Wo;
+        const int img = m / hw, rem = m - img * hw;
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        r.base = img * p.Hi * p.Wi;
+        r.y = yo * p.stride - 1;
+        r.x = xo * p.stride - 1;
+    } else if (p.mode == MODE_TEMPORAL) {
+        r.base = m;
+        r.y = (m / p.HW) % p.F;
+        r.x = 0;
+    } else {
+        r.base = m;
+        r.y = r.x = 0;
+    }
+    return r;
+}
+
+// source row of output row `r` for filter tap `tap`, or -1 when the tap falls into the zero padding
+__device__ __forceinline__ int src_row(const GemmK& p, const RowInfo& r, int tap) {
+    if (p.mode == MODE_CONV2D) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        int yi = r.y + dy, xi = r.x + dx;
+        const int ly = p.up ? 2 * p.Hi : p.Hi, lx = p.up ? 2 * p.Wi : p.Wi;
+        const bool ok = (yi >= 0) & (yi < ly) & (xi >= 0) & (xi < lx);
+        if (p.up) {
+            yi >>= 1;
+            xi >>= 1;
+        }
+        return ok ? r.base + yi * p.Wi + xi : -1;
+    } else if (p.mode == MODE_TEMPORAL) {
+        const int f = r.y + tap - 1;
+        const bool ok = (f >= 0) & (f < p.F);
+        return ok ? r.base + (tap - 1) * p.HW : -1;
+    }
+    return r.base;
+}
+
+__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int NF, bool GLDS, bool GEGLU>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
+    constexpr int BM = 128, BN = NF * 32;
+    constexpr int A_BYTES = BM * 64 * 2;
+    constexpr int B_BYTES = BN * 64 * 2;
+    constexpr int NB = BN / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    char* const As0 = smem;
+    char* const Bs0 = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);  // XCD-contiguous tile order (bijective)
+    const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    const int m_blk = mt * BM, n_blk = nt * BN;
+
+    // staging: thread -> rows srow0 + 32 i, physical 16-B chunk pc, logical chunk kc
+    const int srow0 = tid >> 3;
+    const int pc = tid & 7;
+    const int kc = pc ^ (srow0 & 7);
+    RowInfo ri[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ri[i] = make_row(p, m_blk + srow0 + 32 * i);
+    const half_t* bptr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        int n = n_blk + srow0 + 32 * i;
+        n = n < p.N ? n : p.N - 1;
+        bptr[i] = p.W + (size_t)n * p.Ktot + kc * 8;
+    }
+
+    h8 ra[4], rb[NB];
+    auto issue = [&](int kt_c, int tap, int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sr = src_row(p, ri[i], tap);
+            const half_t* g;
+            if (sr < 0)
+                g = p.zeros;
+            else if (kt_c < p.nt0)
+                g = p.A0 + (size_t)sr * p.lda0 + kt_c * 64 + kc * 8;
+            else
+                g = p.A1 + (size_t)sr * p.lda1 + (kt_c - p.nt0) * 64 + kc * 8;
+            if constexpr (GLDS)
+                glds16(g, As0 + buf * A_BYTES + (i * 256 + w * 64) * 16);
+            else
+                ra[i] = *(const h8*)g;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const half_t* g = bptr[i] + (size_t)kt * 64;
+            if constexpr (GLDS)
+                glds16(g, Bs0 + buf * B_BYTES + (i * 256 + w * 64) * 16);
+            else
+                rb[i] = *(const h8*)g;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(h8*)(As0 + buf * A_BYTES + ((srow0 + 32 * i) * 8 + pc) * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *(h8*)(Bs0 + buf * B_BYTES + ((srow0 + 32 * i) * 8 + pc) * 16) = rb[i];
+    };
+
+    f4 acc[4][NF];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, lq = lane >> 4;
+    auto compute = [&](int buf) {
+        const char* as = As0 + buf * A_BYTES;
+        const char* bs = Bs0 + buf * B_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 af[4], bf[NF];
+            const int c = (ks * 4 + lq) ^ (l15 & 7);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) af[mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bf[nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][nf], 0, 0, 0);
+        }
+    };
+
+    const int ntap = p.nt0 + p.nt1;
+    const int nk = p.taps * ntap;
+    int tap = 0, kt_c = 0;
+    issue(0, 0, 0, 0);
+    if constexpr (!GLDS) commit(0);
+    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        int nkt_c = kt_c + 1, ntp = tap;
+        if (nkt_c == ntap) {
+            nkt_c = 0;
+            ++ntp;
+        }
+        const bool has_next = kt + 1 < nk;
+        if (has_next) issue(nkt_c, ntp, kt + 1, cur ^ 1);
+        compute(cur);
+        if constexpr (!GLDS) {
+            if (has_next) commit(cur ^ 1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        kt_c = nkt_c;
+        tap = ntp;
+    }
+
+    // ---------------- epilogue: registers -> (bias, temb, act) -> fp16 tile in LDS -> (+residual) -> global
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    constexpr int CS_LD = BNO + 8;
+    half_t* const Cs = (half_t*)smem;
+    const int Nout = GEGLU ? p.N / 2 : p.N;
+    const int n_out_blk = GEGLU ? n_blk / 2 : n_blk;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int ml = wr * 64 + mf * 16 + l15;
+        const int m = m_blk + ml;
+        const half_t* rv = nullptr;
+        if (p.rowvec != nullptr && m < p.M) rv = p.rowvec + (size_t)(m / p.rowvec_div) * p.ldrv;
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int np = 0; np < NF / 2; ++np) {
+                const int nh = n_blk + wc * NF * 16 + np * 32 + 4 * lq;  // packed row of h; gate = +16
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float hv = acc[mf][2 * np][r], gv = acc[mf][2 * np + 1][r];
+                    if (p.bias != nullptr) {
+                        hv += (float)p.bias[nh + r];
+                        gv += (float)p.bias[nh + 16 + r];
+                    }
+                    // torch: proj output is rounded to fp16 before chunk / gelu / mul
+                    hv = (float)(half_t)hv;
+                    gv = (float)(half_t)gv;
+                    o[r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
+                }
+                *(h4*)(Cs + ml * CS_LD + wc * NF * 8 + np * 16 + 4 * lq) = o;
+            }
+        } else {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int nl = wc * NF * 16 + nf * 16 + 4 * lq;
+                const int n = n_blk + nl;
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[mf][nf][r];
+                    if (n + r < p.N) {
+                        if (p.bias != nullptr) v += (float)p.bias[n + r];
+                        if (rv != nullptr) v += (float)rv[n + r];
+                    }
+                    if (p.act == ACT_SILU)
+                        v = av_silu(v);
+                    else if (p.act == ACT_GELU)
+                        v = av_gelu(v);
+                    o[r] = (half_t)v;
+                }
+                *(h4*)(Cs + ml * CS_LD + nl) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BNO / 8;
+    for (int id = tid; id < BM * CPR; id += 256) {
+        const int r = id / CPR, cc = id - r * CPR;
+        const int m = m_blk + r;
+        const int n0 = n_out_blk + cc * 8;
+        if (m >= p.M || n0 >= Nout) continue;
+        h8 v = *(const h8*)(Cs + r * CS_LD + cc * 8);
+        if (n0 + 8 <= Nout) {
+            if (p.R != nullptr) {
+                const h8 rr = *(const h8*)(p.R + (size_t)m * p.ldr + n0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+            }
+            *(h8*)(p.C + (size_t)m * p.ldc + n0) = v;
+        } else {
+            for (int e = 0; e < 8 && n0 + e < Nout; ++e) {
+                float x = (float)v[e];
+                if (p.R != nullptr) x += (float)p.R[(size_t)m * p.ldr + n0 + e];
+                p.C[(size_t)m * p.ldc + n0 + e] = (half_t)x;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Reference-grade kernel: one thread per output element, any shape.  Used for the tiny once-per-clip
+// conditioning layers (Cin = 4/16/32 ...) and as the on-device cross-check of the MFMA kernel in the tests.
+__global__ void gemm_naive_kernel(const GemmK p) {
+    const bool geglu = p.act == ACT_GEGLU;
+    const int Nout = geglu ? p.N / 2 : p.N;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)p.M * Nout) return;
+    const int m = (int)(idx / Nout), j = (int)(idx - (long long)m * Nout);
+    const int n = geglu ? 32 * (j / 16) + (j % 16) : j;
+    const RowInfo ri = make_row(p, m);
+    const int K = p.C0 + p.C1;
+    float a0 = 0.f, a1 = 0.f;
+    for (int tap = 0; tap < p.taps; ++tap) {
+        const int sr = src_row(p, ri, tap);
+        if (sr < 0) continue;
+        const half_t* w0 = p.W + (size_t)n * p.Ktot + (size_t)tap * K;
+        const half_t* w1 = w0 + (size_t)16 * p.Ktot;
+        const half_t* x0 = p.A0 + (size_t)sr * p.lda0;
+        for (int k = 0; k < p.C0; ++k) {
+            const float x = (float)x0[k];
+            a0 += x * (float)w0[k];
+            if (geglu) a1 += x * (float)w1[k];
+        }
+        if (p.C1 > 0) {
+            const half_t* x1 = p.A1 + (size_t)sr * p.lda1;
+            for (int k = 0; k < p.C1; ++k) {
+                const float x = (float)x1[k];
+                a0 += x * (float)w0[p.C0 + k];
+                if (geglu) a1 += x * (float)w1[p.C0 + k];
+            }
+        }
+    }
+    float v;
+    if (geglu) {
+        if (p.bias != nullptr) {
+            a0 += (float)p.bias[n];
+            a1 += (float)p.bias[n + 16];
+        }
+        a0 = (float)(half_t)a0;
+        a1 = (float)(half_t)a1;
+        v = a0 * (float)(half_t)av_gelu(a1);
+    } else {
+        v = a0;
+        if (p.bias != nullptr) v += (float)p.bias[n];
+        if (p.rowvec != nullptr) v += (float)p.rowvec[(size_t)(m / p.rowvec_div) * p.ldrv + n];
+        if (p.act == ACT_SILU)
+            v = av_silu(v);
+        else if (p.act == ACT_GELU)
+            v = av_gelu(v);
+    }
+    if (p.R != nullptr) v = (float)(half_t)v + (float)p.R[(size_t)m * p.ldr + j];
+    p.C[(size_t)m * p.ldc + j] = (half_t)v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static const half_t* zero_line() {
+    static const half_t* z = nullptr;
+    if (z == nullptr) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_zero_line)) == hipSuccess) z = (const half_t*)ptr;
+    }
+    return z;
+}
+
+template <int NF, bool GLDS, bool GEGLU>
+static void launch_mfma(const GemmK& k, hipStream_t s) {
+    const int tilesM = (k.M + 127) / 128;
+    hipLaunchKernelGGL((gemm_mfma_kernel<NF, GLDS, GEGLU>), dim3(tilesM * k.tilesN), dim3(256), 0, s, k);
+}
+
+extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
+    AV_CHECK(d != nullptr, "gemm: null descriptor");
+    AV_CHECK(d->A0 && d->W && d->C, "gemm: null A0/W/C");
+    AV_CHECK(d->M > 0 && d->N > 0 && d->C0 > 0 && d->C1 >= 0, "gemm: bad M/N/C0/C1 (%d %d %d %d)", d->M, d->N, d->C0, d->C1);
+    AV_CHECK(d->mode >= 0 && d->mode <= 2, "gemm: bad mode %d", d->mode);
+    AV_CHECK(d->act >= 0 && d->act <= 3, "gemm: bad act %d", d->act);
+    AV_CHECK(d->C1 == 0 || d->A1 != nullptr, "gemm: C1 > 0 but A1 is null");
+    AV_CHECK(d->rowvec == nullptr || d->rowvec_div > 0, "gemm: rowvec needs rowvec_div > 0");
+    if (d->mode == MODE_CONV2D) {
+        AV_CHECK(d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && (d->stride == 1 || d->stride == 2),
+                 "gemm: bad conv geometry");
+        AV_CHECK(d->M % (d->Ho * d->Wo) == 0, "gemm: M not a multiple of Ho*Wo");
+    }
+    if (d->mode == MODE_TEMPORAL) {
+        AV_CHECK(d->F > 0 && d->HW > 0 && d->M % (d->F * d->HW) == 0, "gemm: bad temporal geometry");
+    }
+    if (d->act == ACT_GEGLU) {
+        AV_CHECK(d->N % 32 == 0, "gemm: GEGLU needs N %% 32 == 0");
+        AV_CHECK(d->rowvec == nullptr, "gemm: GEGLU with rowvec unsupported");
+    }
+    GemmK k;
+    k.A0 = (const half_t*)d->A0;
+    k.A1 = (const half_t*)d->A1;
+    k.W = (const half_t*)d->W;
+    k.C = (half_t*)d->C;
+    k.bias = (const half_t*)d->bias;
+    k.rowvec = (const half_t*)d->rowvec;
+    k.R = (const half_t*)d->R;
+    k.zeros = zero_line();
+    AV_CHECK(k.zeros != nullptr, "gemm: zero line symbol unavailable");
+    k.M = d->M; k.N = d->N; k.C0 = d->C0; k.C1 = d->C1;
+    k.lda0 = d->lda0; k.lda1 = d->lda1; k.ldc = d->ldc; k.ldr = d->ldr; k.ldrv = d->ldrv;
+    k.rowvec_div = d->rowvec_div > 0 ? d->rowvec_div : 1;
+    k.mode = d->mode; k.Hi = d->Hi; k.Wi = d->Wi; k.Ho = d->Ho; k.Wo = d->Wo; k.stride = d->stride; k.up = d->up;
+    k.F = d->F; k.HW = d->HW; k.act = d->act;
+    k.taps = d->mode == MODE_LINEAR ? 1 : (d->mode == MODE_CONV2D ? 9 : 3);
+    k.Ktot = k.taps * (d->C0 + d->C1);
+    k.nt0 = d->C0 / 64;
+    k.nt1 = d->C1 / 64;
+    hipStream_t s = (hipStream_t)stream;
+
+    const bool geglu = d->act == ACT_GEGLU;
+    bool fast = !(d->flags & 1) && d->C0 % 64 == 0 && d->C1 % 64 == 0 && d->lda0 % 8 == 0 &&
+                (d->C1 == 0 || d->lda1 % 8 == 0) && d->ldc % 8 == 0 && av_aligned16(d->A0) && av_aligned16(d->A1) &&
+                av_aligned16(d->W) && av_aligned16(d->C) && (d->R == nullptr || (d->ldr % 8 == 0 && av_aligned16(d->R))) &&
+                (!geglu || d->N % 128 == 0);
+    if (!fast) {
+        const int Nout = geglu ? d->N / 2 : d->N;
+        const long long total = (long long)d->M * Nout;
+        hipLaunchKernelGGL(gemm_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
+        return av_launch_status("gemm_naive");
+    }
+    const bool glds = (d->flags & 2) != 0;
+    if (geglu) {
+        k.tilesN = d->N / 128;
+        if (glds) launch_mfma<4, true, true>(k, s); else launch_mfma<4, false, true>(k, s);
+    } else if (d->N % 160 == 0) {
+        k.tilesN = d->N / 160;
+        if (glds) launch_mfma<5, true, false>(k, s); else launch_mfma<5, false, false>(k, s);
+    } else {
+        k.tilesN = (d->N + 127) / 128;
+        if (glds) launch_mfma<4, true, false>(k, s); else launch_mfma<4, false, false>(k, s);
+    }
+    return av_launch_status("gemm_mfma");
+}

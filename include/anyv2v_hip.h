@@ -1,0 +1,153 @@
+/*
+ * anyv2v_hip.h -- C ABI of libanyv2v_hip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * AnyV2V I2VGen-XL DDIM-inversion + PnP-edit hot path.
+ *
+ * The reference (TIGER-AI-Lab/AnyV2V) is pure Python and has no FFI layer; its hot path sits behind
+ * Python protocol seams.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp16 ("half") data unless the name says f32 / i32 / i64;
+ *   - activations are channels-last token matrices  X[(b f) (h w), C]  (row-major, leading dim in elements);
+ *   - `stream` is a hipStream_t (0 = default stream); kernels are enqueued, never synchronised;
+ *   - nothing allocates: the caller owns all memory (PyTorch caching allocator in the Python host);
+ *   - return value: 0 = ok, <0 = ANYV2V_E* (message via anyv2v_last_error()), >0 = hipError_t.
+ */
+#ifndef ANYV2V_HIP_H
+#define ANYV2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANYV2V_OK 0
+#define ANYV2V_EINVAL (-1)   /* bad shape / alignment / null pointer            */
+#define ANYV2V_EUNSUPPORTED (-2) /* shape outside what the fast kernels cover   */
+
+/* ---- gather-GEMM ------------------------------------------------------------------------------
+ * C[m, n] = epilogue( sum_{tap} sum_{k<K} A[row(m,tap), k] * W[n, tap*K + k] ),  fp16 in, fp32 acc.
+ * A is the channel-concatenation [A0 | A1] (K = C0 + C1) -- the skip `torch.cat` of the up blocks
+ * folded into the K loop.
+ *   mode 0  LINEAR    : 1 tap, row = m.                     torch Linear / 1x1 conv
+ *                       (attn.to_q/to_k/to_v/to_out[0]  i2vgen-xl/pnp_utils.py:175,182-183,216;
+ *                        conv_shortcut pnp_utils.py:117-122; time_emb_proj pnp_utils.py:81-88)
+ *   mode 1  CONV2D3x3 : 9 taps, pad 1, stride 1|2, optional nearest x2 upsample folded into the gather
+ *                       (conv1/conv2 pnp_utils.py:78,107; Upsample2D/Downsample2D pnp_utils.py:51-76)
+ *   mode 2  TEMPORAL3 : 3 taps along the frame axis, pad 1 (Conv3d (3,1,1) of TemporalConvLayer;
+ *                       consisti2v/consisti2v/models/videoldm_unet_blocks.py:316-328)
+ * epilogue: + bias[n]; + rowvec[(m / rowvec_div) * ldrv + n] (the temb broadcast pnp_utils.py:91-92);
+ *           act: 0 none, 1 SiLU, 2 GELU(erf), 3 GEGLU (W packed [16 x h | 16 x gate] per 32 rows, out N/2);
+ *           + R[m, n] (residual, pnp_utils.py:124); store fp16.
+ */
+typedef struct AnyV2VGemmDesc {
+    const void* A0;
+    const void* A1;      /* may be NULL when C1 == 0 */
+    const void* W;       /* [N][taps*(C0+C1)] */
+    void* C;
+    const void* bias;    /* [N] or NULL */
+    const void* rowvec;  /* [M/rowvec_div][ldrv] or NULL */
+    const void* R;       /* [M][ldr] or NULL */
+    int32_t M, N;
+    int32_t C0, C1;
+    int32_t lda0, lda1, ldc, ldr, ldrv, rowvec_div;
+    int32_t mode;
+    int32_t Hi, Wi, Ho, Wo, stride, up; /* mode 1 */
+    int32_t F, HW;                      /* mode 2: frames per clip, pixels per frame */
+    int32_t act;
+    int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging */
+} AnyV2VGemmDesc;
+
+int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------
+ * GroupNorm over channels-last tokens, optionally fused SiLU, input = channel concat [X0 | X1].
+ * Statistics are taken over `rows_per_group` consecutive rows x (C/G) channels: rows_per_group = H*W
+ * gives the 4-D per-frame GroupNorm (ResnetBlock2D.norm1/norm2 pnp_utils.py:48,104; Transformer2DModel.norm),
+ * rows_per_group = F*H*W the 5-D per-clip one (TemporalConvLayer, TransformerTemporalModel.norm).
+ * `stats` is caller-provided scratch of (M/rows_per_group)*G*2 floats.
+ */
+int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y, const void* gamma,
+                         const void* beta, float* stats, int32_t M, int32_t rows_per_group, int32_t G, float eps,
+                         int32_t silu, void* stream);
+
+/* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3). */
+int anyv2v_layernorm_f16(const void* X, void* Y, const void* gamma, const void* beta, int32_t M, int32_t C,
+                         float eps, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------
+ * softmax(Q K^T / sqrt(64)) V for head_dim 64, no mask -- F.scaled_dot_product_attention at
+ * i2vgen-xl/pnp_utils.py:208-210 (spatial) and :314-316 (temporal).
+ * Batch element i (0 <= i < batch), sequence position s, head h address row
+ *     row = (i / inner) * outer_stride + (i % inner) * inner_stride + s * seq_stride
+ * of a token matrix with leading dim ld; head h occupies columns [64 h, 64 h + 64).
+ *   spatial : inner = 1,  outer_stride = S,    seq_stride = 1
+ *   temporal: inner = HW, outer_stride = F*HW, inner_stride = 1, seq_stride = HW   (no permute needed)
+ * K/V use batch index i / kv_div (cross-attention: all F frames of a clip share one K/V).
+ * PnP injection (pnp_utils.py:189-196, :295-302): qk_mod > 0 makes Q and K of batch element i come
+ * from element i % qk_mod (the source branch) -- aliasing instead of the reference's copies.
+ */
+typedef struct AnyV2VAttnDesc {
+    const void* Q;
+    const void* K;
+    const void* V;
+    void* O;
+    int32_t ldq, ldk, ldv, ldo;
+    int32_t batch, heads, Sq, Sk;
+    int32_t inner;
+    int64_t q_outer, q_inner, q_seq;     /* strides in rows */
+    int64_t kv_outer, kv_inner, kv_seq;
+    int32_t kv_div;
+    int32_t qk_mod;
+    float scale;
+    int32_t flags;      /* bit0: force the naive reference kernel */
+} AnyV2VAttnDesc;
+
+int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);
+
+/* Small generic attention (any head_dim <= 64, one thread per (batch, head, query)); used once per clip
+ * for image_latents_temporal_encoder (2 heads x dim 4). Same addressing as above with explicit head_dim. */
+int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream);
+
+/* ---- elementwise / layout --------------------------------------------------------------------- */
+/* y = silu(x) (n elements) */
+int anyv2v_silu_f16(const void* X, void* Y, int64_t n, void* stream);
+/* y = a + b */
+int anyv2v_add_f16(const void* A, const void* B, void* Y, int64_t n, void* stream);
+/* sinusoidal timestep embedding, flip_sin_to_cos, freq shift 0: out[b, :] = [cos(t_b w) | sin(t_b w)] */
+int anyv2v_timestep_embedding_f16(const float* t, void* out, int32_t B, int32_t dim, void* stream);
+/* [B, C, F, H, W] (NCFHW, the pipeline's latent layout) -> tokens [(B F) (H W), ldy] at column col0 */
+int anyv2v_ncfhw_to_tokens_f16(const void* X, void* Y, int32_t B, int32_t C, int32_t F, int32_t HW, int32_t ldy,
+                               int32_t col0, void* stream);
+int anyv2v_tokens_to_ncfhw_f16(const void* X, void* Y, int32_t B, int32_t C, int32_t F, int32_t HW, int32_t ldx,
+                               int32_t col0, void* stream);
+/* AdaptiveAvgPool2d over channels-last tokens [N, Hi, Wi, C] -> [N, Ho, Wo, C] */
+int anyv2v_adaptive_avgpool_f16(const void* X, void* Y, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                int32_t C, void* stream);
+/* rows copy with column window: Y[m, ycol0 : ycol0+C] = X[m, xcol0 : xcol0+C] */
+int anyv2v_copy_cols_f16(const void* X, int32_t ldx, int32_t xcol0, void* Y, int32_t ldy, int32_t ycol0, int64_t M,
+                         int32_t C, void* stream);
+
+/* Fused classifier-free-guidance combine + DDIM step (eta = 0, v-prediction), reading the UNet's
+ * channels-last v-prediction tokens directly and updating NCFHW latents in place:
+ *   v = v_unc + g * (v_cond - v_unc)                              pipeline_i2vgen_xl.py:1160-1162
+ *   x0 = sa_t x - sb_t v ; eps = sa_t v + sb_t x ; x' = sa_p x0 + sb_p eps   (DDIMScheduler.step, :1173;
+ *   inverse: consisti2v/ddim_inverse_scheduler.py:329-369 -- same formula, different alphas)
+ * Vtok: [(nb F) HW, ldv] tokens; branch `b_unc` / `b_cond` select the batch slices (b_unc < 0: no CFG).
+ * coef: 4 floats on the device {sa_t, sb_t, sa_p, sb_p}.  lat/out: [1, C, F, H, W] fp16; out may alias lat.
+ */
+int anyv2v_cfg_ddim_step_f16(const void* Vtok, int32_t ldv, int32_t b_unc, int32_t b_cond, float guidance,
+                             const float* coef, const void* lat, void* out, int32_t C, int32_t F, int32_t HW,
+                             void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------------- */
+const char* anyv2v_last_error(void);
+int anyv2v_version(void);
+/* MFMA / LDS layout self-test used by the gpu test-suite (returns 0 when the layouts the kernels assume hold) */
+int anyv2v_selftest(void* scratch, int64_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANYV2V_HIP_H */

@@ -1,0 +1,103 @@
+"""Import the REFERENCE's own python files in this container (TEST INFRASTRUCTURE).
+
+``/root/reference/i2vgen-xl/pnp_utils.py`` and
+``/root/reference/consisti2v/ddim_inverse_scheduler.py`` import a handful of symbols
+from packages that are not installed here (``torchvision``, ``diffusers``).  This
+module puts minimal stand-ins for exactly those symbols into ``sys.modules`` and then
+imports the reference files *unmodified* from where they lie.  Used only to pin the
+oracle / generate ``tests/golden`` fixtures; ``/root/reference`` does not exist on the
+GPU box, so nothing on the ``-m gpu`` path calls this.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("ANYV2V_REFERENCE", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "i2vgen-xl", "pnp_utils.py"))
+
+
+def _mod(name: str, **attrs):
+    m = sys.modules.get(name)
+    if m is None:
+        m = types.ModuleType(name)
+        m.__path__ = []  # behave like a package
+        sys.modules[name] = m
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+def install_stubs():
+    from oracle import unet_oracle as uo
+
+    _mod("torchvision")
+    _mod("torchvision.transforms")
+    _mod("torchvision.io", read_video=None, write_video=None)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].io = sys.modules["torchvision.io"]
+
+    class ConfigMixin:
+        config_name = "scheduler_config.json"
+
+    def register_to_config(init):
+        import functools
+        import inspect
+
+        @functools.wraps(init)
+        def wrapper(self, *a, **kw):
+            sig = inspect.signature(init)
+            bound = sig.bind(self, *a, **kw)
+            bound.apply_defaults()
+            cfg = {k: v for k, v in bound.arguments.items() if k not in ("self", "kwargs")}
+            self.config = types.SimpleNamespace(**cfg)
+            init(self, *a, **kw)
+        return wrapper
+
+    class SchedulerMixin:
+        pass
+
+    class BaseOutput:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    import dataclasses
+
+    def _baseoutput_dc(cls):
+        return cls
+
+    _mod("diffusers")
+    _mod("diffusers.utils", USE_PEFT_BACKEND=True, BaseOutput=object, deprecate=lambda *a, **k: None)
+    _mod("diffusers.models")
+    _mod("diffusers.models.upsampling", Upsample2D=uo.Upsample2D)
+    _mod("diffusers.models.downsampling", Downsample2D=uo.Downsample2D)
+    _mod("diffusers.models.attention_processor", AttnProcessor2_0=uo.AttnProcessor2_0)
+    _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    _mod("diffusers.schedulers")
+    _mod("diffusers.schedulers.scheduling_utils", SchedulerMixin=SchedulerMixin,
+         KarrasDiffusionSchedulers=[])
+    _mod("diffusers.utils.torch_utils", randn_tensor=None)
+
+
+def _load(path: str, name: str):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference_pnp_utils():
+    """The reference's ``i2vgen-xl/pnp_utils.py``, verbatim."""
+    install_stubs()
+    return _load(os.path.join(REFERENCE_ROOT, "i2vgen-xl", "pnp_utils.py"), "_ref_pnp_utils")
+
+
+def load_reference_inverse_scheduler():
+    """The reference's vendored ``consisti2v/ddim_inverse_scheduler.py``, verbatim."""
+    install_stubs()
+    return _load(os.path.join(REFERENCE_ROOT, "consisti2v", "ddim_inverse_scheduler.py"), "_ref_ddim_inverse")
