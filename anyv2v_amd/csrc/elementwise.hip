@@ -109,6 +109,16 @@ __global__ void cfg_ddim_step_kernel(const half_t* __restrict__ V, int ldv, int 
     }
 }
 
+__global__ void ddim_step_kernel(const half_t* __restrict__ V, const half_t* __restrict__ X, half_t* __restrict__ Y,
+                                 float sa_t, float sb_t, float sa_p, float sb_p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = (float)V[i], x = (float)X[i];
+        const float x0 = sa_t * x - sb_t * v;
+        const float eps = sa_t * v + sb_t * x;
+        Y[i] = (half_t)(sa_p * x0 + sb_p * eps);
+    }
+}
+
 static inline unsigned nblk(long long n, int t, long long cap = 65535) {
     long long b = (n + t - 1) / t;
     if (b < 1) b = 1;
@@ -180,6 +190,14 @@ extern "C" int anyv2v_cfg_ddim_step_f16(const void* Vtok, int32_t ldv, int32_t b
                        (hipStream_t)stream, (const half_t*)Vtok, ldv, b_unc, b_cond, guidance, coef, (const half_t*)lat,
                        (half_t*)out, C, F, HW);
     return av_launch_status("cfg_ddim_step");
+}
+
+extern "C" int anyv2v_ddim_step_f16(const void* V, const void* X, void* Y, float sa_t, float sb_t, float sa_p,
+                                    float sb_p, int64_t n, void* stream) {
+    AV_CHECK(V && X && Y && n > 0, "ddim_step: bad arguments");
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const half_t*)V,
+                       (const half_t*)X, (half_t*)Y, sa_t, sb_t, sa_p, sb_p, (long long)n);
+    return av_launch_status("ddim_step");
 }
 
 // ---------------------------------------------------------------------------------------------------------

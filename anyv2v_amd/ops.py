@@ -1,0 +1,230 @@
+"""Thin torch-tensor -> C-ABI wrappers.  Torch is plumbing only (device memory + current stream)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, GemmDesc
+
+MODE_LINEAR, MODE_CONV2D, MODE_TEMPORAL = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
+
+# global knobs (tests flip them to cross-check kernel variants)
+FORCE_NAIVE = False   # route GEMM / attention through the reference-grade kernels
+USE_GLDS = False      # LDS-DMA staging variant of the GEMM
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rowmajor(t: torch.Tensor, name: str):
+    assert t.dim() == 2 and t.stride(1) == 1, f"{name}: need a 2-D row-major (stride(1)==1) fp16 view, got {tuple(t.shape)} {t.stride()}"
+    assert t.dtype == torch.float16, f"{name}: fp16 expected, got {t.dtype}"
+    assert t.is_cuda, f"{name}: device tensor expected"
+
+
+def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowvec=None,
+         rowvec_div: int = 0, residual=None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+         mode: int = MODE_LINEAR, conv=None, temporal=None, M: Optional[int] = None, naive: bool = False):
+    """out[M, N'] = epilogue(gather(A) @ W^T).  ``w`` is [N, taps*K] packed (see anyv2v_hip.h).
+
+    conv = (Hi, Wi, Ho, Wo, stride, up) for MODE_CONV2D; temporal = (F, HW) for MODE_TEMPORAL.
+    ``M`` overrides the row count (output rows); A may have a different number of rows for convs.
+    """
+    lib = _lib.load()
+    _rowmajor(a0, "A0")
+    _rowmajor(w, "W")
+    C0 = a0.shape[1]
+    C1 = 0
+    if a1 is not None:
+        _rowmajor(a1, "A1")
+        C1 = a1.shape[1]
+    taps = 1 if mode == MODE_LINEAR else (9 if mode == MODE_CONV2D else 3)
+    N = w.shape[0]
+    assert w.shape[1] == taps * (C0 + C1), f"W is {tuple(w.shape)}, expected [{N}, {taps}*({C0}+{C1})]"
+    assert w.stride(0) == w.shape[1], "W must be contiguous"
+    if M is None:
+        M = a0.shape[0]
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=a0.device)
+    _rowmajor(out, "C")
+    assert out.shape[0] >= M and out.shape[1] >= n_out
+    d = GemmDesc()
+    d.A0, d.A1, d.W, d.C = _p(a0), _p(a1), _p(w), _p(out)
+    d.bias, d.rowvec, d.R = _p(bias), _p(rowvec), _p(residual)
+    d.M, d.N, d.C0, d.C1 = M, N, C0, C1
+    d.lda0 = a0.stride(0)
+    d.lda1 = a1.stride(0) if a1 is not None else 0
+    d.ldc = out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.ldrv = rowvec.stride(0) if rowvec is not None else 0
+    d.rowvec_div = rowvec_div
+    d.mode = mode
+    if mode == MODE_CONV2D:
+        d.Hi, d.Wi, d.Ho, d.Wo, d.stride, d.up = conv
+    elif mode == MODE_TEMPORAL:
+        d.F, d.HW = temporal
+    d.act = act
+    d.flags = (1 if (naive or FORCE_NAIVE) else 0) | (2 if USE_GLDS else 0)
+    _lib.check(lib.anyv2v_gemm_f16(C.byref(d), _stream()), "anyv2v_gemm_f16")
+    return out
+
+
+def groupnorm(x0: torch.Tensor, gamma, beta, stats: torch.Tensor, rows_per_group: int, *, x1=None, groups: int = 32,
+              eps: float = 1e-5, silu: bool = False, out=None):
+    lib = _lib.load()
+    _rowmajor(x0, "X0")
+    assert x0.is_contiguous()
+    M, C0 = x0.shape
+    C1 = 0
+    if x1 is not None:
+        _rowmajor(x1, "X1")
+        assert x1.is_contiguous() and x1.shape[0] == M
+        C1 = x1.shape[1]
+    if out is None:
+        out = torch.empty((M, C0 + C1), dtype=torch.float16, device=x0.device)
+    assert out.is_contiguous()
+    need = (M // rows_per_group) * groups * 2
+    assert stats.dtype == torch.float32 and stats.numel() >= need
+    _lib.check(lib.anyv2v_groupnorm_f16(_p(x0), _p(x1), C0, C1, _p(out), _p(gamma), _p(beta), _p(stats), M,
+                                        rows_per_group, groups, eps, int(silu), _stream()), "anyv2v_groupnorm_f16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5, out=None):
+    lib = _lib.load()
+    _rowmajor(x, "X")
+    assert x.is_contiguous()
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.anyv2v_layernorm_f16(_p(x), _p(out), _p(gamma), _p(beta), M, Cc, eps, _stream()), "anyv2v_layernorm_f16")
+    return out
+
+
+def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_strides, kv_div=1, qk_mod=0,
+              scale=0.125, head_dim=64, naive=False):
+    """Strided multi-head attention over token matrices; see anyv2v_hip.h for the addressing."""
+    lib = _lib.load()
+    for t, n in ((q, "Q"), (k, "K"), (v, "V"), (out, "O")):
+        _rowmajor(t, n)
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = _p(q), _p(k), _p(v), _p(out)
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.batch, d.heads, d.Sq, d.Sk, d.inner = batch, heads, Sq, Sk, inner
+    d.q_outer, d.q_inner, d.q_seq = q_strides
+    d.kv_outer, d.kv_inner, d.kv_seq = kv_strides
+    d.kv_div, d.qk_mod, d.scale = kv_div, qk_mod, scale
+    d.flags = 1 if (naive or FORCE_NAIVE) else 0
+    if head_dim == 64:
+        _lib.check(lib.anyv2v_attention_f16(C.byref(d), _stream()), "anyv2v_attention_f16")
+    else:
+        _lib.check(lib.anyv2v_attention_small_f16(C.byref(d), head_dim, _stream()), "anyv2v_attention_small_f16")
+    return out
+
+
+def silu(x: torch.Tensor, out=None):
+    lib = _lib.load()
+    assert x.is_contiguous() and x.dtype == torch.float16
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.anyv2v_silu_f16(_p(x), _p(out), x.numel(), _stream()), "anyv2v_silu_f16")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out=None):
+    lib = _lib.load()
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(lib.anyv2v_add_f16(_p(a), _p(b), _p(out), a.numel(), _stream()), "anyv2v_add_f16")
+    return out
+
+
+def timestep_embedding(t_f32: torch.Tensor, dim: int, out=None):
+    lib = _lib.load()
+    assert t_f32.dtype == torch.float32 and t_f32.is_contiguous()
+    B = t_f32.numel()
+    if out is None:
+        out = torch.empty((B, dim), dtype=torch.float16, device=t_f32.device)
+    _lib.check(lib.anyv2v_timestep_embedding_f16(_p(t_f32), _p(out), B, dim, _stream()), "anyv2v_timestep_embedding_f16")
+    return out
+
+
+def ncfhw_to_tokens(x: torch.Tensor, out: torch.Tensor, col0: int = 0):
+    lib = _lib.load()
+    B, Cc, F, H, W = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float16
+    _rowmajor(out, "Y")
+    _lib.check(lib.anyv2v_ncfhw_to_tokens_f16(_p(x), _p(out), B, Cc, F, H * W, out.stride(0), col0, _stream()),
+               "anyv2v_ncfhw_to_tokens_f16")
+    return out
+
+
+def tokens_to_ncfhw(x: torch.Tensor, B: int, Cc: int, F: int, H: int, W: int, col0: int = 0, out=None):
+    lib = _lib.load()
+    _rowmajor(x, "X")
+    if out is None:
+        out = torch.empty((B, Cc, F, H, W), dtype=torch.float16, device=x.device)
+    _lib.check(lib.anyv2v_tokens_to_ncfhw_f16(_p(x), _p(out), B, Cc, F, H * W, x.stride(0), col0, _stream()),
+               "anyv2v_tokens_to_ncfhw_f16")
+    return out
+
+
+def adaptive_avgpool(x: torch.Tensor, N: int, Hi: int, Wi: int, Ho: int, Wo: int):
+    lib = _lib.load()
+    _rowmajor(x, "X")
+    assert x.is_contiguous()
+    Cc = x.shape[1]
+    out = torch.empty((N * Ho * Wo, Cc), dtype=torch.float16, device=x.device)
+    _lib.check(lib.anyv2v_adaptive_avgpool_f16(_p(x), _p(out), N, Hi, Wi, Ho, Wo, Cc, _stream()), "anyv2v_adaptive_avgpool_f16")
+    return out
+
+
+def copy_cols(x: torch.Tensor, xcol0: int, y: torch.Tensor, ycol0: int, ncols: int):
+    lib = _lib.load()
+    _rowmajor(x, "X")
+    _rowmajor(y, "Y")
+    assert x.shape[0] == y.shape[0]
+    _lib.check(lib.anyv2v_copy_cols_f16(_p(x), x.stride(0), xcol0, _p(y), y.stride(0), ycol0, x.shape[0], ncols, _stream()),
+               "anyv2v_copy_cols_f16")
+    return y
+
+
+def cfg_ddim_step(vtok: torch.Tensor, b_unc: int, b_cond: int, guidance: float, coef: torch.Tensor,
+                  lat: torch.Tensor, out: torch.Tensor):
+    """lat/out: [1, C, F, H, W] fp16; vtok: [(nb F) HW, ld] channels-last v-prediction; coef: 4 device floats."""
+    lib = _lib.load()
+    _rowmajor(vtok, "V")
+    assert lat.is_contiguous() and out.is_contiguous() and lat.dtype == torch.float16 and lat.shape[0] == 1
+    assert coef.dtype == torch.float32 and coef.numel() >= 4
+    _, Cc, F, H, W = lat.shape
+    _lib.check(lib.anyv2v_cfg_ddim_step_f16(_p(vtok), vtok.stride(0), b_unc, b_cond, float(guidance), _p(coef), _p(lat),
+                                            _p(out), Cc, F, H * W, _stream()), "anyv2v_cfg_ddim_step_f16")
+    return out
+
+
+def ddim_step(v: torch.Tensor, x: torch.Tensor, sa_t: float, sb_t: float, sa_p: float, sb_p: float, out=None):
+    lib = _lib.load()
+    v = v.to(torch.float16).contiguous()
+    x = x.to(torch.float16).contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.anyv2v_ddim_step_f16(_p(v), _p(x), _p(out), sa_t, sb_t, sa_p, sb_p, x.numel(), _stream()),
+               "anyv2v_ddim_step_f16")
+    return out
+
+
+def selftest(scratch: torch.Tensor):
+    lib = _lib.load()
+    assert scratch.dtype == torch.uint8 and scratch.is_contiguous()
+    _lib.check(lib.anyv2v_selftest(_p(scratch), scratch.numel(), _stream()), "anyv2v_selftest")

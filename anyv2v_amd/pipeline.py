@@ -1,0 +1,465 @@
+"""``I2VGenXLPipeline`` with the reference's call surface (seam B5; ``i2vgen-xl/pipelines/pipeline_i2vgen_xl.py:133``):
+``from_pretrained``, ``.to``, ``register_modules``, ``encode_vae_video`` (:565), ``invert`` (:1197), ``__call__``
+(:652), ``sample_with_pnp`` (:892) -- driving the MI355X-native UNet.
+
+The three denoising loops (inversion :1385-1433, PnP sampling :1131-1179, CFG sampling :839-874) are the hot path.
+What changed relative to the reference, all exact:
+  * the inversion trajectory stays in HBM (``LatentTrajectory``); ``ddim_latents_{t}.pt`` files are still written
+    (background thread, after the loop) and still readable, but no step blocks on disk or H2D;
+  * no per-step ``t.item()`` sync: timesteps / DDIM coefficients live in small device tables;
+  * CFG combine + scheduler step + the two permutes are one kernel reading the UNet's channels-last output;
+  * a whole step (UNet forward + CFG/DDIM step) is captured once per injection state into a HIP graph and replayed.
+VAE / CLIP encoders are optional components: without them the pipeline takes precomputed
+``prompt_embeds`` / ``image_embeddings`` / ``image_latents`` and returns latents.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from . import ops, pnp_utils
+from .schedulers import DDIMInverseScheduler, DDIMScheduler
+from .unet import I2VGenXLUNet, I2VGenXLUNetConfig
+from .utils import LatentTrajectory, load_ddim_latents_at_t
+
+logger = logging.getLogger(__name__)
+
+
+class I2VGenXLPipelineOutput:
+    def __init__(self, frames):
+        self.frames = frames
+
+
+class StableVideoDiffusionInversionPipelineOutput:
+    def __init__(self, inverted_latents):
+        self.inverted_latents = inverted_latents
+
+
+def _use_graphs() -> bool:
+    return os.environ.get("ANYV2V_NO_GRAPH", "0") != "1"
+
+
+class _StepEngine:
+    """One denoising step = UNet forward on ``sample[B,4,F,h,w]`` + fused CFG/DDIM update of the latent slot.
+
+    ``sample`` is a static buffer: slot ``lat_slot`` (the last one) IS the latent being denoised and is updated in
+    place; ``dup_slots`` are re-filled from it after the update (CFG feeds the same latent twice); slot 0 of a PnP
+    step is overwritten by the caller with the source trajectory before each step.
+    """
+
+    def __init__(self, pipe, sample, cond, b_unc, b_cond, guidance, dup_slots):
+        self.pipe, self.unet = pipe, pipe.unet
+        self.sample = sample
+        self.cond = cond
+        self.b_unc, self.b_cond, self.guidance = b_unc, b_cond, float(guidance)
+        self.lat_slot = sample.shape[0] - 1
+        self.dup_slots = list(dup_slots)
+        self.coef = torch.zeros(4, dtype=torch.float32, device=sample.device)
+        self.graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        self.use_graphs = _use_graphs() and sample.is_cuda
+        B, _, F, H, W = sample.shape
+        unet = self.unet
+        if not unet._packed:
+            unet.pack()
+        self.ctx = unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
+                                      cond["image_embeddings"])
+
+    def _body(self):
+        vtok = self.unet._forward_core(self.ctx, self.sample)
+        L = self.lat_slot
+        lat = self.sample[L:L + 1]
+        ops.cfg_ddim_step(vtok, self.b_unc, self.b_cond, self.guidance, self.coef, lat, lat)
+        for s in self.dup_slots:
+            self.sample[s].copy_(self.sample[L])
+
+    def step(self, t_row: torch.Tensor, coef_row: torch.Tensor, key: tuple):
+        self.ctx.t_buf.copy_(t_row, non_blocking=True)
+        self.coef.copy_(coef_row, non_blocking=True)
+        if not self.use_graphs:
+            self._body()
+            return
+        g = self.graphs.get(key)
+        if g is None:
+            # warm up eagerly on the side (pure: the UNet forward does not touch the latents), then capture
+            self.unet._forward_core(self.ctx, self.sample)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self.graphs[key] = g
+            # capture does not execute: fall through to the replay below
+        g.replay()
+
+
+class I2VGenXLPipeline:
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, image_encoder=None, feature_extractor=None,
+                 unet: Optional[I2VGenXLUNet] = None, scheduler=None):
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.image_encoder, self.feature_extractor = image_encoder, feature_extractor
+        self.unet, self.scheduler = unet, scheduler
+        self.vae_scale_factor = 8
+        self._guidance_scale = 1.0
+        self._device = torch.device("cpu")
+
+    # ------------------------------------------------------------------ construction / plumbing
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.float16, variant="fp16",
+                        unet_config: Optional[I2VGenXLUNetConfig] = None, random_init_seed: Optional[int] = None, **kw):
+        """Loads ``<path>/unet/diffusion_pytorch_model[.fp16].safetensors`` (diffusers key naming) when present.
+        There is no network here: for the hub id ``"ali-vilab/i2vgen-xl"`` without a local copy, random weights of
+        the exact architecture are used when ``random_init_seed`` (or ANYV2V_RANDOM_INIT_SEED) is given."""
+        if torch_dtype != torch.float16:
+            raise ValueError("the HIP kernels compute in fp16 (fp32 accumulate); torch_dtype must be torch.float16")
+        unet = I2VGenXLUNet(unet_config)
+        root = str(pretrained_model_name_or_path)
+        cands = [os.path.join(root, "unet", f"diffusion_pytorch_model.{variant}.safetensors"),
+                 os.path.join(root, "unet", "diffusion_pytorch_model.safetensors")]
+        path = next((c for c in cands if os.path.isfile(c)), None)
+        if path is not None:
+            from safetensors.torch import load_file
+            unet.load_state_dict(load_file(path), strict=True)
+        else:
+            seed = random_init_seed
+            if seed is None and os.environ.get("ANYV2V_RANDOM_INIT_SEED") is not None:
+                seed = int(os.environ["ANYV2V_RANDOM_INIT_SEED"])
+            if seed is None:
+                raise FileNotFoundError(
+                    f"no UNet weights under {root!r} (expected unet/diffusion_pytorch_model.{variant}.safetensors) and no "
+                    "network; pass random_init_seed= (or ANYV2V_RANDOM_INIT_SEED) to run with random weights")
+            unet._random_seed = seed
+        scheduler = DDIMScheduler.from_pretrained(root, subfolder="scheduler")
+        return cls(unet=unet, scheduler=scheduler)
+
+    def to(self, device):
+        device = torch.device(device)
+        self._device = device
+        self.unet.to(device)
+        seed = getattr(self.unet, "_random_seed", None)
+        if seed is not None:
+            init_random_weights_(self.unet, seed)
+            self.unet._random_seed = None
+        for m in (self.vae, self.text_encoder, self.image_encoder):
+            if m is not None and hasattr(m, "to"):
+                m.to(device)
+        return self
+
+    def register_modules(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def _execution_device(self):
+        return self._device
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1
+
+    def progress_bar(self, iterable=None, total=None):
+        return iterable
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    # ------------------------------------------------------------------ input checks (pipeline_i2vgen_xl.py:483-530)
+    def check_inputs(self, prompt, image, height, width, negative_prompt=None, prompt_embeds=None,
+                     negative_prompt_embeds=None):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                             " only forward one of the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        elif prompt is not None and (not isinstance(prompt, str) and not isinstance(prompt, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `negative_prompt`: {negative_prompt} and `negative_prompt_embeds`:"
+                             f" {negative_prompt_embeds}. Please make sure to only forward one of the two.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None:
+            if prompt_embeds.shape != negative_prompt_embeds.shape:
+                raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
+                                 f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds`"
+                                 f" {negative_prompt_embeds.shape}.")
+
+    # ------------------------------------------------------------------ encoders (optional components, F1)
+    def _need(self, name):
+        m = getattr(self, name)
+        if m is None:
+            raise RuntimeError(
+                f"pipeline component `{name}` is not loaded (VAE/CLIP are outside the HIP hot path and no pretrained weights "
+                "exist offline); pass the precomputed tensors instead (prompt_embeds / negative_prompt_embeds / "
+                "image_embeddings / image_latents / latents, output_type='latent')")
+        return m
+
+    def encode_prompt(self, prompt, device, num_videos_per_prompt=1, negative_prompt=None, prompt_embeds=None,
+                      negative_prompt_embeds=None, lora_scale=None, clip_skip=None):
+        if prompt_embeds is None:
+            enc, tok = self._need("text_encoder"), self._need("tokenizer")
+            prompt_embeds = _clip_text(enc, tok, prompt, device, clip_skip)
+        if self.do_classifier_free_guidance and negative_prompt_embeds is None:
+            enc, tok = self._need("text_encoder"), self._need("tokenizer")
+            n = negative_prompt if negative_prompt is not None else ""
+            if isinstance(n, str):
+                n = [n] * prompt_embeds.shape[0]
+            negative_prompt_embeds = _clip_text(enc, tok, n, device, clip_skip)
+        return prompt_embeds, negative_prompt_embeds
+
+    def prepare_image_latents_from_first_frame_latent(self, first_latent, num_frames):
+        """``prepare_image_latents`` (:532-562) after the VAE: first-frame latent + (F-1) frame-position planes."""
+        il = first_latent.unsqueeze(2)  # [b,4,1,h,w]
+        planes = [torch.ones_like(il[:, :, :1]) * ((i + 1) / (num_frames - 1)) for i in range(num_frames - 1)]
+        if planes:
+            il = torch.cat([il] + planes, dim=2)
+        return il
+
+    def encode_vae_video(self, video, device, height=576, width=1024):
+        vae = self._need("vae")
+        return vae.encode_video(video, device, height, width)
+
+    def decode_latents(self, latents, decode_chunk_size=None):
+        vae = self._need("vae")
+        return vae.decode_video(latents, decode_chunk_size)
+
+    def prepare_latents(self, batch_size, num_channels_latents, num_frames, height, width, dtype, device, generator,
+                        latents=None):
+        shape = (batch_size, num_channels_latents, num_frames, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, dtype=torch.float32).to(device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    # ------------------------------------------------------------------ conditioning assembly
+    def _conditioning(self, prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
+                      negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents):
+        """Returns per-branch lists: cond branch tensors and (when CFG) uncond ones, following :1014-1101."""
+        device = self._execution_device
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, device, 1, negative_prompt, prompt_embeds=prompt_embeds,
+            negative_prompt_embeds=negative_prompt_embeds, clip_skip=clip_skip)
+        if image_embeddings is None:
+            image_embeddings = _clip_image(self._need("image_encoder"), self._need("feature_extractor"), image, width, device)
+        if image_latents is None:
+            first = self._need("vae").encode_image(image, device, height, width)
+            image_latents = self.prepare_image_latents_from_first_frame_latent(first, num_frames)
+        return (prompt_embeds.to(device, torch.float16), None if negative_prompt_embeds is None else
+                negative_prompt_embeds.to(device, torch.float16), image_embeddings.to(device, torch.float16),
+                image_latents.to(device, torch.float16))
+
+    # ------------------------------------------------------------------ A1: DDIM inversion (:1197-1451)
+    @torch.no_grad()
+    def invert(self, prompt=None, image=None, height: Optional[int] = 704, width: Optional[int] = 1280,
+               target_fps: Optional[int] = 16, num_frames: int = 16, num_inference_steps: int = 50,
+               guidance_scale: float = 9.0, negative_prompt=None, eta: float = 0.0, num_videos_per_prompt: Optional[int] = 1,
+               decode_chunk_size: Optional[int] = 1, generator=None, latents: Optional[torch.Tensor] = None,
+               prompt_embeds=None, negative_prompt_embeds=None, output_type: Optional[str] = "pil",
+               return_dict: bool = True, cross_attention_kwargs=None, clip_skip: Optional[int] = 1,
+               output_dir: Optional[str] = None, image_embeddings=None, image_latents=None,
+               return_trajectory: bool = False):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, image, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        device = self._execution_device
+        self._guidance_scale = guidance_scale
+        pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
+                                             negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
+        cfg_on = self.do_classifier_free_guidance
+        if cfg_on:  # [uncond, cond] (:1329-1337); zero negative image embedding (:437-439)
+            ehs = torch.cat([npe, pe])
+            ie_all = torch.cat([torch.zeros_like(ie), ie])
+            il_all = torch.cat([il, il])
+        else:
+            ehs, ie_all, il_all = pe, ie, il
+        nb = ehs.shape[0]
+        fps = torch.tensor([target_fps] * nb, device=device)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        latents = self.prepare_latents(1, self.unet.config.in_channels, num_frames, height, width, torch.float16, device,
+                                       generator, latents).to(torch.float16)
+        sample = latents.repeat(nb, 1, 1, 1, 1).contiguous()
+        cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
+                    image_embeddings=ie_all.contiguous())
+        eng = _StepEngine(self, sample, cond, b_unc=0 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
+                          dup_slots=range(nb - 1))
+        ts = [int(t) for t in timesteps.tolist()]
+        t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, nb).contiguous()
+        coef_table = self.scheduler.coefficient_table(ts, device)
+        traj = LatentTrajectory()
+        for i, t in enumerate(ts):
+            eng.step(t_table[i], coef_table[i], key=("inv",))
+            traj[t] = sample[nb - 1:nb].clone()
+        if output_dir is not None:
+            traj.save(output_dir)  # ddim_latents_{t}.pt, reference format, written in the background
+            logger.info(f"saving noisy latents for {len(ts)} timesteps to {output_dir}")
+        self._last_trajectory = traj
+        inverted = torch.stack([traj[t] for t in reversed(ts)], 1)  # [1, n, 4, F, h, w] (:1436)
+        if return_trajectory:
+            return traj
+        if not return_dict:
+            return inverted
+        return StableVideoDiffusionInversionPipelineOutput(inverted_latents=inverted)
+
+    # ------------------------------------------------------------------ A3: plain CFG sampling (:652-888)
+    @torch.no_grad()
+    def __call__(self, prompt=None, image=None, height: Optional[int] = 704, width: Optional[int] = 1280,
+                 target_fps: Optional[int] = 16, num_frames: int = 16, num_inference_steps: int = 50,
+                 guidance_scale: float = 9.0, negative_prompt=None, eta: float = 0.0, num_videos_per_prompt: Optional[int] = 1,
+                 decode_chunk_size: Optional[int] = 1, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds=None, negative_prompt_embeds=None, output_type: Optional[str] = "pil",
+                 return_dict: bool = True, cross_attention_kwargs=None, clip_skip: Optional[int] = 1,
+                 ddim_init_latents_t_idx: Optional[int] = 1, image_embeddings=None, image_latents=None):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, image, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        device = self._execution_device
+        self._guidance_scale = guidance_scale
+        pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
+                                             negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
+        cfg_on = self.do_classifier_free_guidance
+        if cfg_on:
+            ehs, ie_all, il_all = torch.cat([npe, pe]), torch.cat([torch.zeros_like(ie), ie]), torch.cat([il, il])
+        else:
+            ehs, ie_all, il_all = pe, ie, il
+        nb = ehs.shape[0]
+        fps = torch.tensor([target_fps] * nb, device=device)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]  # :813
+        ts = [int(t) for t in self.scheduler.timesteps.tolist()]
+        latents = self.prepare_latents(1, self.unet.config.in_channels, num_frames, height, width, torch.float16, device,
+                                       generator, latents).to(torch.float16)
+        sample = latents.repeat(nb, 1, 1, 1, 1).contiguous()
+        cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
+                    image_embeddings=ie_all.contiguous())
+        eng = _StepEngine(self, sample, cond, b_unc=0 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
+                          dup_slots=range(nb - 1))
+        t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, nb).contiguous()
+        coef_table = self.scheduler.coefficient_table(ts, device)
+        for i, t in enumerate(ts):
+            eng.step(t_table[i], coef_table[i], key=("cfg",))
+        return self._finish(sample[nb - 1:nb].clone(), output_type, decode_chunk_size, return_dict)
+
+    # ------------------------------------------------------------------ A2: PnP edit (:892-1193)
+    @torch.no_grad()
+    def sample_with_pnp(self, prompt=None, image=None, height: Optional[int] = 704, width: Optional[int] = 1280,
+                        target_fps: Optional[int] = 16, num_frames: int = 16, num_inference_steps: int = 50,
+                        guidance_scale: float = 9.0, negative_prompt=None, eta: float = 0.0,
+                        num_videos_per_prompt: Optional[int] = 1, decode_chunk_size: Optional[int] = 1, generator=None,
+                        latents: Optional[torch.Tensor] = None, prompt_embeds=None, negative_prompt_embeds=None,
+                        output_type: Optional[str] = "pil", return_dict: bool = True, cross_attention_kwargs=None,
+                        clip_skip: Optional[int] = 1, ddim_init_latents_t_idx: Optional[int] = 1,
+                        ddim_inv_latents_path: Union[str, LatentTrajectory, None] = None, ddim_inv_prompt=None,
+                        ddim_inv_1st_frame=None, image_embeddings=None, image_latents=None,
+                        ddim_inv_prompt_embeds=None, ddim_inv_image_embeddings=None, ddim_inv_image_latents=None):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, image, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        if isinstance(prompt, list):
+            assert len(ddim_inv_prompt) == len(prompt)  # :1000
+        device = self._execution_device
+        self._guidance_scale = guidance_scale
+        pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
+                                             negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
+        # source (ddim inversion) branch: its own prompt, first frame, positive image embedding (:1027-1091)
+        if ddim_inv_prompt_embeds is None:
+            ddim_inv_prompt_embeds = _clip_text(self._need("text_encoder"), self._need("tokenizer"), ddim_inv_prompt,
+                                                device, clip_skip)
+        if ddim_inv_image_embeddings is None:
+            ddim_inv_image_embeddings = _clip_image(self._need("image_encoder"), self._need("feature_extractor"),
+                                                    ddim_inv_1st_frame, width, device)
+        if ddim_inv_image_latents is None:
+            first = self._need("vae").encode_image(ddim_inv_1st_frame, device, height, width)
+            ddim_inv_image_latents = self.prepare_image_latents_from_first_frame_latent(first, num_frames)
+        spe = ddim_inv_prompt_embeds.to(device, torch.float16)
+        sie = ddim_inv_image_embeddings.to(device, torch.float16)
+        sil = ddim_inv_image_latents.to(device, torch.float16)
+        cfg_on = self.do_classifier_free_guidance
+        if cfg_on:  # order: [ddim_inversion, negative, editing] (:1044,1093-1094)
+            ehs = torch.cat([spe, npe, pe])
+            ie_all = torch.cat([sie, torch.zeros_like(ie), ie])
+            il_all = torch.cat([sil, il, il])
+        else:
+            ehs, ie_all, il_all = torch.cat([spe, pe]), torch.cat([sie, ie]), torch.cat([sil, il])
+        nb = ehs.shape[0]
+        fps = torch.tensor([target_fps] * nb, device=device)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]  # :1105
+        ts = [int(t) for t in self.scheduler.timesteps.tolist()]
+        latents = self.prepare_latents(1, self.unet.config.in_channels, num_frames, height, width, torch.float16, device,
+                                       generator, latents).to(torch.float16)
+        sample = latents.repeat(nb, 1, 1, 1, 1).contiguous()
+        cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
+                    image_embeddings=ie_all.contiguous())
+        eng = _StepEngine(self, sample, cond, b_unc=1 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
+                          dup_slots=range(1, nb - 1))
+        # source trajectory resident in HBM (in-memory hand-off from invert(), or read once from the reference's files)
+        if isinstance(ddim_inv_latents_path, LatentTrajectory):
+            traj = ddim_inv_latents_path
+        else:
+            traj = LatentTrajectory.load(ddim_inv_latents_path, device=device, timesteps=ts)
+        t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, nb).contiguous()
+        coef_table = self.scheduler.coefficient_table(ts, device)
+        for i, t in enumerate(ts):
+            sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)
+            pnp_utils.register_time(self, t)  # host-side only: python int, no device sync (:1143)
+            eng.step(t_table[i], coef_table[i], key=("pnp",) + pnp_utils.injection_state(self))
+        return self._finish(sample[nb - 1:nb].clone(), output_type, decode_chunk_size, return_dict)
+
+    def _finish(self, latents, output_type, decode_chunk_size, return_dict):
+        if output_type == "latent":
+            return I2VGenXLPipelineOutput(frames=latents)
+        video = self.decode_latents(latents, decode_chunk_size=decode_chunk_size)
+        frames = self._need("vae").to_pil(video) if output_type == "pil" else video
+        if not return_dict:
+            return (frames,)
+        return I2VGenXLPipelineOutput(frames=frames)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def init_random_weights_(unet: I2VGenXLUNet, seed: int):
+    """Random weights of the exact architecture, generated on the device (no pretrained weights offline).
+    N(0, 1/fan_in) matrices, N(0, 0.02) biases, N(1, 0.05) norm gains -- same law as oracle.random_state_dict."""
+    g = torch.Generator(device=unet.device).manual_seed(seed)
+    for name, p in unet.named_parameters():
+        shp = p.shape
+        if name.endswith(".bias"):
+            t = torch.randn(shp, generator=g, device=p.device) * 0.02
+        elif p.dim() == 1:
+            t = 1.0 + torch.randn(shp, generator=g, device=p.device) * 0.05
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = torch.randn(shp, generator=g, device=p.device) / (fan_in ** 0.5)
+        p.data.copy_(t.to(torch.float16))
+    unet._packed = False
+
+
+def _clip_text(text_encoder, tokenizer, prompt, device, clip_skip):
+    """``encode_prompt`` body (:286-334): CLIP text tower, ``clip_skip`` layers from the end + final LayerNorm."""
+    if isinstance(prompt, str):
+        prompt = [prompt]
+    ids = tokenizer(prompt, padding="max_length", max_length=tokenizer.model_max_length, truncation=True,
+                    return_tensors="pt").input_ids.to(device)
+    if clip_skip is None:
+        return text_encoder(ids)[0]
+    out = text_encoder(ids, output_hidden_states=True)
+    h = out[-1][-(clip_skip + 1)]
+    return text_encoder.text_model.final_layer_norm(h)
+
+
+def _clip_image(image_encoder, feature_extractor, image, width, device):
+    raise RuntimeError("CLIP image tower not available offline; pass image_embeddings= (SURVEY.md 8(f) F1)")

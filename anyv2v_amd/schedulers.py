@@ -1,0 +1,159 @@
+"""DDIM and inverse-DDIM schedulers with the diffusers call surface the reference relies on (seam B4):
+``set_timesteps(n, device=)``, assignable ``.timesteps``, ``scale_model_input``, ``step(...).prev_sample``,
+``init_noise_sigma``, ``order``, ``from_pretrained(repo, subfolder="scheduler")``
+(used at ``i2vgen-xl/run_group_ddim_inversion.py:92-100`` and ``pipeline_i2vgen_xl.py:812,868,1104,1173,1359,1418``).
+
+Numerics follow the vendored inverse scheduler ``consisti2v/ddim_inverse_scheduler.py`` (betas :72-90,
+zero-terminal-SNR rescale :94-127, timesteps :253-289, step :329-369) with the configuration the reference run
+logged at ``i2vgen-xl/demo.ipynb:1208-1226``.  The elementwise update itself runs in the HIP kernels
+(``anyv2v_ddim_step_f16``; or fused with CFG in ``anyv2v_cfg_ddim_step_f16`` on the fast path).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops
+
+I2VGEN_XL_SCHEDULER_CONFIG = dict(  # i2vgen-xl/demo.ipynb:1208-1226
+    num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="squaredcos_cap_v2",
+    trained_betas=None, clip_sample=False, clip_sample_range=1.0, set_alpha_to_one=True, steps_offset=1,
+    prediction_type="v_prediction", thresholding=False, dynamic_thresholding_ratio=0.995, sample_max_value=1.0,
+    timestep_spacing="leading", rescale_betas_zero_snr=True)
+
+
+def _cosine_betas(n: int, max_beta: float = 0.999) -> torch.Tensor:
+    t = np.arange(n + 1, dtype=np.float64) / n
+    abar = np.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+    return torch.tensor(np.minimum(1.0 - abar[1:] / abar[:-1], max_beta), dtype=torch.float32)
+
+
+def _zero_terminal_snr(betas: torch.Tensor) -> torch.Tensor:
+    s = torch.cumprod(1.0 - betas, 0).sqrt()
+    s0, sT = s[0].clone(), s[-1].clone()
+    s = (s - sT) * (s0 / (s0 - sT))
+    abar = s ** 2
+    alphas = torch.cat([abar[:1], abar[1:] / abar[:-1]])
+    return 1.0 - alphas
+
+
+class SchedulerOutput:
+    def __init__(self, prev_sample, pred_original_sample=None):
+        self.prev_sample = prev_sample
+        self.pred_original_sample = pred_original_sample
+
+
+class _DDIMBase:
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, **kwargs):
+        cfg = dict(I2VGEN_XL_SCHEDULER_CONFIG)
+        cfg.update(kwargs)
+        self.config = SimpleNamespace(**cfg)
+        n = cfg["num_train_timesteps"]
+        if cfg["trained_betas"] is not None:
+            betas = torch.tensor(cfg["trained_betas"], dtype=torch.float32)
+        elif cfg["beta_schedule"] == "linear":
+            betas = torch.linspace(cfg["beta_start"], cfg["beta_end"], n, dtype=torch.float32)
+        elif cfg["beta_schedule"] == "scaled_linear":
+            betas = torch.linspace(cfg["beta_start"] ** 0.5, cfg["beta_end"] ** 0.5, n, dtype=torch.float32) ** 2
+        elif cfg["beta_schedule"] == "squaredcos_cap_v2":
+            betas = _cosine_betas(n)
+        else:
+            raise NotImplementedError(f"{cfg['beta_schedule']} is not implemented for {self.__class__}")
+        if cfg["rescale_betas_zero_snr"]:
+            betas = _zero_terminal_snr(betas)
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if cfg["set_alpha_to_one"] else self.alphas_cumprod[0]
+        self.initial_alpha_cumprod = self.final_alpha_cumprod
+        self.num_inference_steps = None
+        self.timesteps = torch.arange(n - 1, -1, -1, dtype=torch.int64)
+        if cfg["prediction_type"] != "v_prediction" or cfg["clip_sample"] or cfg["thresholding"]:
+            raise NotImplementedError("only the I2VGen-XL configuration (v_prediction, no clipping) is implemented")
+
+    @classmethod
+    def from_pretrained(cls, repo, subfolder=None, **kw):
+        """Offline loader: a local directory with ``scheduler_config.json`` if it exists, else the I2VGen-XL config."""
+        path = os.path.join(repo, subfolder or "", "scheduler_config.json")
+        cfg = {}
+        if os.path.isfile(path):
+            with open(path) as f:
+                cfg = {k: v for k, v in json.load(f).items() if k in I2VGEN_XL_SCHEDULER_CONFIG}
+        cfg.update(kw)
+        return cls(**cfg)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _ratio(self) -> int:
+        return self.config.num_train_timesteps // self.num_inference_steps
+
+    def _check_n(self, n):
+        if n > self.config.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {n} cannot be larger than `self.config.train_timesteps`:"
+                             f" {self.config.num_train_timesteps}")
+        if self.config.timestep_spacing != "leading":
+            raise NotImplementedError("only timestep_spacing='leading' is implemented")
+
+    def _abar(self, t: int) -> float:
+        return float(self.alphas_cumprod[t]) if t >= 0 else float(self.final_alpha_cumprod)
+
+    def coefficients(self, timestep: int):
+        raise NotImplementedError
+
+    def coefficient_table(self, timesteps, device) -> torch.Tensor:
+        """[len(timesteps), 4] fp32 device table {sqrt(a_t), sqrt(1-a_t), sqrt(a_p), sqrt(1-a_p)} for the fused step."""
+        rows = [self.coefficients(int(t)) for t in timesteps]
+        return torch.tensor(rows, dtype=torch.float32, device=device)
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output=False, generator=None,
+             variance_noise=None, return_dict: bool = True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if eta != 0.0:
+            raise NotImplementedError("eta > 0 (stochastic DDIM) is not used by AnyV2V and not implemented")
+        sa_t, sb_t, sa_p, sb_p = self.coefficients(int(timestep))
+        prev = ops.ddim_step(model_output, sample, sa_t, sb_t, sa_p, sb_p)
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev)
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+class DDIMScheduler(_DDIMBase):
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self._check_n(num_inference_steps)
+        self.num_inference_steps = num_inference_steps
+        r = self._ratio()
+        ts = (np.arange(0, num_inference_steps) * r).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts).to(device)
+
+    def coefficients(self, timestep: int):
+        prev = timestep - self._ratio()
+        a_t, a_p = self._abar(timestep), self._abar(prev)
+        return (math.sqrt(a_t), math.sqrt(1.0 - a_t), math.sqrt(a_p), math.sqrt(1.0 - a_p))
+
+
+class DDIMInverseScheduler(_DDIMBase):
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self._check_n(num_inference_steps)
+        self.num_inference_steps = num_inference_steps
+        r = self._ratio()
+        ts = (np.arange(0, num_inference_steps) * r).round().copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts).to(device)
+
+    def coefficients(self, timestep: int):
+        # the sample lives at level c = t - r (alpha 1.0 below 0); the step takes it to level t
+        cur = min(timestep - self._ratio(), self.config.num_train_timesteps - 1)
+        a_c, a_n = self._abar(cur), self._abar(timestep)
+        return (math.sqrt(a_c), math.sqrt(1.0 - a_c), math.sqrt(a_n), math.sqrt(1.0 - a_n))

@@ -1,0 +1,128 @@
+"""Seeding, latent-trajectory store and frame I/O with the reference's file formats
+(``i2vgen-xl/utils.py:17-79``; writer ``pipeline_i2vgen_xl.py:1424-1428``)."""
+from __future__ import annotations
+
+import glob
+import logging
+import os
+import random
+import threading
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from PIL import Image
+
+logger = logging.getLogger(__name__)
+
+
+def seed_everything(seed):
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+
+
+def load_ddim_latents_at_t(t, ddim_latents_path):
+    """``i2vgen-xl/utils.py:25-30``.  ``ddim_latents_path`` may also be an in-memory ``LatentTrajectory``."""
+    if isinstance(ddim_latents_path, LatentTrajectory):
+        return ddim_latents_path[int(t)]
+    ddim_latents_at_t_path = os.path.join(ddim_latents_path, f"ddim_latents_{int(t)}.pt")
+    assert os.path.exists(ddim_latents_at_t_path), f"Missing latents at t {t} path {ddim_latents_at_t_path}"
+    ddim_latents_at_t = torch.load(ddim_latents_at_t_path, map_location="cpu")
+    logger.debug(f"Loaded ddim_latents_at_t from {ddim_latents_at_t_path}")
+    return ddim_latents_at_t
+
+
+def load_ddim_latents_at_T(ddim_latents_path):
+    if isinstance(ddim_latents_path, LatentTrajectory):
+        return ddim_latents_path[max(ddim_latents_path.keys())]
+    noisest = max(int(x.split("_")[-1].split(".")[0])
+                  for x in glob.glob(os.path.join(ddim_latents_path, "ddim_latents_*.pt")))
+    return torch.load(os.path.join(ddim_latents_path, f"ddim_latents_{noisest}.pt"), map_location="cpu")
+
+
+class LatentTrajectory:
+    """The inversion trajectory {t: latents[1,4,F,h,w]} kept resident in HBM (25 MB for 50 steps at 16f x 512^2)
+    instead of the reference's blocking ``torch.save`` / ``torch.load`` round trip inside both hot loops.
+    ``save`` writes the reference's on-disk format (``ddim_latents_{t}.pt``) from a background thread."""
+
+    def __init__(self):
+        self._lat: Dict[int, torch.Tensor] = {}
+        self._writer: Optional[threading.Thread] = None
+
+    def __setitem__(self, t, x):
+        self._lat[int(t)] = x
+
+    def __getitem__(self, t):
+        t = int(t)
+        assert t in self._lat, f"Missing latents at t {t}"
+        return self._lat[t]
+
+    def __contains__(self, t):
+        return int(t) in self._lat
+
+    def keys(self):
+        return self._lat.keys()
+
+    def __len__(self):
+        return len(self._lat)
+
+    def save(self, output_dir: str, background: bool = True):
+        os.makedirs(output_dir, exist_ok=True)
+        host = {t: x.detach().to("cpu") for t, x in self._lat.items()}  # one sync for the whole trajectory
+
+        def work():
+            for t, x in host.items():
+                torch.save(x, os.path.join(output_dir, f"ddim_latents_{t}.pt"))
+
+        if background:
+            self._writer = threading.Thread(target=work, daemon=False)
+            self._writer.start()
+        else:
+            work()
+
+    def wait(self):
+        if self._writer is not None:
+            self._writer.join()
+            self._writer = None
+
+    @classmethod
+    def load(cls, ddim_latents_path: str, device=None, timesteps=None) -> "LatentTrajectory":
+        tr = cls()
+        if timesteps is None:
+            timesteps = [int(x.split("_")[-1].split(".")[0])
+                         for x in glob.glob(os.path.join(ddim_latents_path, "ddim_latents_*.pt"))]
+        for t in timesteps:
+            x = load_ddim_latents_at_t(int(t), ddim_latents_path)
+            tr[int(t)] = x.to(device) if device is not None else x
+        return tr
+
+
+def load_image(path) -> Image.Image:
+    img = Image.open(path)
+    return img.convert("RGB")
+
+
+def load_video_frames(frames_path, n_frames, image_size=(512, 512)):
+    """``i2vgen-xl/utils.py:70-79``."""
+    paths = [f"{frames_path}/%05d.png" % i for i in range(n_frames)]
+    frames = [load_image(p) for p in paths]
+    for f in frames:
+        if f.size != tuple(image_size):
+            logger.error(f"Frame size {f.size} does not match config.image_size {image_size}")
+            raise ValueError(f"Frame size {f.size} does not match config.image_size {image_size}")
+    return paths, frames
+
+
+def convert_video_to_frames(video_path, img_size=(512, 512), save_frames=True):
+    """``i2vgen-xl/utils.py:43-67`` needs an mp4 decoder (torchvision/ffmpeg), which this image does not ship."""
+    raise RuntimeError(f"cannot decode {video_path}: no video decoder available here (no torchvision/ffmpeg/cv2); "
+                       "provide the frames as a directory of %05d.png files")
+
+
+def export_to_gif(frames: List[Image.Image], path: str, fps: int = 8):
+    frames[0].save(path, save_all=True, append_images=frames[1:], optimize=False, duration=int(1000 / fps), loop=0)
+    return path

@@ -141,6 +141,11 @@ int anyv2v_cfg_ddim_step_f16(const void* Vtok, int32_t ldv, int32_t b_unc, int32
                              const float* coef, const void* lat, void* out, int32_t C, int32_t F, int32_t HW,
                              void* stream);
 
+/* Plain elementwise DDIM / inverse-DDIM step (eta = 0, v-prediction) on same-layout tensors:
+ * the generic `scheduler.step(model_output, t, sample).prev_sample` (pipeline_i2vgen_xl.py:868,1173,1418). */
+int anyv2v_ddim_step_f16(const void* V, const void* X, void* Y, float sa_t, float sb_t, float sa_p, float sb_p,
+                         int64_t n, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 const char* anyv2v_last_error(void);
 int anyv2v_version(void);

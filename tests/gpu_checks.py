@@ -1,0 +1,503 @@
+"""GPU parity checks shared by the pytest files (``-m gpu``) and ``tools/gpu_check.py`` (diagnostic report).
+
+Each check returns a dict(name=..., err=..., tol=..., ok=...).  Kernel-level checks compare the HIP kernels with
+plain PyTorch fp32 ops on the same fp16-rounded inputs; model-level checks compare with the CPU oracle
+(``oracle/``) and with the golden fixtures generated from the reference's own code (``tests/golden``).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from anyv2v_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor):
+    a, b = a.float(), b.float()
+    denom = b.abs().max().clamp_min(1e-6)
+    return float((a - b).abs().max() / denom), float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def _res(name, got, ref, tol):
+    if not torch.isfinite(got.float()).all():
+        return dict(name=name, err=float("nan"), l2=float("nan"), tol=tol, ok=False)
+    mx, l2 = _rel(got, ref)
+    return dict(name=name, err=mx, l2=l2, tol=tol, ok=bool(mx <= tol))
+
+
+def rnd(*shape, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) % 100000))
+    return (torch.randn(*shape, generator=g) * scale).to(torch.float16).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ layouts
+def check_selftest():
+    out = []
+    scratch = torch.zeros(16384, dtype=torch.uint8, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    A16 = torch.randint(-4, 5, (16, 32), generator=g).to(torch.float16)
+    B16 = torch.randint(-4, 5, (32, 16), generator=g).to(torch.float16)
+    A32 = torch.randint(-4, 5, (32, 16), generator=g).to(torch.float16)
+    B32 = torch.randint(-4, 5, (16, 32), generator=g).to(torch.float16)
+    host = scratch.cpu()
+    host[0:1024] = A16.view(torch.uint8).reshape(-1)
+    host[1024:2048] = B16.view(torch.uint8).reshape(-1)
+    host[3072:4096] = A32.view(torch.uint8).reshape(-1)
+    host[4096:5120] = B32.view(torch.uint8).reshape(-1)
+    scratch.copy_(host)
+    ops.selftest(scratch)
+    torch.cuda.synchronize()
+    h = scratch.cpu()
+    D16 = h[2048:3072].view(torch.float32).reshape(16, 16)
+    D32 = h[5120:9216].view(torch.float32).reshape(32, 32)
+    TR = h[9216:9728].view(torch.float16).reshape(64, 4)
+    out.append(_res("mfma_16x16x32_f16 layout", D16, A16.float() @ B16.float(), 0.0))
+    out.append(_res("mfma_32x32x16_f16 layout", D32, A32.float() @ B32.float(), 0.0))
+    # expected tr16 semantics: within each 16-lane group, out[c][j] = in[4 j + (c >> 2)][c & 3]; in[i][e] = 4 (16 g + i) + e
+    exp = torch.empty(64, 4)
+    for l in range(64):
+        gq, c = l // 16, l % 16
+        for j in range(4):
+            i = 4 * j + (c >> 2)
+            exp[l, j] = 4 * (16 * gq + i) + (c & 3)
+    r = _res("ds_read_b64_tr_b16 semantics (probe)", TR.float(), exp, 0.0)
+    r["dump"] = TR.float()[:20].tolist()
+    r["informational"] = True
+    out.append(r)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ gemm
+def _gemm_ref(a, w, bias=None, rowvec=None, rowvec_div=0, residual=None, act=0):
+    y = a.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    if rowvec is not None:
+        idx = torch.arange(y.shape[0], device=y.device) // rowvec_div
+        y = y + rowvec.float()[idx]
+    if act == ops.ACT_SILU:
+        y = F.silu(y)
+    elif act == ops.ACT_GELU:
+        y = F.gelu(y)
+    if residual is not None:
+        y = y + residual.float()
+    return y
+
+
+def check_gemm(variants=("reg", "glds", "naive")):
+    out = []
+    cases = [  # (M, N, K)
+        (300, 320, 320), (1000, 512, 512), (257, 64, 128), (128, 4, 320), (4096, 1280, 1280), (77, 640, 1024),
+    ]
+    for var in variants:
+        ops.USE_GLDS = var == "glds"
+        naive = var == "naive"
+        for (M, N, K) in cases:
+            a, w = rnd(M, K), rnd(N, K, scale=1 / math.sqrt(K))
+            bias, res = rnd(N), rnd(M, N)
+            rv = rnd((M + 49) // 50, N)
+            y = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=50, residual=res, naive=naive,
+                         out=torch.zeros(M, (N + 7) // 8 * 8, dtype=torch.float16, device=DEV))[:, :N]
+            out.append(_res(f"gemm[{var}] M{M} N{N} K{K} +bias+rowvec+res", y, _gemm_ref(a, w, bias, rv, 50, res), 4e-3))
+        # two sources + SiLU
+        a0, a1 = rnd(500, 128), rnd(500, 64)
+        w = rnd(320, 192, scale=0.1)
+        y = ops.gemm(a0, w, a1=a1, act=ops.ACT_SILU, naive=naive)
+        out.append(_res(f"gemm[{var}] two-source + silu", y, _gemm_ref(torch.cat([a0, a1], 1), w, act=ops.ACT_SILU), 4e-3))
+        # strided A / C views (column windows of wider buffers)
+        big = rnd(400, 960)
+        w = rnd(320, 320, scale=0.06)
+        dst = torch.zeros(400, 640, dtype=torch.float16, device=DEV)
+        ops.gemm(big[:, 320:640], w, out=dst[:, 320:], naive=naive)
+        out.append(_res(f"gemm[{var}] strided views", dst[:, 320:], _gemm_ref(big[:, 320:640], w), 4e-3))
+        # GEGLU
+        M, dim, inner = 333, 128, 512
+        a = rnd(M, dim)
+        wfull, bfull = rnd(2 * inner, dim, scale=1 / math.sqrt(dim)), rnd(2 * inner, scale=0.1)
+        wh, wg = wfull[:inner].view(inner // 16, 16, dim), wfull[inner:].view(inner // 16, 16, dim)
+        wp = torch.stack([wh, wg], 1).reshape(2 * inner, dim).contiguous()
+        bp = torch.stack([bfull[:inner].view(-1, 16), bfull[inner:].view(-1, 16)], 1).reshape(-1).contiguous()
+        y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU, naive=naive)
+        proj = a.float() @ wfull.float().t() + bfull.float()
+        ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+        out.append(_res(f"gemm[{var}] GEGLU", y, ref, 6e-3))
+    ops.USE_GLDS = False
+    return out
+
+
+def _to_tokens(x):  # NCHW -> [(n h w), c]
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
+
+
+def _pack_conv(w):  # [Co, Ci, 3, 3] -> [Co, 9*Ci]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def check_conv(variants=("reg", "glds", "naive")):
+    out = []
+    for var in variants:
+        ops.USE_GLDS = var == "glds"
+        naive = var == "naive"
+        # 3x3 stride 1 with bias + temb rowvec + residual
+        n, ci, co, H, W = 6, 64, 128, 12, 10
+        x, w, b = rnd(n, ci, H, W), rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
+        temb, res = rnd(3, co), rnd(n * H * W, co)
+        y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=2 * H * W, residual=res,
+                     mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0), naive=naive)
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+        ref = ref + temb.float().repeat_interleave(2, 0)[:, :, None, None]
+        ref = _to_tokens(ref) + res.float()
+        out.append(_res(f"conv3x3[{var}] s1 +bias+temb+res", y, ref, 4e-3))
+        # stride 2
+        Ho, Wo = H // 2, W // 2
+        y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, Ho, Wo, 2, 0),
+                     M=n * Ho * Wo, naive=naive)
+        ref = _to_tokens(F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1))
+        out.append(_res(f"conv3x3[{var}] stride 2", y, ref, 4e-3))
+        # nearest x2 upsample folded
+        y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, 2 * H, 2 * W, 1, 1),
+                     M=n * 4 * H * W, naive=naive)
+        ref = _to_tokens(F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1))
+        out.append(_res(f"conv3x3[{var}] upsample x2", y, ref, 4e-3))
+        # two sources (skip concat)
+        x1 = rnd(n, 128, H, W)
+        w2 = rnd(co, ci + 128, 3, 3, scale=1 / math.sqrt(9 * (ci + 128)))
+        y = ops.gemm(_to_tokens(x), _pack_conv(w2), a1=_to_tokens(x1), mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0), naive=naive)
+        ref = _to_tokens(F.conv2d(torch.cat([x, x1], 1).float(), w2.float(), padding=1))
+        out.append(_res(f"conv3x3[{var}] two-source", y, ref, 4e-3))
+        # temporal (3,1,1)
+        B, Fr, HW, C = 2, 5, 24, 64
+        xt = rnd(B * Fr * HW, C)
+        w3, b3 = rnd(C, C, 3, 1, 1, scale=1 / math.sqrt(3 * C)), rnd(C)
+        wp = w3[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, -1).contiguous()
+        y = ops.gemm(xt, wp, bias=b3, mode=ops.MODE_TEMPORAL, temporal=(Fr, HW), residual=xt, naive=naive)
+        x5 = xt.view(B, Fr, HW, C).permute(0, 3, 1, 2).unsqueeze(-1).float()  # [B,C,F,HW,1]
+        ref = F.conv3d(x5, w3.float(), b3.float(), padding=(1, 0, 0)) + x5
+        ref = ref.squeeze(-1).permute(0, 2, 3, 1).reshape(B * Fr * HW, C)
+        out.append(_res(f"temporal conv[{var}] +res", y, ref, 4e-3))
+    # tiny-channel conv goes through the reference-grade kernel automatically
+    x, w, b = rnd(2, 4, 8, 8), rnd(16, 4, 3, 3, scale=0.2), rnd(16)
+    y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, act=ops.ACT_SILU, mode=ops.MODE_CONV2D, conv=(8, 8, 8, 8, 1, 0))
+    out.append(_res("conv3x3 Cin=4 (naive path) + silu", y, _to_tokens(F.silu(F.conv2d(x.float(), w.float(), b.float(), padding=1))), 4e-3))
+    ops.USE_GLDS = False
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def check_norms():
+    out = []
+    stats = torch.zeros(4096, dtype=torch.float32, device=DEV)
+    for (n, c, hw, silu, eps) in [(6, 320, 100, True, 1e-5), (3, 64, 64, False, 1e-6), (4, 1280, 64, True, 1e-5)]:
+        x = rnd(n * hw, c) + 0.5
+        ga, be = rnd(c) + 1.0, rnd(c)
+        y = ops.groupnorm(x, ga, be, stats, hw, groups=32, eps=eps, silu=silu)
+        ref = F.group_norm(x.float().view(n, hw, c).permute(0, 2, 1), 32, ga.float(), be.float(), eps)
+        if silu:
+            ref = F.silu(ref)
+        out.append(_res(f"groupnorm 4-D n{n} c{c} hw{hw} silu={silu}", y, ref.permute(0, 2, 1).reshape(n * hw, c), 4e-3))
+    # 5-D (per clip over frames) + two sources with a group straddling the boundary (1280 + 640 -> 60 ch/group)
+    B, Fr, hw, c0, c1 = 2, 3, 16, 1280, 640
+    x0, x1 = rnd(B * Fr * hw, c0), rnd(B * Fr * hw, c1) * 2 + 1
+    ga, be = rnd(c0 + c1) + 1.0, rnd(c0 + c1)
+    y = ops.groupnorm(x0, ga, be, stats, Fr * hw, x1=x1, groups=32, eps=1e-5, silu=True)
+    xc = torch.cat([x0, x1], 1).float().view(B, Fr * hw, c0 + c1).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xc, 32, ga.float(), be.float(), 1e-5)).permute(0, 2, 1).reshape(B * Fr * hw, c0 + c1)
+    out.append(_res("groupnorm 5-D two-source silu", y, ref, 4e-3))
+    for (m, c) in [(1000, 320), (77, 1280), (333, 512), (50, 4), (64, 64)]:
+        x = rnd(m, c) * 2 + 0.3
+        ga, be = rnd(c) + 1.0, rnd(c)
+        y = ops.layernorm(x, ga, be, 1e-5)
+        out.append(_res(f"layernorm m{m} c{c}", y, F.layer_norm(x.float(), (c,), ga.float(), be.float(), 1e-5), 4e-3))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _sdpa(q, k, v):  # [b, h, s, d] fp32
+    return F.scaled_dot_product_attention(q.float(), k.float(), v.float())
+
+
+def check_attention(naive_too=True):
+    out = []
+    for naive in ((False, True) if naive_too else (False,)):
+        tag = "naive" if naive else "flash"
+        # spatial self-attention out of a fused QKV buffer
+        for (b, h, S) in [(3, 2, 200), (2, 5, 1024), (6, 1, 64), (1, 2, 4096)]:
+            C = 64 * h
+            qkv = rnd(b * S, 3 * C, scale=1.0)
+            o = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=b, heads=h, Sq=S, Sk=S, inner=1,
+                          q_strides=(S, 0, 1), kv_strides=(S, 0, 1), naive=naive)
+            q, k, v = (qkv[:, i * C:(i + 1) * C].view(b, S, h, 64).transpose(1, 2) for i in range(3))
+            ref = _sdpa(q, k, v).transpose(1, 2).reshape(b * S, C)
+            out.append(_res(f"attn[{tag}] spatial b{b} h{h} S{S}", o, ref, 6e-3))
+        # PnP aliasing: Q,K of branches 1,2 come from branch 0
+        b, h, S = 6, 2, 192
+        C = 64 * h
+        qkv = rnd(b * S, 3 * C)
+        o = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=b, heads=h, Sq=S, Sk=S, inner=1,
+                      q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=b // 3, naive=naive)
+        q, k, v = (qkv[:, i * C:(i + 1) * C].view(b, S, h, 64).transpose(1, 2).clone() for i in range(3))
+        c3 = b // 3
+        q[c3:2 * c3], k[c3:2 * c3], q[2 * c3:], k[2 * c3:] = q[:c3], k[:c3], q[:c3], k[:c3]  # pnp_utils.py:192-196
+        out.append(_res(f"attn[{tag}] spatial PnP q/k injection", o, _sdpa(q, k, v).transpose(1, 2).reshape(b * S, C), 6e-3))
+        # cross-attention: Sk=145, K/V shared by the F frames of a clip
+        B_, Fr, S, h, Sk = 2, 3, 100, 2, 145
+        C = 64 * h
+        q2 = rnd(B_ * Fr * S, C)
+        kv = rnd(B_ * Sk, 2 * C + 64)  # wider buffer: K at cols [0,C), V at [C,2C)
+        o = torch.zeros(B_ * Fr * S, C, dtype=torch.float16, device=DEV)
+        ops.attention(q2, kv[:, :C], kv[:, C:2 * C], o, batch=B_ * Fr, heads=h, Sq=S, Sk=Sk, inner=1,
+                      q_strides=(S, 0, 1), kv_strides=(Sk, 0, 1), kv_div=Fr, naive=naive)
+        q = q2.view(B_ * Fr, S, h, 64).transpose(1, 2)
+        k = kv[:, :C].reshape(B_, Sk, h, 64).transpose(1, 2).repeat_interleave(Fr, 0)
+        v = kv[:, C:2 * C].reshape(B_, Sk, h, 64).transpose(1, 2).repeat_interleave(Fr, 0)
+        out.append(_res(f"attn[{tag}] cross Sk=145 kv_div", o, _sdpa(q, k, v).transpose(1, 2).reshape(-1, C), 6e-3))
+        # temporal: sequences stride by HW rows inside the [(b f) hw, C] matrix; with and without PnP
+        for Fr in (16, 8, 40):
+            for inj in (False, True):
+                B_, HW, h = 3, 20, 2
+                C = 64 * h
+                qkv = rnd(B_ * Fr * HW, 3 * C)
+                o = torch.zeros(B_ * Fr * HW, C, dtype=torch.float16, device=DEV)
+                st = (Fr * HW, 1, HW)
+                ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=B_ * HW, heads=h, Sq=Fr, Sk=Fr,
+                              inner=HW, q_strides=st, kv_strides=st, qk_mod=HW if inj else 0, naive=naive)
+                # reference layout of pnp_utils.py: [(B HW), F, C]
+                def seq(x):
+                    return x.reshape(B_, Fr, HW, h, 64).permute(0, 2, 3, 1, 4).reshape(B_ * HW, h, Fr, 64).clone()
+                q, k, v = (seq(qkv[:, i * C:(i + 1) * C]) for i in range(3))
+                if inj:
+                    c3 = HW
+                    q[c3:2 * c3], k[c3:2 * c3], q[2 * c3:], k[2 * c3:] = q[:c3], k[:c3], q[:c3], k[:c3]
+                ref = _sdpa(q, k, v).reshape(B_, HW, h, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B_ * Fr * HW, C)
+                out.append(_res(f"attn[{tag}] temporal F{Fr} inject={inj}", o, ref, 6e-3))
+    # small-head generic kernel (image_latents_temporal_encoder: 2 heads x dim 4)
+    B_, Fr, HW, h, d = 2, 6, 10, 2, 4
+    qkv = rnd(B_ * Fr * HW, 3 * h * d)
+    C = h * d
+    o = torch.zeros(B_ * Fr * HW, C, dtype=torch.float16, device=DEV)
+    st = (Fr * HW, 1, HW)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=B_ * HW, heads=h, Sq=Fr, Sk=Fr, inner=HW,
+                  q_strides=st, kv_strides=st, scale=d ** -0.5, head_dim=d)
+    def seq(x):
+        return x.reshape(B_, Fr, HW, h, d).permute(0, 2, 3, 1, 4).reshape(B_ * HW, h, Fr, d)
+    q, k, v = (seq(qkv[:, i * C:(i + 1) * C]) for i in range(3))
+    ref = _sdpa(q, k, v).reshape(B_, HW, h, Fr, d).permute(0, 3, 1, 2, 4).reshape(-1, C)
+    out.append(_res("attn small head_dim 4", o, ref, 6e-3))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def check_elementwise():
+    out = []
+    x = rnd(1000, 33)
+    out.append(_res("silu", ops.silu(x), F.silu(x.float()), 2e-3))
+    a, b = rnd(777, 13), rnd(777, 13)
+    out.append(_res("add", ops.add(a, b), a.float() + b.float(), 2e-3))
+    t = torch.tensor([981.0, 1.0, 500.0], device=DEV)
+    e = ops.timestep_embedding(t, 320)
+    half = 160
+    fr = torch.exp(-math.log(10000.0) * torch.arange(half, device=DEV).float() / half)
+    arg = t[:, None] * fr[None]
+    out.append(_res("timestep embedding", e, torch.cat([arg.cos(), arg.sin()], -1), 2e-3))
+    B, C, Fr, H, W = 2, 4, 3, 5, 6
+    lat = rnd(B, C, Fr, H, W)
+    tok = torch.zeros(B * Fr * H * W, 16, dtype=torch.float16, device=DEV)
+    ops.ncfhw_to_tokens(lat, tok, col0=4)
+    ref = lat.permute(0, 2, 3, 4, 1).reshape(-1, C)
+    out.append(_res("ncfhw_to_tokens", tok[:, 4:8], ref, 0.0))
+    back = ops.tokens_to_ncfhw(tok, B, C, Fr, H, W, col0=4)
+    out.append(_res("tokens_to_ncfhw", back, lat, 0.0))
+    xp = rnd(2 * 8 * 8, 32)
+    y = ops.adaptive_avgpool(xp, 2, 8, 8, 32, 32)
+    ref = F.adaptive_avg_pool2d(xp.float().view(2, 8, 8, 32).permute(0, 3, 1, 2), (32, 32)).permute(0, 2, 3, 1).reshape(-1, 32)
+    out.append(_res("adaptive_avgpool 8->32", y, ref, 2e-3))
+    xp = rnd(2 * 64 * 64, 8)
+    y = ops.adaptive_avgpool(xp, 2, 64, 64, 32, 32)
+    ref = F.adaptive_avg_pool2d(xp.float().view(2, 64, 64, 8).permute(0, 3, 1, 2), (32, 32)).permute(0, 2, 3, 1).reshape(-1, 8)
+    out.append(_res("adaptive_avgpool 64->32", y, ref, 2e-3))
+    # fused CFG + DDIM step
+    Fr, H, W = 3, 4, 5
+    vt = rnd(3 * Fr * H * W, 8)
+    latx = rnd(1, 4, Fr, H, W)
+    coef = torch.tensor([0.8, 0.6, 0.9, math.sqrt(1 - 0.81)], dtype=torch.float32, device=DEV)
+    o = torch.zeros_like(latx)
+    ops.cfg_ddim_step(vt, 1, 2, 9.0, coef, latx, o)
+    v3 = vt[:, :4].float().view(3, Fr, H * W, 4).permute(0, 3, 1, 2).reshape(3, 4, Fr, H, W)
+    v = v3[1] + 9.0 * (v3[2] - v3[1])
+    xx = latx.float()[0]
+    x0 = 0.8 * xx - 0.6 * v
+    eps = 0.8 * v + 0.6 * xx
+    out.append(_res("cfg + ddim step", o[0], 0.9 * x0 + float(coef[3]) * eps, 6e-3))
+    o2 = ops.ddim_step(v3[2].half(), latx[0], 0.8, 0.6, 0.9, float(coef[3]))
+    x0 = 0.8 * xx - 0.6 * v3[2]
+    eps = 0.8 * v3[2] + 0.6 * xx
+    out.append(_res("ddim step", o2, 0.9 * x0 + float(coef[3]) * eps, 3e-3))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ model level
+def build_pair(cfg_name="mini", seed=1234, oracle_device="cpu"):
+    from anyv2v_amd.unet import I2VGenXLUNet, I2VGenXLUNetConfig
+    from oracle.unet_oracle import UNetConfig, build_oracle, random_state_dict
+    ocfg = UNetConfig.mini() if cfg_name == "mini" else UNetConfig.i2vgen_xl()
+    ncfg = I2VGenXLUNetConfig.mini() if cfg_name == "mini" else I2VGenXLUNetConfig()
+    sd = random_state_dict(ocfg, seed)
+    oracle = build_oracle(ocfg, sd, dtype=torch.float32, device=oracle_device)
+    with torch.device("meta"):
+        native = I2VGenXLUNet(ncfg)
+    native = native.to_empty(device=DEV)
+    native.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    return native, oracle, ocfg
+
+
+def check_unet_golden():
+    """Native UNet + native PnP hooks vs the fixture produced by the reference's own pnp_utils.py on the oracle."""
+    import types
+    from anyv2v_amd import pnp_utils
+    out = []
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "pnp_hooks_mini.pt"))
+    native, _, _ = build_pair("mini", gold["mini_seed"])
+    inp = {k: v.to(DEV) for k, v in gold["inputs"].items()}
+    kw = dict(fps=inp["fps"], image_latents=inp["image_latents"].half(), image_embeddings=inp["image_embeddings"].half(),
+              encoder_hidden_states=inp["encoder_hidden_states"].half())
+    sample = inp["sample"].half()
+    v = native(sample, 981, **kw)[0]
+    out.append(_res("unet mini (no hooks) vs reference-run fixture", v.cpu(), gold["v_nohook_t981"], 3e-2))
+    pipe = types.SimpleNamespace(unet=native)
+    n, p = gold["n_steps"], gold["pnp"]
+    ts = [981 - 20 * i for i in range(50)]
+    pnp_utils.register_conv_injection(pipe, ts[: int(n * p["pnp_f_t"])])
+    pnp_utils.register_spatial_attention_pnp(pipe, ts[: int(n * p["pnp_spatial_attn_t"])])
+    pnp_utils.register_temp_attention_pnp(pipe, ts[: int(n * p["pnp_temp_attn_t"])])
+    for t in (981, 701, 301, 101):
+        pnp_utils.register_time(pipe, t)
+        v = native(sample, t, **kw)[0]
+        out.append(_res(f"unet mini + native PnP hooks t={t} vs reference pnp_utils fixture", v.cpu(), gold[f"v_hook_t{t}"], 3e-2))
+    return out
+
+
+def config1_inputs(cfg, B, Fr=8, hw=32, seed=8888):
+    """BASELINE config 1 inputs: random latents, frame-position planes, seed 8888."""
+    g = torch.Generator().manual_seed(seed)
+    sample = torch.randn(B, 4, Fr, hw, hw, generator=g)
+    il = torch.randn(B, 4, Fr, hw, hw, generator=g)
+    for i in range(1, Fr):
+        il[:, :, i] = i / (Fr - 1)
+    ehs = torch.randn(B, 77, cfg.cross_attention_dim, generator=g)
+    ie = torch.randn(B, 1, cfg.cross_attention_dim, generator=g)
+    return dict(sample=sample, image_latents=il, encoder_hidden_states=ehs, image_embeddings=ie, fps=torch.tensor([8] * B))
+
+
+def check_unet_vs_oracle(cfg_name="mini", B=3, Fr=4, hw=8, with_pnp=True, tol=3e-2, report=None):
+    """Single denoise step, HIP UNet (fp16) vs CPU oracle (fp32) on identical fp16-rounded weights and inputs."""
+    import time
+    import types
+    from anyv2v_amd import pnp_utils
+    from oracle import pnp_oracle
+    out = []
+    native, oracle, ocfg = build_pair(cfg_name, 1234)
+    inp = config1_inputs(ocfg, B, Fr, hw)
+    inp16 = {k: (v.half() if v.is_floating_point() else v) for k, v in inp.items()}
+    kw_o = dict(fps=inp["fps"], image_latents=inp16["image_latents"].float(), image_embeddings=inp16["image_embeddings"].float(),
+                encoder_hidden_states=inp16["encoder_hidden_states"].float())
+    kw_n = dict(fps=inp["fps"].to(DEV), image_latents=inp16["image_latents"].to(DEV),
+                image_embeddings=inp16["image_embeddings"].to(DEV), encoder_hidden_states=inp16["encoder_hidden_states"].to(DEV))
+    t0 = time.time()
+    with torch.no_grad():
+        vo = oracle(inp16["sample"].float(), 981, **kw_o)[0]
+    t_cpu = time.time() - t0
+    vn = native(inp16["sample"].to(DEV), 981, **kw_n)[0]
+    torch.cuda.synchronize()
+    out.append(_res(f"unet {cfg_name} B{B} F{Fr} {hw}x{hw} step vs oracle", vn.cpu(), vo, tol))
+    if report is not None:
+        report[f"cpu_oracle_seconds_{cfg_name}_B{B}"] = t_cpu
+    if with_pnp and B == 3:
+        ts = [981 - 20 * i for i in range(50)]
+        pipe = types.SimpleNamespace(unet=native)
+        pnp_utils.register_conv_injection(pipe, ts[:10])
+        pnp_utils.register_spatial_attention_pnp(pipe, ts[:25])
+        pnp_utils.register_temp_attention_pnp(pipe, ts[:40])
+        pnp_oracle.register_conv_injection(oracle, ts[:10])
+        pnp_oracle.register_spatial_attention_pnp(oracle, ts[:25])
+        pnp_oracle.register_temp_attention_pnp(oracle, ts[:40])
+        for t in (981, 301):
+            pnp_utils.register_time(pipe, t)
+            pnp_oracle.register_time(oracle, t)
+            with torch.no_grad():
+                vo = oracle(inp16["sample"].float(), t, **kw_o)[0]
+            vn = native(inp16["sample"].to(DEV), t, **kw_n)[0]
+            out.append(_res(f"unet {cfg_name} B3 PnP step t={t} vs oracle", vn.cpu(), vo, tol))
+    return out
+
+
+def check_loops_mini():
+    """Multi-step: inversion -> PnP edit with the pipeline (HIP graphs) vs the oracle loops; plus graph == eager."""
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    from anyv2v_amd import pnp_utils
+    from oracle import pnp_oracle
+    out = []
+    native, oracle, ocfg = build_pair("mini", 1234)
+    Fr, hw, n_steps = 4, 8, 10
+    inp = config1_inputs(ocfg, 3, Fr, hw)
+    h = lambda x: x.half()
+    lat0 = h(inp["sample"][:1])
+    ehs, ie, il = h(inp["encoder_hidden_states"]), h(inp["image_embeddings"]), h(inp["image_latents"])
+    # oracle: inversion with the source conditioning (branch 0), then PnP edit
+    cond_src = dict(fps=torch.tensor([8]), image_latents=il[:1].float(), image_embeddings=ie[:1].float(),
+                    encoder_hidden_states=ehs[:1].float())
+    traj_o = pnp_oracle.invert_loop(oracle, lat0.float(), cond_src, n_steps)
+    ie_all = torch.cat([ie[:1], torch.zeros_like(ie[2:3]), ie[2:3]])
+    il_all = torch.cat([il[:1], il[2:3], il[2:3]])
+    cond_all = dict(fps=torch.tensor([8] * 3), image_latents=il_all.float(), image_embeddings=ie_all.float(),
+                    encoder_hidden_states=ehs.float())
+    pnp_oracle.init_pnp(oracle, n_steps, 0.3, 0.6, 1.0)
+    T = max(traj_o.keys())
+    edited_o = pnp_oracle.pnp_loop(oracle, traj_o[T].clone(), traj_o, cond_all, n_steps, 9.0, t_idx=0)
+    # native pipeline
+    for graphs in (True, False):
+        os.environ["ANYV2V_NO_GRAPH"] = "0" if graphs else "1"
+        pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+        pipe._device = torch.device(DEV)
+        traj = pipe.invert(prompt_embeds=ehs[:1].to(DEV), image_embeddings=ie[:1].to(DEV), image_latents=il[:1].to(DEV),
+                           height=hw * 8, width=hw * 8, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0,
+                           target_fps=8, latents=lat0.to(DEV), return_trajectory=True)
+        tag = "graph" if graphs else "eager"
+        out.append(_res(f"pipeline.invert {n_steps} steps [{tag}] final latent vs oracle", traj[T].cpu(), traj_o[T], 5e-2))
+        sched = DDIMScheduler()
+        sched.set_timesteps(n_steps)
+        k = lambda r: sched.timesteps[: int(n_steps * r)]
+        pnp_utils.register_conv_injection(pipe, k(0.3))
+        pnp_utils.register_spatial_attention_pnp(pipe, k(0.6))
+        pnp_utils.register_temp_attention_pnp(pipe, k(1.0))
+        pipe.register_modules(scheduler=sched)
+        res = pipe.sample_with_pnp(prompt_embeds=ehs[2:3].to(DEV), negative_prompt_embeds=ehs[1:2].to(DEV),
+                                   image_embeddings=ie[2:3].to(DEV), image_latents=il[2:3].to(DEV), height=hw * 8,
+                                   width=hw * 8, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=9.0,
+                                   target_fps=8, latents=traj[T].clone(), output_type="latent", ddim_init_latents_t_idx=0,
+                                   ddim_inv_latents_path=traj, ddim_inv_prompt_embeds=ehs[:1].to(DEV),
+                                   ddim_inv_image_embeddings=ie[:1].to(DEV), ddim_inv_image_latents=il[:1].to(DEV)).frames
+        out.append(_res(f"pipeline.sample_with_pnp {n_steps} steps [{tag}] vs oracle", res.cpu(), edited_o, 8e-2))
+        if graphs:
+            res_graph = res.clone()
+        else:
+            out.append(_res("pipeline graph replay == eager", res_graph.cpu(), res.cpu(), 1e-3))
+    os.environ["ANYV2V_NO_GRAPH"] = "0"
+    return out
+
+
+ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_conv, check_norms, check_attention, check_elementwise]
