@@ -40,6 +40,17 @@ def register_time(model, t):
             setattr(unet.up_blocks[res].temp_attentions[block].transformer_blocks[0].attn1.processor, "t", t)
 
 
+def clear_time(model):
+    """Forget the registered timestep (hooks inert): needed when inversion (B=1, no hooks in the reference's
+    stage-1 process) and PnP editing share one process / one UNet object."""
+    unet = model.unet
+    setattr(unet.up_blocks[1].resnets[1], "t", None)
+    for res, blocks in _TIME_SITES.items():
+        for block in blocks:
+            setattr(unet.up_blocks[res].attentions[block].transformer_blocks[0].attn1.processor, "t", None)
+            setattr(unet.up_blocks[res].temp_attentions[block].transformer_blocks[0].attn1.processor, "t", None)
+
+
 def register_conv_injection(model, injection_schedule):
     conv_module = model.unet.up_blocks[1].resnets[1]
     setattr(conv_module, "injection_schedule", _as_schedule(injection_schedule))

@@ -1,0 +1,239 @@
+"""bench.py -- frames/sec for 16f x 512x512 DDIM-inversion + PnP-edit on MI355X (BASELINE.json metric).
+
+A "step" here is ONE inversion denoise step (UNet B=1 + inverse-DDIM update + trajectory write) PLUS ONE PnP-edit
+denoise step (source-latent read, UNet B=3 with conv / spatial / temporal feature injection, CFG 9.0 + DDIM update)
+on one synthetic 16-frame 512x512 clip, i.e. 1/50 of BASELINE config 3 (50-step inversion + 50-step edit);
+--steps 50 is exactly one clip.  frames/sec = 16 * (K / 50) * n_gpus / seconds.
+Everything inside the step runs in the hand-written HIP kernels (anyv2v_amd/libanyv2v_hip.so); weights are random
+(seeded) with the exact I2VGen-XL architecture, inputs synthetic and HBM-resident; VAE/CLIP pre/post are outside.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEPS_PER_STAGE = 50          # BASELINE config 2/3: 50 inversion steps, 50 edit steps
+FRAMES, LAT = 16, 64          # 16 frames, 512/8 = 64
+PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def synthetic_clip(device, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(torch.float16).to(device)
+    lat = r(1, 4, FRAMES, LAT, LAT)
+    ehs = r(3, 77, 1024)                      # [ddim_inv prompt, negative, edit] (pipeline_i2vgen_xl.py:1044)
+    ie = r(3, 1, 1024)
+    ie[1].zero_()                             # zero negative image embedding (:437-439)
+    il = r(2, 4, FRAMES, LAT, LAT)            # first-frame latents of the source / edited frame
+    for i in range(1, FRAMES):                # frame-position planes (:548-554)
+        il[:, :, i] = i / (FRAMES - 1)
+    il_all = torch.stack([il[0], il[1], il[1]]).contiguous()
+    return lat, ehs, ie, il_all
+
+
+def measure_kernel(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms per launch, HIP events on the launching stream
+
+
+def roofline_spatial_attention(device):
+    """Spatial self-attention at the PnP-step shape (N=48 images, 5 heads, S=4096, d=64): 4*N*h*S^2*d FLOP."""
+    from anyv2v_amd import ops
+    N, h, S, d = 48, 5, 4096, 64
+    C = h * d
+    qkv = (torch.randn(N * S, 3 * C, device=device) * 1.0).to(torch.float16)
+    o = torch.empty(N * S, C, dtype=torch.float16, device=device)
+    fn = lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=N, heads=h, Sq=S, Sk=S, inner=1,
+                               q_strides=(S, 0, 1), kv_strides=(S, 0, 1))
+    ms = measure_kernel(fn)
+    flops = 4.0 * N * h * S * S * d
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "flash_attn_d64_kernel (spatial self-attn, N=48 h=5 S=4096 d=64)",
+            "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
+
+
+def roofline_conv(device):
+    """ResNet conv3x3 320->320 at 64x64, N=48 (the most frequent conv shape): 2*T*9*Cin*Cout FLOP."""
+    from anyv2v_amd import ops
+    N, H, C = 48, 64, 320
+    x = torch.randn(N * H * H, C, device=device).to(torch.float16)
+    w = (torch.randn(C, 9 * C, device=device) / (9 * C) ** 0.5).to(torch.float16)
+    b = torch.zeros(C, dtype=torch.float16, device=device)
+    out = torch.empty(N * H * H, C, dtype=torch.float16, device=device)
+    fn = lambda: ops.gemm(x, w, bias=b, mode=ops.MODE_CONV2D, conv=(H, H, H, H, 1, 0), out=out)
+    ms = measure_kernel(fn)
+    flops = 2.0 * N * H * H * 9 * C * C
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_mfma_kernel (conv3x3 320->320 @64x64, N=48)", "achieved": round(ach, 2),
+            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
+
+
+def cpu_baseline():
+    """The oracle (fp32 PyTorch restatement of the reference UNet + the PnP hooks) timed on this host's cores on a
+    bounded sample: ONE inversion step (B=1) + ONE PnP step (B=3, all hooks on) of BASELINE config 1
+    (1 clip x 8 frames x 256x256), extrapolated to the 50+50-step job: frames/s = 8 / (50 * (t1 + t3))."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pnp_oracle
+    from oracle.unet_oracle import UNetConfig, build_oracle, random_state_dict
+    import gpu_checks as gc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = UNetConfig.i2vgen_xl()
+    oracle = build_oracle(cfg, random_state_dict(cfg, 0), dtype=torch.float32)
+    inp = gc.config1_inputs(cfg, 3, 8, 32)
+    kw = lambda s: dict(fps=inp["fps"][s], image_latents=inp["image_latents"][s], image_embeddings=inp["image_embeddings"][s],
+                        encoder_hidden_states=inp["encoder_hidden_states"][s])
+    with torch.no_grad():
+        t0 = time.time()
+        oracle(inp["sample"][:1], 981, **kw(slice(0, 1)))
+        t1 = time.time() - t0
+        pnp_oracle.init_pnp(oracle, 50, 1.0, 1.0, 1.0)
+        pnp_oracle.register_time(oracle, 981)
+        t0 = time.time()
+        oracle(inp["sample"], 981, **kw(slice(0, 3)))
+        t3 = time.time() - t0
+    fps = 8.0 / (STEPS_PER_STAGE * (t1 + t3))
+    return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"config 1 (1 clip x 8f x 256x256): 1 inversion step B=1 ({t1:.2f}s) + 1 PnP step B=3 with hooks ({t3:.2f}s), "
+                      f"fp32 torch on {cores} threads, extrapolated x50 steps per stage",
+            "seconds_B1": round(t1, 3), "seconds_B3": round(t3, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--seed", type=int, default=8888)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.pipeline import I2VGenXLPipeline, _StepEngine
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+
+    torch.set_grad_enabled(False)
+    pipe = I2VGenXLPipeline.from_pretrained("ali-vilab/i2vgen-xl", torch_dtype=torch.float16, variant="fp16",
+                                            random_init_seed=0)
+    pipe.to(device)
+    lat, ehs, ie, il_all = synthetic_clip(device, args.seed + rank)  # one independent clip per rank (weak scaling)
+    fps1, fps3 = torch.tensor([8], device=device), torch.tensor([8, 8, 8], device=device)
+
+    inv, fwd = DDIMInverseScheduler(), DDIMScheduler()
+    inv.set_timesteps(STEPS_PER_STAGE)
+    fwd.set_timesteps(STEPS_PER_STAGE)
+    ts_inv, ts_pnp = [int(t) for t in inv.timesteps], [int(t) for t in fwd.timesteps]
+    # first demo entry (configs/group_pnp_edit/group_config.json:9-12): all three injections on for every step
+    pnp_utils.register_conv_injection(pipe, fwd.timesteps[: int(STEPS_PER_STAGE * 1.0)])
+    pnp_utils.register_spatial_attention_pnp(pipe, fwd.timesteps[: int(STEPS_PER_STAGE * 1.0)])
+    pnp_utils.register_temp_attention_pnp(pipe, fwd.timesteps[: int(STEPS_PER_STAGE * 1.0)])
+
+    s_inv = lat.clone()
+    s_pnp = lat.repeat(3, 1, 1, 1, 1).contiguous()
+    cond1 = dict(encoder_hidden_states=ehs[:1].contiguous(), fps=fps1, image_latents=il_all[:1].contiguous(),
+                 image_embeddings=ie[:1].contiguous())
+    cond3 = dict(encoder_hidden_states=ehs, fps=fps3, image_latents=il_all, image_embeddings=ie)
+    pnp_utils.clear_time(pipe)   # inversion steps run hook-free (stage 1 of the reference has no hooks registered)
+    e_inv = _StepEngine(pipe, s_inv, cond1, b_unc=-1, b_cond=0, guidance=1.0, dup_slots=[])
+    e_pnp = _StepEngine(pipe, s_pnp, cond3, b_unc=1, b_cond=2, guidance=9.0, dup_slots=[1])
+    tt_inv = torch.tensor(ts_inv, dtype=torch.float32, device=device)[:, None].contiguous()
+    tt_pnp = torch.tensor(ts_pnp, dtype=torch.float32, device=device)[:, None].expand(-1, 3).contiguous()
+    cf_inv, cf_pnp = inv.coefficient_table(ts_inv, device), fwd.coefficient_table(ts_pnp, device)
+    traj = torch.zeros(STEPS_PER_STAGE, 4, FRAMES, LAT, LAT, dtype=torch.float16, device=device)  # HBM-resident trajectory
+
+    def pair(i):
+        j = i % STEPS_PER_STAGE
+        # --- inversion step (pipeline_i2vgen_xl.py:1385-1433); inversion never injects (cfg 1.0, B=1)
+        pnp_utils.clear_time(pipe)
+        e_inv.step(tt_inv[j], cf_inv[j], key=("inv",))
+        traj[j].copy_(s_inv[0])
+        # --- PnP edit step (:1131-1179): source latent from the trajectory, 3-way batch, injections on
+        s_pnp[0].copy_(traj[STEPS_PER_STAGE - 1 - j] if i >= STEPS_PER_STAGE else traj[j])
+        pnp_utils.register_time(pipe, ts_pnp[j])
+        e_pnp.step(tt_pnp[j], cf_pnp[j], key=("pnp",) + pnp_utils.injection_state(pipe))
+
+    for i in range(args.warmup):
+        pair(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pair(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        # the one collective of the sharded job: all-gather of the edited latents (512 KiB per rank) over RCCL/xGMI
+        out = [torch.empty_like(s_pnp[2:3]) for _ in range(world)]
+        dist.all_gather(out, s_pnp[2:3].contiguous())
+        tmax = torch.tensor([dt], device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    finite = bool(torch.isfinite(s_pnp.float()).all() and torch.isfinite(s_inv.float()).all())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = FRAMES * (args.steps / STEPS_PER_STAGE) * world / dt
+        line = {
+            "metric": "frames/sec for 16fx512x512 DDIM-inversion+PnP-edit; spatial-attn MFMA % of peak",
+            "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3 per GPU: 1 clip x 16f x 512x512, 50-step DDIM inversion (UNet B=1) + 50-step "
+                                   "PnP edit (UNet B=3, cfg 9.0, conv+spatial+temporal injection on every step); a bench step = "
+                                   "1 inversion step + 1 edit step = 1/50 clip; I2VGen-XL 3D-UNet 1.42B params, random init",
+                       "steps_per_stage": STEPS_PER_STAGE, "frames": FRAMES, "latent": [4, FRAMES, LAT, LAT],
+                       "hip_graphs": os.environ.get("ANYV2V_NO_GRAPH", "0") != "1", "finite": finite,
+                       "excluded": "VAE encode/decode, CLIP encoders, file I/O (SURVEY 8(f) F1/F2)"},
+        }
+        if world == 1 and not args.no_roofline:
+            line["roofline"] = roofline_spatial_attention(device)
+            line["roofline_gemm"] = roofline_conv(device)
+        if world == 1 and not args.no_cpu_baseline:
+            del pipe, e_inv, e_pnp
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+"""TEST-ONLY emulation of the C-ABI ops (``anyv2v_amd.ops``) with plain torch on the CPU.
+
+Purpose: exercise the *host logic* (UNet wiring over the token layout, weight packing, conditioning cache,
+PnP aliasing, pipeline loops, graph-free step engine) in the ``-m "not gpu"`` suite, where no GPU exists.
+It is installed by monkeypatching inside tests and is never importable from the product package: the product
+path has no CPU fallback (``anyv2v_amd._lib`` raises when the HIP library is missing).
+Each function restates the contract documented in ``include/anyv2v_hip.h``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+MODE_LINEAR, MODE_CONV2D, MODE_TEMPORAL = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
+
+
+def _h(x):
+    return x.to(torch.float16)
+
+
+def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, out=None,
+         mode=MODE_LINEAR, conv=None, temporal=None, M=None, naive=False):
+    a = a0.float() if a1 is None else torch.cat([a0.float(), a1.float()], 1)
+    K = a.shape[1]
+    N = w.shape[0]
+    wf = w.float()
+    if mode == MODE_LINEAR:
+        y = a @ wf.t()
+    elif mode == MODE_CONV2D:
+        Hi, Wi, Ho, Wo, stride, up = conv
+        n = a.shape[0] // (Hi * Wi)
+        x = a.view(n, Hi, Wi, K).permute(0, 3, 1, 2)
+        if up:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        w4 = wf.view(N, 3, 3, K).permute(0, 3, 1, 2)
+        y = F.conv2d(x, w4, None, stride=stride, padding=1)
+        assert y.shape[2] == Ho and y.shape[3] == Wo
+        y = y.permute(0, 2, 3, 1).reshape(n * Ho * Wo, N)
+    else:
+        Fr, HW = temporal
+        B = a.shape[0] // (Fr * HW)
+        x = a.view(B, Fr, HW, K).permute(0, 3, 1, 2).unsqueeze(-1)
+        w5 = wf.view(N, 3, K).permute(0, 2, 1)[:, :, :, None, None]
+        y = F.conv3d(x, w5, None, padding=(1, 0, 0)).squeeze(-1).permute(0, 2, 3, 1).reshape(B * Fr * HW, N)
+    if M is not None:
+        assert y.shape[0] == M, (y.shape, M)
+    if act == ACT_GEGLU:
+        if bias is not None:
+            y = y + bias.float()
+        y = y.view(y.shape[0], N // 32, 2, 16)
+        y = (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(y.shape[0], N // 2)
+    else:
+        if bias is not None:
+            y = y + bias.float()
+        if rowvec is not None:
+            idx = torch.arange(y.shape[0]) // rowvec_div
+            y = y + rowvec.float()[idx]
+        if act == ACT_SILU:
+            y = F.silu(y)
+        elif act == ACT_GELU:
+            y = F.gelu(y)
+    if residual is not None:
+        y = _h(y).float() + residual.float()
+    y = _h(y)
+    if out is None:
+        return y
+    out[: y.shape[0], : y.shape[1]] = y
+    return out
+
+
+def groupnorm(x0, gamma, beta, stats, rows_per_group, *, x1=None, groups=32, eps=1e-5, silu=False, out=None):
+    x = x0.float() if x1 is None else torch.cat([x0.float(), x1.float()], 1)
+    M, C = x.shape
+    n = M // rows_per_group
+    y = F.group_norm(x.view(n, rows_per_group, C).permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)
+    if silu:
+        y = F.silu(y)
+    y = _h(y.permute(0, 2, 1).reshape(M, C))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    y = _h(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_strides, kv_div=1, qk_mod=0, scale=0.125,
+              head_dim=64, naive=False):
+    i = torch.arange(batch)
+    iq = i % qk_mod if qk_mod > 0 else i
+
+    def rows(idx, st, S):
+        base = (idx // inner) * st[0] + (idx % inner) * st[1]
+        return base[:, None] + torch.arange(S)[None, :] * st[2]  # [batch, S]
+
+    rq, ro = rows(iq, q_strides, Sq), rows(i, q_strides, Sq)
+    rk, rv = rows(iq // kv_div, kv_strides, Sk), rows(i // kv_div, kv_strides, Sk)
+    D = head_dim
+    Q = q.float()[rq].view(batch, Sq, heads, D).transpose(1, 2)
+    K = k.float()[rk].view(batch, Sk, heads, D).transpose(1, 2)
+    V = v.float()[rv].view(batch, Sk, heads, D).transpose(1, 2)
+    O = F.scaled_dot_product_attention(Q, K, V, scale=scale).transpose(1, 2).reshape(batch, Sq, heads * D)
+    out[ro.reshape(-1)] = _h(O.reshape(batch * Sq, heads * D))
+    return out
+
+
+def silu(x, out=None):
+    y = _h(F.silu(x.float()))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def add(a, b, out=None):
+    y = _h(a.float() + b.float())
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def timestep_embedding(t_f32, dim, out=None):
+    half = dim // 2
+    fr = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t_f32.float()[:, None] * fr[None]
+    return _h(torch.cat([arg.cos(), arg.sin()], -1))
+
+
+def ncfhw_to_tokens(x, out, col0=0):
+    B, C, Fr, H, W = x.shape
+    out[:, col0:col0 + C] = x.permute(0, 2, 3, 4, 1).reshape(-1, C)
+    return out
+
+
+def tokens_to_ncfhw(x, B, Cc, Fr, H, W, col0=0, out=None):
+    y = x[:, col0:col0 + Cc].reshape(B, Fr, H, W, Cc).permute(0, 4, 1, 2, 3).contiguous()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def adaptive_avgpool(x, N, Hi, Wi, Ho, Wo):
+    C = x.shape[1]
+    y = F.adaptive_avg_pool2d(x.float().view(N, Hi, Wi, C).permute(0, 3, 1, 2), (Ho, Wo))
+    return _h(y.permute(0, 2, 3, 1).reshape(N * Ho * Wo, C))
+
+
+def copy_cols(x, xcol0, y, ycol0, ncols):
+    y[:, ycol0:ycol0 + ncols] = x[:, xcol0:xcol0 + ncols]
+    return y
+
+
+def cfg_ddim_step(vtok, b_unc, b_cond, guidance, coef, lat, out):
+    _, C, Fr, H, W = lat.shape
+    n = Fr * H * W
+    def branch(b):
+        return vtok[b * n:(b + 1) * n, :C].float().view(Fr, H, W, C).permute(3, 0, 1, 2)
+    v = branch(b_cond)
+    if b_unc >= 0:
+        vu = branch(b_unc)
+        v = vu + guidance * (v - vu)
+    sa_t, sb_t, sa_p, sb_p = [float(c) for c in coef[:4]]
+    x = lat.float()[0]
+    x0 = sa_t * x - sb_t * v
+    eps = sa_t * v + sb_t * x
+    out[0] = _h(sa_p * x0 + sb_p * eps)
+    return out
+
+
+def ddim_step(v, x, sa_t, sb_t, sa_p, sb_p, out=None):
+    v, x = v.float(), x.float()
+    x0 = sa_t * x - sb_t * v
+    eps = sa_t * v + sb_t * x
+    y = _h(sa_p * x0 + sb_p * eps)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def install(monkeypatch=None):
+    """Replace every function of ``anyv2v_amd.ops`` with the emulation (tests only)."""
+    from anyv2v_amd import ops
+    names = ["gemm", "groupnorm", "layernorm", "attention", "silu", "add", "timestep_embedding", "ncfhw_to_tokens",
+             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "cfg_ddim_step", "ddim_step"]
+    g = globals()
+    for n in names:
+        if monkeypatch is not None:
+            monkeypatch.setattr(ops, n, g[n])
+        else:
+            setattr(ops, n, g[n])

@@ -22,8 +22,9 @@ def main():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     report = {"device": torch.cuda.get_device_name(0), "torch": torch.__version__, "results": []}
     groups = []
-    if "kernels" in what:
-        groups += [(f.__name__, f) for f in gc.ALL_KERNEL_CHECKS]
+    for f in gc.ALL_KERNEL_CHECKS:
+        if "kernels" in what or f.__name__.replace("check_", "") in what:
+            groups.append((f.__name__, f))
     if "mini" in what:
         groups += [("unet_golden", gc.check_unet_golden),
                    ("unet_mini_vs_oracle", lambda: gc.check_unet_vs_oracle("mini", 3, 4, 8, report=report)),
@@ -55,9 +56,10 @@ def main():
         lines.append(f"---- {name}: {time.time() - t0:.1f}s")
         print("\n".join(lines[-(len(res) + 1):]), flush=True)
     report["failures"] = nfail
-    with open(os.path.join(ROOT, "gpurun_out", "gpu_check.json"), "w") as f:
+    tag = "_".join(sorted(what))
+    with open(os.path.join(ROOT, "gpurun_out", f"gpu_check_{tag}.json"), "w") as f:
         json.dump(report, f, indent=1, default=str)
-    with open(os.path.join(ROOT, "gpurun_out", "gpu_check.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"gpu_check_{tag}.txt"), "w") as f:
         f.write("\n".join(lines) + f"\nFAILURES: {nfail}\n")
     print(f"FAILURES: {nfail}")
     return 0
