@@ -1,0 +1,123 @@
+"""Encoders either side of the hot loop -- component interface + offline stand-ins.
+
+The reference wires ``AutoencoderKL`` / ``CLIPTextModel`` / ``CLIPVisionModelWithProjection`` from the hub repo
+``ali-vilab/i2vgen-xl`` (``pipeline_i2vgen_xl.py:155-178``).  Neither the weights nor ``diffusers`` exist offline, and
+these once-per-clip stages are outside the HIP hot path of this round.  The pipeline only needs four small
+interfaces, defined here, and ships *synthetic* implementations (deterministic, weight-free, NOT the real models) so
+that the CLIs, file formats and multi-GPU sharding can be exercised end to end:
+
+  vae.encode_image(pil, device, height, width) -> [1,4,h,w]      (posterior mean x scaling_factor)
+  vae.encode_video(list[pil], device, height, width) -> [1,4,F,h,w]
+  vae.decode_video(latents[1,4,F,h,w], decode_chunk_size) -> float32 [1,3,F,H,W] in [-1,1];  vae.to_pil(video)
+  text_encoder.encode(list[str], device, clip_skip) -> [n,77,1024]
+  image_encoder.encode(pil, width, device) -> [1,1,1024]
+"""
+from __future__ import annotations
+
+import hashlib
+from types import SimpleNamespace
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from PIL import Image
+
+
+def _center_crop_wide(image: Image.Image, resolution):
+    """``pipeline_i2vgen_xl.py:1487-1509``: resize to cover, then centre-crop to ``resolution`` = (w, h)."""
+    w, h = image.size
+    scale = min(w / resolution[0], h / resolution[1])
+    image = image.resize((round(w / scale), round(h / scale)), resample=Image.BOX)
+    x1 = (image.width - resolution[0]) // 2
+    y1 = (image.height - resolution[1]) // 2
+    return image.crop((x1, y1, x1 + resolution[0], y1 + resolution[1]))
+
+
+def _pil_to_tensor(img: Image.Image) -> torch.Tensor:
+    a = np.asarray(img.convert("RGB"), dtype=np.float32) / 255.0
+    return torch.from_numpy(a).permute(2, 0, 1)[None] * 2.0 - 1.0  # [1,3,H,W] in [-1,1]
+
+
+class SyntheticVAE:
+    """8x area-pool + fixed orthogonal-ish 3->4 channel mix (and its pseudo-inverse for decoding).  Weight-free
+    stand-in with the SD-VAE's shapes / scaling factor; deterministic (the real VAE *samples* its posterior with the
+    global RNG, ``pipeline_i2vgen_xl.py:540,582``)."""
+
+    def __init__(self):
+        self.config = SimpleNamespace(scaling_factor=0.18215, block_out_channels=(128, 256, 512, 512))
+        g = torch.Generator().manual_seed(20240229)
+        self.mix = torch.linalg.qr(torch.randn(4, 4, generator=g))[0][:, :3].contiguous()  # [4,3]
+
+    def to(self, device):
+        return self
+
+    def _enc(self, x):  # [n,3,H,W] -> [n,4,H/8,W/8]
+        x = F.avg_pool2d(x, 8)
+        return torch.einsum("oc,nchw->nohw", self.mix, x) * (self.config.scaling_factor * 4.0)
+
+    def encode_image(self, image, device, height, width):
+        x = _pil_to_tensor(_center_crop_wide(image, (width, height)))
+        return self._enc(x).to(device=device, dtype=torch.float16)
+
+    def encode_video(self, video: List[Image.Image], device, height, width):
+        lat = torch.cat([self._enc(_pil_to_tensor(_center_crop_wide(f, (width, height)))) for f in video])  # [F,4,h,w]
+        return lat.permute(1, 0, 2, 3)[None].to(device=device, dtype=torch.float16)
+
+    def decode_video(self, latents, decode_chunk_size=None):
+        z = latents.float().cpu() / (self.config.scaling_factor * 4.0)
+        b, c, f, h, w = z.shape
+        x = torch.einsum("oc,bofhw->bcfhw", self.mix, z)
+        x = F.interpolate(x.reshape(b, 3 * f, h, w), scale_factor=8, mode="nearest").reshape(b, 3, f, h * 8, w * 8)
+        return x.clamp(-1, 1)
+
+    def to_pil(self, video):
+        """``tensor2vid`` (``pipeline_i2vgen_xl.py:79-97``) for one clip: [1,3,F,H,W] in [-1,1] -> list of PIL."""
+        x = ((video[0].permute(1, 2, 3, 0) + 1.0) * 127.5).round().clamp(0, 255).to(torch.uint8).numpy()
+        return [Image.fromarray(fr) for fr in x]
+
+
+def _seeded(text: str, shape):
+    seed = int.from_bytes(hashlib.sha256(text.encode()).digest()[:8], "little") % (2 ** 63)
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+class SyntheticTextEncoder:
+    """Hash-seeded N(0,1) token embeddings with the OpenCLIP ViT-H text tower's output shape (77 x 1024)."""
+
+    def __init__(self, dim=1024, tokens=77):
+        self.dim, self.tokens = dim, tokens
+
+    def to(self, device):
+        return self
+
+    def encode(self, prompts, device, clip_skip=None):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        e = torch.stack([_seeded("txt:" + p, (self.tokens, self.dim)) for p in prompts])
+        return e.to(device=device, dtype=torch.float16)
+
+
+class SyntheticImageEncoder:
+    """Image embedding = fixed random projection of the 224x224 bilinear-resized, centre-cropped frame."""
+
+    def __init__(self, dim=1024):
+        self.dim = dim
+        self.proj = torch.randn(dim, 3 * 14 * 14, generator=torch.Generator().manual_seed(7)) / (3 * 14 * 14) ** 0.5
+
+    def to(self, device):
+        return self
+
+    def encode(self, image, width, device):
+        img = _center_crop_wide(image, (width, width)).resize((224, 224), resample=Image.BILINEAR)
+        x = F.avg_pool2d(_pil_to_tensor(img), 16).reshape(-1)
+        return (self.proj @ x)[None, None].to(device=device, dtype=torch.float16)
+
+
+def attach_synthetic_encoders(pipe):
+    pipe.vae = SyntheticVAE()
+    pipe.text_encoder = SyntheticTextEncoder(pipe.unet.cfg.cross_attention_dim)
+    pipe.tokenizer = object()
+    pipe.image_encoder = SyntheticImageEncoder(pipe.unet.cfg.cross_attention_dim)
+    pipe.feature_extractor = object()
+    return pipe

@@ -275,6 +275,7 @@ class I2VGenXLPipeline:
         self.check_inputs(prompt, image, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
         device = self._execution_device
         self._guidance_scale = guidance_scale
+        pnp_utils.clear_time(self)  # inversion never injects (stage 1 of the reference runs without hooks)
         pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                                              negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
         cfg_on = self.do_classifier_free_guidance
@@ -330,6 +331,7 @@ class I2VGenXLPipeline:
         pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                                              negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
         cfg_on = self.do_classifier_free_guidance
+        pnp_utils.clear_time(self)  # plain CFG sampling (DDIM reconstruction) runs hook-free
         if cfg_on:
             ehs, ie_all, il_all = torch.cat([npe, pe]), torch.cat([torch.zeros_like(ie), ie]), torch.cat([il, il])
         else:
@@ -449,17 +451,12 @@ def init_random_weights_(unet: I2VGenXLUNet, seed: int):
 
 
 def _clip_text(text_encoder, tokenizer, prompt, device, clip_skip):
-    """``encode_prompt`` body (:286-334): CLIP text tower, ``clip_skip`` layers from the end + final LayerNorm."""
+    """``encode_prompt`` (:224-409) through the component interface of ``anyv2v_amd.encoders``."""
     if isinstance(prompt, str):
         prompt = [prompt]
-    ids = tokenizer(prompt, padding="max_length", max_length=tokenizer.model_max_length, truncation=True,
-                    return_tensors="pt").input_ids.to(device)
-    if clip_skip is None:
-        return text_encoder(ids)[0]
-    out = text_encoder(ids, output_hidden_states=True)
-    h = out[-1][-(clip_skip + 1)]
-    return text_encoder.text_model.final_layer_norm(h)
+    return text_encoder.encode(prompt, device, clip_skip)
 
 
 def _clip_image(image_encoder, feature_extractor, image, width, device):
-    raise RuntimeError("CLIP image tower not available offline; pass image_embeddings= (SURVEY.md 8(f) F1)")
+    """``_encode_image`` (:411-441) on the centre-cropped, 224x224 bilinear-resized frame (:1051-1055)."""
+    return image_encoder.encode(image, width, device)

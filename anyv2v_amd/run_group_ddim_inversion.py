@@ -1,0 +1,142 @@
+"""Stage 1 CLI -- DDIM inversion of a list of clips (same flags / config keys / output files as the reference's
+``i2vgen-xl/run_group_ddim_inversion.py``):
+
+    python -m anyv2v_amd.run_group_ddim_inversion --template_config configs/group_ddim_inversion/template.yaml \
+                                                  --configs_json configs/group_ddim_inversion/group_config.json
+
+Under ``torchrun --nproc-per-node N`` the active entries are dealt round-robin to the ranks (one clip per GPU at a
+time); each rank writes its own ``ddim_latents_{t}.pt`` files, so stage 1 needs no collective.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+from pathlib import Path
+
+import torch
+from PIL import Image
+
+from .config import OmegaConf
+from .encoders import attach_synthetic_encoders
+from .parallel import init_distributed, seed_for_entry, shard_entries
+from .pipeline import I2VGenXLPipeline
+from .schedulers import DDIMInverseScheduler, DDIMScheduler
+from .utils import convert_video_to_frames, export_to_gif, load_ddim_latents_at_t, load_video_frames, seed_everything
+
+MODEL_ID = "ali-vilab/i2vgen-xl"
+
+
+def ddim_inversion(config, first_frame, frame_list, pipe: I2VGenXLPipeline, inverse_scheduler, g):
+    """``run_group_ddim_inversion.py:29-55``."""
+    pipe.scheduler = inverse_scheduler
+    video_latents_at_0 = pipe.encode_vae_video(frame_list, device=pipe._execution_device, height=config.image_size[1],
+                                               width=config.image_size[0])
+    ddim_latents = pipe.invert(prompt=config.prompt, image=first_frame, height=config.image_size[1],
+                               width=config.image_size[0], num_frames=config.n_frames,
+                               num_inference_steps=config.n_steps, guidance_scale=config.cfg,
+                               negative_prompt=config.negative_prompt, target_fps=config.target_fps,
+                               latents=video_latents_at_0, generator=g, return_dict=False, output_dir=config.output_dir)
+    logging.getLogger(__name__).debug(f"ddim_latents.shape: {ddim_latents.shape}")
+    return ddim_latents[0]  # [num_inference_steps, c, num_frames, h, w]
+
+
+def ddim_sampling(config, first_frame, ddim_latents_at_T, pipe: I2VGenXLPipeline, ddim_scheduler, ddim_init_latents_t_idx, g):
+    """``run_group_ddim_inversion.py:58-77``."""
+    pipe.scheduler = ddim_scheduler
+    return pipe(prompt=config.prompt, image=first_frame, height=config.image_size[1], width=config.image_size[0],
+                num_frames=config.n_frames, num_inference_steps=config.n_steps, guidance_scale=config.cfg,
+                negative_prompt=config.negative_prompt, target_fps=config.target_fps, latents=ddim_latents_at_T,
+                generator=g, return_dict=True, ddim_init_latents_t_idx=ddim_init_latents_t_idx).frames[0]
+
+
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None):
+    rank, local_rank, world = init_distributed()
+    pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
+                                            variant="fp16", random_init_seed=random_init_seed)
+    pipe.to(device)
+    if synthetic_encoders:
+        attach_synthetic_encoders(pipe)
+    inverse_scheduler = DDIMInverseScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
+    ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
+    video_dir = template_config.video_dir
+    assert os.path.exists(video_dir), f"video_dir: {video_dir} does not exist"
+    all_active = [e for e in configs_list if e["active"] is not False]
+    for config_entry in configs_list:
+        if config_entry["active"] is False:
+            logger.info(f"Skipping config_entry: {config_entry}")
+    for config_entry in shard_entries(configs_list, rank, world):
+        entry_idx = all_active.index(config_entry)
+        logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
+        config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
+        config.video_path = os.path.join(config.video_dir, config.video_name + ".mp4")
+        config.video_frames_path = os.path.join(config.video_dir, config.video_name)
+        if os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False):
+            logger.info(f"### Skipping !!! {config.output_dir} already exists. ")
+            continue
+        logger.info(f"config: {OmegaConf.to_yaml(config)}")
+        try:
+            logger.info(f"Loading frames from: {config.video_frames_path}")
+            _, frame_list = load_video_frames(config.video_frames_path, config.n_frames, tuple(config.image_size))
+        except Exception:
+            logger.error(f"Failed to load frames from: {config.video_frames_path}")
+            logger.info(f"Converting mp4 video to frames: {config.video_path}")
+            frame_list = convert_video_to_frames(config.video_path, tuple(config.image_size), save_frames=True)
+            frame_list = frame_list[: config.n_frames]
+            export_to_gif(frame_list, os.path.join(config.video_frames_path, config.video_name + ".gif"))
+        first_frame = frame_list[0]
+        if config.inverse_config.inverse_static_video:
+            logger.info("### Inverse a static video!")
+            frame_list = [frame_list[0]] * config.n_frames
+        if config.inverse_config.null_image_inversion:
+            logger.info("### Inverse a null image!")
+            first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
+        seed_everything(seed_for_entry(template_config.seed, entry_idx) if world > 1 else template_config.seed)
+        g = torch.Generator().manual_seed(template_config.seed)
+        ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, inverse_scheduler, g)
+        recon_config = config.recon_config
+        if recon_config.enable_recon:
+            t_idx = recon_config.ddim_init_latents_t_idx
+            ddim_scheduler.set_timesteps(recon_config.n_steps)
+            logger.info(f"ddim_scheduler.timesteps: {ddim_scheduler.timesteps}")
+            # in-memory hand-off of the trajectory (the files are being written in the background)
+            traj = pipe._last_trajectory
+            ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
+            reconstructed_video = ddim_sampling(recon_config, first_frame, ddim_latents_at_t, pipe, ddim_scheduler, t_idx, g)
+            os.makedirs(config.output_dir, exist_ok=True)
+            reconstructed_video = [f.resize((512, 512), resample=Image.LANCZOS) for f in reconstructed_video]
+            export_to_gif(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.gif"), fps=10)
+            logger.info(f"Saved reconstructed video to {config.output_dir}")
+        pipe._last_trajectory.wait()
+
+
+def cli(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--template_config", type=str, default="./configs/group_ddim_inversion/template.yaml")
+    parser.add_argument("--configs_json", type=str, default="./configs/group_config.json")
+    parser.add_argument("--synthetic_encoders", action="store_true",
+                        help="use the weight-free stand-ins for VAE/CLIP (no pretrained weights offline)")
+    parser.add_argument("--random_init_seed", type=int, default=None, help="random UNet weights (no checkpoint offline)")
+    args = parser.parse_args(argv)
+    template_config = OmegaConf.load(args.template_config)
+    logging_level = logging.DEBUG if template_config.debug else logging.INFO
+    logging.basicConfig(level=logging_level, format="%(asctime)s - %(levelname)s - [%(funcName)s] - %(message)s")
+    logger = logging.getLogger(__name__)
+    logger.info(f"template_config: {OmegaConf.to_yaml(template_config)}")
+    assert Path(args.configs_json).exists()
+    with open(args.configs_json, "r") as f:
+        configs_list = json.load(f)
+    logger.info(f"Loaded {len(configs_list)} configs from {args.configs_json}")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = template_config.device if world == 1 else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+    device = torch.device(dev)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    torch.set_grad_enabled(False)
+    seed_everything(template_config.seed)
+    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed)
+
+
+if __name__ == "__main__":
+    cli()

@@ -1,0 +1,164 @@
+"""Stage 2 CLI -- PnP edit of a list of (clip, edited first frame) entries (same flags / config keys / output files as
+the reference's ``i2vgen-xl/run_group_pnp_edit.py``):
+
+    python -m anyv2v_amd.run_group_pnp_edit --template_config configs/group_pnp_edit/template.yaml \
+                                            --configs_json configs/group_pnp_edit/group_config.json
+
+Under ``torchrun --nproc-per-node N`` entries are dealt round-robin to the ranks; after the local loop the edited
+latents of every rank's last entry are exchanged with ONE all_gather (RCCL over xGMI) and rank 0
+writes ``gathered_latents.pt`` next to the outputs.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+from pathlib import Path
+
+import torch
+from PIL import Image
+
+from .config import OmegaConf
+from .encoders import attach_synthetic_encoders
+from .parallel import gather_latents, init_distributed, seed_for_entry, shard_entries
+from .pipeline import I2VGenXLPipeline
+from .pnp_utils import register_conv_injection, register_spatial_attention_pnp, register_temp_attention_pnp
+from .schedulers import DDIMScheduler
+from .utils import (LatentTrajectory, convert_video_to_frames, export_to_gif, load_ddim_latents_at_t, load_image,
+                    load_video_frames, seed_everything)
+
+MODEL_ID = "ali-vilab/i2vgen-xl"
+
+
+def init_pnp(pipe, scheduler, config):
+    """``run_group_pnp_edit.py:35-56``: int() truncation; schedules are prefixes of the FULL timestep list."""
+    conv_injection_t = int(config.n_steps * config.pnp_f_t)
+    spatial_attn_qk_injection_t = int(config.n_steps * config.pnp_spatial_attn_t)
+    temp_attn_qk_injection_t = int(config.n_steps * config.pnp_temp_attn_t)
+    ts = scheduler.timesteps
+    register_conv_injection(pipe, ts[:conv_injection_t] if conv_injection_t >= 0 else [])
+    register_spatial_attention_pnp(pipe, ts[:spatial_attn_qk_injection_t] if spatial_attn_qk_injection_t >= 0 else [])
+    register_temp_attention_pnp(pipe, ts[:temp_attn_qk_injection_t] if temp_attn_qk_injection_t >= 0 else [])
+    logger = logging.getLogger(__name__)
+    logger.debug(f"conv_injection_t: {conv_injection_t}")
+    logger.debug(f"spatial_attn_qk_injection_t: {spatial_attn_qk_injection_t}")
+    logger.debug(f"temp_attn_qk_injection_t: {temp_attn_qk_injection_t}")
+
+
+def output_suffix(config, ddim_init_latents_t_idx) -> str:
+    """``run_group_pnp_edit.py:154-167``."""
+    return ("ddim_init_latents_t_idx_" + str(ddim_init_latents_t_idx) + "_nsteps_" + str(config.n_steps) + "_cfg_"
+            + str(config.cfg) + "_pnpf" + str(config.pnp_f_t) + "_pnps" + str(config.pnp_spatial_attn_t) + "_pnpt"
+            + str(config.pnp_temp_attn_t))
+
+
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None):
+    rank, local_rank, world = init_distributed()
+    pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
+                                            variant="fp16", random_init_seed=random_init_seed)
+    pipe.to(device)
+    if synthetic_encoders:
+        attach_synthetic_encoders(pipe)
+    ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
+    all_active = [e for e in configs_list if e["active"] is not False]
+    for config_entry in configs_list:
+        if config_entry["active"] is False:
+            logger.info(f"Skipping config_entry: {config_entry}")
+    last_latents, lat_shape = None, None
+    for config_entry in shard_entries(configs_list, rank, world):
+        entry_idx = all_active.index(config_entry)
+        logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
+        config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
+        config.video_path = os.path.join(config.video_dir, config.video_name + ".mp4")
+        config.video_frames_path = os.path.join(config.video_dir, config.video_name)
+        config.edited_first_frame_path = os.path.join(config.data_dir, config.edited_first_frame_path)
+        logger.info(f"config: {OmegaConf.to_yaml(config)}")
+        for k, v in config.items():  # logs only -- the reference's `continue` continues this inner loop (:89-93)
+            if "ReplaceMe" in str(v):
+                logger.error(f"Field {k} contains 'ReplaceMe'")
+        try:
+            logger.info(f"Loading frames from: {config.video_frames_path}")
+            _, frame_list = load_video_frames(config.video_frames_path, config.n_frames, tuple(config.image_size))
+        except Exception:
+            logger.error(f"Failed to load frames from: {config.video_frames_path}")
+            frame_list = convert_video_to_frames(config.video_path, tuple(config.image_size), save_frames=True)
+            frame_list = frame_list[: config.n_frames]
+        src_1st_frame = frame_list[0]
+        edited_1st_frame = load_image(config.edited_first_frame_path)
+        edited_1st_frame = edited_1st_frame.resize(tuple(config.image_size), resample=Image.Resampling.LANCZOS)
+
+        t_idx = config.ddim_init_latents_t_idx
+        ddim_scheduler.set_timesteps(config.n_steps)
+        logger.info(f"ddim_scheduler.timesteps: {ddim_scheduler.timesteps}")
+        # read the whole source trajectory once into HBM (the reference re-reads one file per step, :1134)
+        traj = LatentTrajectory.load(config.ddim_latents_path, device=device,
+                                     timesteps=[int(t) for t in ddim_scheduler.timesteps[t_idx:]])
+        ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
+        seed_everything(seed_for_entry(template_config.seed, entry_idx) if world > 1 else template_config.seed)
+        random_latents = torch.randn(ddim_latents_at_t.shape, dtype=torch.float32).to(ddim_latents_at_t)  # drawn even if unused (:124)
+        logger.info(f"Blending random_ratio (1 means random latent): {config.random_ratio}")
+        mixed_latents = random_latents * config.random_ratio + ddim_latents_at_t * (1 - config.random_ratio)
+
+        init_pnp(pipe, ddim_scheduler, config)
+        pipe.register_modules(scheduler=ddim_scheduler)
+        edited_latents = pipe.sample_with_pnp(
+            prompt=config.editing_prompt, image=edited_1st_frame, height=config.image_size[1], width=config.image_size[0],
+            num_frames=config.n_frames, num_inference_steps=config.n_steps, guidance_scale=config.cfg,
+            negative_prompt=config.editing_negative_prompt, target_fps=config.target_fps, latents=mixed_latents,
+            generator=torch.manual_seed(config.seed), return_dict=True, ddim_init_latents_t_idx=t_idx,
+            ddim_inv_latents_path=traj, ddim_inv_prompt=config.ddim_inv_prompt, ddim_inv_1st_frame=src_1st_frame,
+            output_type="latent").frames
+        last_latents, lat_shape = edited_latents, tuple(edited_latents.shape)
+        video = pipe.decode_latents(edited_latents, decode_chunk_size=1)
+        edited_video = pipe.vae.to_pil(video)
+
+        output_dir = os.path.join(config.output_dir, output_suffix(config, t_idx))
+        os.makedirs(output_dir, exist_ok=True)
+        edited_video = [frame.resize(tuple(config.image_size), resample=Image.LANCZOS) for frame in edited_video]
+        name = "video"
+        export_to_gif(edited_video, os.path.join(output_dir, f"{name}.gif"), fps=config.target_fps)
+        logger.info(f"Saved gif to: {os.path.join(output_dir, f'{name}.gif')} (mp4 export needs ffmpeg, absent here)")
+        for i, frame in enumerate(edited_video):
+            frame.save(os.path.join(output_dir, f"{name}_{i:05d}.png"))
+        torch.save(edited_latents.cpu(), os.path.join(output_dir, "edited_latents.pt"))
+
+    if world > 1:
+        import torch.distributed as dist
+        shape = lat_shape or (1, 4, template_config.n_frames, template_config.image_size[1] // 8, template_config.image_size[0] // 8)
+        gathered = gather_latents(last_latents, shape, torch.float16, device)
+        if rank == 0:
+            out = os.path.join(template_config.get("data_dir", "."), "gathered_latents.pt")
+            torch.save(torch.cat([g.cpu() for g in gathered]), out)
+            logger.info(f"all_gather of edited latents from {world} ranks -> {out}")
+        dist.barrier()
+
+
+def cli(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--template_config", type=str, default="./configs/group_pnp_edit/template.yaml")
+    parser.add_argument("--configs_json", type=str, default="./configs/group_config.json")
+    parser.add_argument("--synthetic_encoders", action="store_true")
+    parser.add_argument("--random_init_seed", type=int, default=None)
+    args = parser.parse_args(argv)
+    template_config = OmegaConf.load(args.template_config)
+    logging_level = logging.DEBUG if template_config.debug else logging.INFO
+    logging.basicConfig(level=logging_level, format="%(asctime)s - %(levelname)s - [%(funcName)s] - %(message)s")
+    logger = logging.getLogger(__name__)
+    logger.info(f"template_config: {OmegaConf.to_yaml(template_config)}")
+    assert Path(args.configs_json).exists()
+    with open(args.configs_json, "r") as f:
+        configs_list = json.load(f)
+    logger.info(f"Loaded {len(configs_list)} configs from {args.configs_json}")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = template_config.device if world == 1 else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+    device = torch.device(dev)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    torch.set_grad_enabled(False)
+    seed_everything(template_config.seed)
+    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed)
+
+
+if __name__ == "__main__":
+    cli()
