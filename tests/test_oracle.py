@@ -1,0 +1,135 @@
+"""The oracle is pinned before it is trusted (CPU, no GPU):
+  * against the committed golden fixtures, which were produced by running the REFERENCE's own files
+    (i2vgen-xl/pnp_utils.py, consisti2v/ddim_inverse_scheduler.py) -- tests/golden/make_golden.py;
+  * against the reference itself, live, when /root/reference is present (this container only);
+  * against the known answers logged in i2vgen-xl/demo.ipynb (timesteps, scheduler config).
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pnp_oracle, ref_stubs
+from oracle import schedulers_oracle as so
+from oracle.unet_oracle import UNetConfig, build_oracle, param_count, random_state_dict
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_param_count_matches_checkpoint_size():
+    # 2.841 GB fp16 UNet checkpoint of ali-vilab/i2vgen-xl
+    n = param_count(UNetConfig.i2vgen_xl())
+    assert n == 1_420_469_224
+    assert abs(n * 2 / 1e9 - 2.841) < 0.001
+
+
+def test_timesteps_known_answers_from_reference_notebook():
+    # i2vgen-xl/demo.ipynb:1201-1204,1228-1231: 50-step sampling timesteps 981, 961, ..., 21, 1
+    assert so.ddim_timesteps(50).tolist() == list(range(981, 0, -20))
+    # i2vgen-xl/demo.ipynb:498-505,994-997: 500-step inversion timesteps 1, 3, ..., 999
+    assert so.inverse_timesteps(500).tolist() == list(range(1, 1000, 2))
+    assert so.inverse_timesteps(50).tolist() == list(range(1, 1000, 20))
+
+
+def test_scheduler_oracle_vs_reference_generated_fixture():
+    g = torch.load(os.path.join(GOLD, "inverse_scheduler.pt"))
+    ac = so.alphas_cumprod()
+    np.testing.assert_allclose(ac, g["alphas_cumprod"].numpy(), rtol=2e-6, atol=1e-9)
+    assert ac[999] == 0.0  # zero terminal SNR
+    assert so.inverse_timesteps(50).tolist() == g["timesteps_50"].tolist()
+    assert so.inverse_timesteps(500).tolist() == g["timesteps_500"].tolist()
+    x, v = g["x"].numpy(), g["v"].numpy()
+    for k, ref in g.items():
+        if not k.startswith("inv_step_"):
+            continue
+        n, t = int(k.split("_n")[1].split("_")[0]), int(k.split("_t")[1])
+        # the reference takes sqrt() of the fp32 table entries in fp32; the oracle in float64 -> ~1e-6 differences
+        np.testing.assert_allclose(so.inverse_step(v, t, x, n, ac), ref.numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_ddim_step_inverts_inverse_step():
+    """The forward step at t undoes the inverse step that produced level t, for a fixed v (formulas SURVEY.md A.4)."""
+    ac = so.alphas_cumprod()
+    rng = np.random.default_rng(0)
+    x, v = rng.standard_normal((4, 8)), rng.standard_normal((4, 8))
+    for t in (21, 501, 981):
+        x_t = so.inverse_step(v, t, x, 50, ac)            # level t-20 -> t
+        # recover v in the parametrisation of level t, then step back
+        a_c, a_n = ac[t - 20], ac[t]
+        x0 = np.sqrt(a_c) * x - np.sqrt(1 - a_c) * v
+        eps = np.sqrt(a_c) * v + np.sqrt(1 - a_c) * x
+        v_t = np.sqrt(a_n) * eps - np.sqrt(1 - a_n) * x0
+        np.testing.assert_allclose(so.ddim_step(v_t, t, x_t, 50, ac), x, rtol=1e-5, atol=1e-6)
+
+
+def _mini():
+    g = torch.load(os.path.join(GOLD, "pnp_hooks_mini.pt"))
+    cfg = UNetConfig.mini()
+    unet = build_oracle(cfg, random_state_dict(cfg, g["mini_seed"]), dtype=torch.float32)
+    inp = g["inputs"]
+    kw = dict(fps=inp["fps"], image_latents=inp["image_latents"], image_embeddings=inp["image_embeddings"],
+              encoder_hidden_states=inp["encoder_hidden_states"])
+    return g, unet, inp, kw
+
+
+def test_pnp_oracle_vs_reference_generated_fixture():
+    """oracle.pnp_oracle (independent restatement) == the reference's pnp_utils.py run on the same model."""
+    g, unet, inp, kw = _mini()
+    with torch.no_grad():
+        torch.testing.assert_close(unet(inp["sample"], 981, **kw)[0], g["v_nohook_t981"], rtol=1e-5, atol=1e-5)
+        pnp_oracle.init_pnp(unet, g["n_steps"], **g["pnp"])
+        for t in (981, 701, 301, 101):
+            pnp_oracle.register_time(unet, t)
+            torch.testing.assert_close(unet(inp["sample"], t, **kw)[0], g[f"v_hook_t{t}"], rtol=1e-5, atol=1e-5)
+    # injection changed the target branches but not the source branch
+    assert torch.equal(g["v_hook_t981"][0], g["v_nohook_t981"][0]) or torch.allclose(g["v_hook_t981"][0], g["v_nohook_t981"][0], atol=1e-6)
+    assert not torch.allclose(g["v_hook_t981"][1:], g["v_nohook_t981"][1:], atol=1e-3)
+    # off every schedule -> hooks are a no-op: equals a fresh, un-hooked model at the same t
+    _, fresh, _, _ = _mini()
+    with torch.no_grad():
+        torch.testing.assert_close(g["v_hook_t101"], fresh(inp["sample"], 101, **kw)[0], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="/root/reference not present (GPU box)")
+def test_fixture_is_what_the_reference_produces_live():
+    """Re-run the reference's own pnp_utils.py here and compare with the committed fixture (fixture freshness)."""
+    ref = ref_stubs.load_reference_pnp_utils()
+    g, unet, inp, kw = _mini()
+    pipe = types.SimpleNamespace(unet=unet)
+    ts = torch.arange(g["n_steps"]).flip(0) * (1000 // g["n_steps"]) + 1
+    p, n = g["pnp"], g["n_steps"]
+    ref.register_conv_injection(pipe, ts[: int(n * p["pnp_f_t"])])
+    ref.register_spatial_attention_pnp(pipe, ts[: int(n * p["pnp_spatial_attn_t"])])
+    ref.register_temp_attention_pnp(pipe, ts[: int(n * p["pnp_temp_attn_t"])])
+    with torch.no_grad():
+        for t in (981, 301):
+            ref.register_time(pipe, t)
+            torch.testing.assert_close(unet(inp["sample"], t, **kw)[0], g[f"v_hook_t{t}"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="/root/reference not present (GPU box)")
+def test_reference_inverse_scheduler_live():
+    mod = ref_stubs.load_reference_inverse_scheduler()
+    s = mod.DDIMInverseScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False, set_alpha_to_one=True, steps_offset=1,
+                                 prediction_type="v_prediction", timestep_spacing="leading", rescale_betas_zero_snr=True)
+    np.testing.assert_allclose(so.alphas_cumprod(), s.alphas_cumprod.numpy(), rtol=2e-6, atol=1e-9)
+    s.set_timesteps(50)
+    ac = so.alphas_cumprod()
+    x, v = torch.randn(3, 5, dtype=torch.float64), torch.randn(3, 5, dtype=torch.float64)
+    for t in (1, 21, 981):
+        np.testing.assert_allclose(so.inverse_step(v.numpy(), t, x.numpy(), 50, ac), s.step(v, t, x).prev_sample.numpy(),
+                                   rtol=1e-5, atol=2e-5)
+
+
+def test_branch_independence_and_shared_softmax_identities():
+    """The two exact savings the native path uses: branches are independent, and with injected
+    Q/K one softmax serves all three V's."""
+    torch.manual_seed(0)
+    q, k, v = torch.randn(3, 2, 16, 8, dtype=torch.float64), torch.randn(3, 2, 16, 8, dtype=torch.float64), torch.randn(3, 2, 16, 8, dtype=torch.float64)
+    qi, ki = q.clone(), k.clone()
+    qi[1:], ki[1:] = q[:1], k[:1]
+    ref = torch.nn.functional.scaled_dot_product_attention(qi, ki, v)
+    p = torch.softmax(q[0] @ k[0].transpose(-1, -2) / 8 ** 0.5, -1)
+    torch.testing.assert_close(torch.stack([p @ v[i] for i in range(3)]), ref, rtol=1e-10, atol=1e-10)
