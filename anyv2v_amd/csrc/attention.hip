@@ -202,6 +202,101 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(const AttnK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Short-sequence attention (S <= 16, head_dim 64): the temporal self-attention of TransformerTemporalModel at the
+// benchmark's 16 frames (pnp_utils.py:247-334).  HBM-bound (4 x 2 KiB per (clip, pixel, head)); one WAVE owns one
+// (batch element, head):
+//   S^T[key][q] : 2 x v_mfma_f32_16x16x32_f16, K and Q fragments loaded straight from global (both are k-contiguous)
+//   softmax     : lane (q = l&15, key group l>>4) holds 4 keys -> in-lane + 2 shuffles
+//   O^T = V^T P^T : 4 x v_mfma_f32_16x16x16_f16; P^T is already the B operand; V^T fragments come from a row-major
+//                 2 KiB LDS image of V through ds_read_b64_tr_b16 (hardware 4x16 transpose; semantics pinned by
+//                 anyv2v_selftest): lane i of a 16-lane group supplies &V[4g + (i>>2)][d0 + 4(i&3)] and receives
+//                 V[4g + 0..3][d0 + i].
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
+
+__global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
+    __shared__ __attribute__((aligned(16))) half_t vs[4][16 * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long unit = (long long)blockIdx.x * 4 + w;  // (batch element, head)
+    if (unit >= (long long)p.batch * p.heads) return;      // wave-uniform; no block-level sync in this kernel
+    const int h = (int)(unit % p.heads);
+    const long long i = unit / p.heads;
+    const long long iq = p.qk_mod > 0 ? i % p.qk_mod : i;
+    const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
+    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
+    const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    const int l15 = lane & 15, g = lane >> 4;
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // fragments: lane (row = l15, k-chunk g): 8 halves at column 8 g + 32 ks
+    h8 qf[2], kf[2];
+    {
+        const int qr = l15 < p.Sq ? l15 : p.Sq - 1;
+        const half_t* qp = p.Q + (qbase + (long long)qr * p.q_seq) * p.ldq + h * 64 + 8 * g;
+        const half_t* kp = p.K + (kbase + (long long)l15 * p.kv_seq) * p.ldk + h * 64 + 8 * g;
+        const bool kok = l15 < p.Sk;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *(const h8*)(qp + 32 * ks);
+            kf[ks] = kok ? *(const h8*)(kp + 32 * ks) : zero8;
+        }
+    }
+    // V -> LDS row-major [16 keys][64 d]: lane (key = lane >> 2, chunks 2 (lane & 3), +1)
+    {
+        const int key = lane >> 2, c0 = 2 * (lane & 3);
+        const bool ok = key < p.Sk;
+        const half_t* vp = p.V + (vbase + (long long)key * p.kv_seq) * p.ldv + h * 64 + c0 * 8;
+        const h8 v0 = ok ? *(const h8*)vp : zero8;
+        const h8 v1 = ok ? *(const h8*)(vp + 8) : zero8;
+        *(h8*)(&vs[w][key * 64 + c0 * 8]) = v0;
+        *(h8*)(&vs[w][key * 64 + c0 * 8 + 8]) = v1;
+    }
+    // S^T = K Q^T: D[key = 4 g + r][q = l15]
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], s, 0, 0, 0);
+    const float c = p.scale_log2;
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (4 * g + r >= p.Sk) s[r] = -1e30f;
+        mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    h4 pf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float e = exp2f((s[r] - mx) * c);
+        sum += e;
+        pf[r] = (half_t)e;
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; same-wave LDS write -> read is ordered (in-order DS queue)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    half_t* op = p.O + (obase + (long long)l15 * p.q_seq) * p.ldo + h * 64 + 4 * g;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const half_t* src = &vs[w][(4 * g + (l15 >> 2)) * 64 + 16 * db + 4 * (l15 & 3)];
+        const fp16x4_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)src);
+        h4 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vf[j] = (half_t)vt[j];
+        f4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o, 0, 0, 0);
+        if (l15 < p.Sq) {
+            h4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[r] * inv);
+            *(h4*)(op + 16 * db) = ov;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Generic reference kernel: one thread per (batch, head, query); any head_dim <= 64, any strides.
 __global__ void attn_naive_kernel(const AttnK p) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +370,11 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     const bool fast = !(d->flags & 1) && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0 &&
                       av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) && av_aligned16(d->O);
     if (!fast) return launch_naive(k, s);
+    if (k.Sq <= 16 && k.Sk <= 16 && !(d->flags & 2)) {  // temporal attention at <= 16 frames: one wave per sequence
+        const long long units = (long long)k.batch * k.heads;
+        hipLaunchKernelGGL(short_attn_d64_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, k);
+        return av_launch_status("short_attn_d64");
+    }
     const long long nwg = (long long)k.batch * k.heads * k.q_tiles;
     AV_CHECK(nwg < (1ll << 31), "attention: grid too large");
     hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nwg), dim3(256), 0, s, k);

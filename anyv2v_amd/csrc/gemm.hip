@@ -6,12 +6,14 @@
 // conv_shortcut :117-122, residual :124, attn.to_q/to_k/to_v :175,:182-183, attn.to_out[0] :216, and the
 // diffusers-0.26.3 Linear/Conv2d/Conv3d layers of I2VGenXLUNet behind pipeline_i2vgen_xl.py:1146.
 //
-// Tile: 128 x (NF*32) x 64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64 x NF*16 via
-// v_mfma_f32_16x16x32_f16 with SWAPPED operands (a = weight fragment, b = activation fragment) so that a lane
-// ends up with 4 consecutive output channels of one token -> 8-byte LDS writes in the epilogue and full-line
-// coalesced 16-byte global stores.  LDS tiles are [row][64 k] with the 16-byte chunk index XOR-swizzled by
-// (row & 7): conflict-free for ds_read_b128 fragment reads (MI355X guide, T2).  Double-buffered; the next
-// K-tile is fetched (registers or LDS-DMA) while the current one is multiplied; one barrier per K-tile.
+// Wave tile: 64 x NF*16 via v_mfma_f32_16x16x32_f16 with SWAPPED operands (a = weight fragment, b = activation
+// fragment) so that a lane ends up with 4 consecutive output channels of one token -> 8-byte LDS writes in the
+// epilogue and full-line coalesced 16-byte global stores.  LDS tiles are [row][64 k] with the 16-byte chunk index
+// XOR-swizzled by (row & 7): conflict-free for the ds_read_b128 fragment reads (MI355X guide, T2); with LDS-DMA the
+// swizzle is applied on the global SOURCE address (destination stays lane-linear, guide rule 21).
+//   gemm_mfma_kernel  : 128 x NF*32 x 64, 4 waves 2x2, 2 LDS stages (register- or LDS-DMA-staged), 2 blocks/CU.
+//   gemm_mfma3_kernel : 256 x NF*32 x 64, 8 waves 4x2, 3 LDS stages by LDS-DMA two K-tiles ahead, counted
+//                       s_waitcnt vmcnt(N) + one raw s_barrier per K-tile (guide T3/T4) -- the large-M workhorse.
 #include "common.h"
 
 enum { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_TEMPORAL = 2 };
@@ -31,6 +33,7 @@ struct GemmK {
     int M, N, C0, C1, lda0, lda1, ldc, ldr, ldrv, rowvec_div;
     int mode, Hi, Wi, Ho, Wo, stride, up, F, HW, act;
     int taps, Ktot, nt0, nt1, tilesN;
+    int vec_epi;  // bias / rowvec may be read as 8-byte vectors
 };
 
 struct RowInfo {
@@ -38,49 +41,63 @@ struct RowInfo {
     int y, x;  // conv2d: yo*stride-1, xo*stride-1 ; temporal: y = frame index
 };
 
+template <int MODE>
 __device__ __forceinline__ RowInfo make_row(const GemmK& p, int m) {
     RowInfo r;
-    if (m >= p.M) {
-        r.base = -1;
-        r.y = r.x = -(1 << 28);
-        return r;
-    }
-    if (p.mode == MODE_CONV2D) {
+    const bool ok = m < p.M;
+    if constexpr (MODE == MODE_CONV2D) {
         const int hw = p.Ho * p.Wo;
         const int img = m / hw, rem = m - img * hw;
         const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
         r.base = img * p.Hi * p.Wi;
-        r.y = yo * p.stride - 1;
+        r.y = ok ? yo * p.stride - 1 : -(1 << 28);
         r.x = xo * p.stride - 1;
-    } else if (p.mode == MODE_TEMPORAL) {
+    } else if constexpr (MODE == MODE_TEMPORAL) {
         r.base = m;
-        r.y = (m / p.HW) % p.F;
+        r.y = ok ? (m / p.HW) % p.F : -(1 << 28);
         r.x = 0;
     } else {
-        r.base = m;
+        r.base = ok ? m : -1;
         r.y = r.x = 0;
     }
     return r;
 }
 
-// source row of output row `r` for filter tap `tap`, or -1 when the tap falls into the zero padding
+// source row of output row `r` for filter tap `tap`, or -1 when the tap falls into the zero padding (branch-free)
+template <int MODE>
 __device__ __forceinline__ int src_row(const GemmK& p, const RowInfo& r, int tap) {
-    if (p.mode == MODE_CONV2D) {
+    if constexpr (MODE == MODE_CONV2D) {
         const int dy = tap / 3, dx = tap - dy * 3;
         int yi = r.y + dy, xi = r.x + dx;
-        const int ly = p.up ? 2 * p.Hi : p.Hi, lx = p.up ? 2 * p.Wi : p.Wi;
+        const int ly = p.Hi << p.up, lx = p.Wi << p.up;
         const bool ok = (yi >= 0) & (yi < ly) & (xi >= 0) & (xi < lx);
-        if (p.up) {
-            yi >>= 1;
-            xi >>= 1;
-        }
+        yi >>= p.up;
+        xi >>= p.up;
         return ok ? r.base + yi * p.Wi + xi : -1;
-    } else if (p.mode == MODE_TEMPORAL) {
+    } else if constexpr (MODE == MODE_TEMPORAL) {
         const int f = r.y + tap - 1;
         const bool ok = (f >= 0) & (f < p.F);
         return ok ? r.base + (tap - 1) * p.HW : -1;
+    } else {
+        return r.base;
     }
-    return r.base;
+}
+
+// per-K-tile A source: wave-uniform (base pointer, leading dim, column offset) + per-row select against the zero line
+struct ASrc {
+    const half_t* base;
+    int ld;
+};
+__device__ __forceinline__ ASrc a_source(const GemmK& p, int kt_c, int kc) {
+    ASrc s;
+    const bool first = kt_c < p.nt0;
+    s.base = (first ? p.A0 + kt_c * 64 : p.A1 + (kt_c - p.nt0) * 64) + kc * 8;
+    s.ld = first ? p.lda0 : p.lda1;
+    return s;
+}
+__device__ __forceinline__ const half_t* a_addr(const GemmK& p, const ASrc& s, int sr) {
+    const half_t* g = s.base + (long long)sr * s.ld;
+    return sr < 0 ? p.zeros : g;
 }
 
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
@@ -88,7 +105,119 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NF, bool GLDS, bool GEGLU>
+// ---------------------------------------------------------------------------------------------------------
+// Shared epilogue: accumulators -> (+bias, +temb row vector, activation / GEGLU) -> fp16 tile staged in LDS ->
+// (+residual) -> coalesced 16-byte stores.  Caller guarantees all waves are done with the pipeline LDS.
+template <int NF, bool GEGLU, int BM, int NTHREADS>
+__device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char* smem, int m_blk, int n_blk, int wr,
+                                         int wc, int lane, int tid) {
+    constexpr int BN = NF * 32;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    constexpr int CS_LD = BNO + 8;
+    half_t* const Cs = (half_t*)smem;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int Nout = GEGLU ? p.N / 2 : p.N;
+    const int n_out_blk = GEGLU ? n_blk / 2 : n_blk;
+    // All epilogue operands are fetched with unconditional 8-byte loads (absent / out-of-range -> the zero line),
+    // so the loads of a row fragment are in flight together instead of one branch + vmcnt(0) per element.
+    h4 bvec[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const int n = n_blk + wc * NF * 16 + nf * 16 + 4 * lq;
+        const half_t* src = (p.bias != nullptr && n + 4 <= p.N) ? p.bias + n : p.zeros;
+        bvec[nf] = *(const h4*)src;
+    }
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int ml = wr * 64 + mf * 16 + l15;
+        const int m = m_blk + ml;
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int np = 0; np < NF / 2; ++np) {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // torch: the proj output is rounded to fp16 before chunk / gelu / mul
+                    const float hv = (float)(half_t)(acc[mf][2 * np][r] + (float)bvec[2 * np][r]);
+                    const float gv = (float)(half_t)(acc[mf][2 * np + 1][r] + (float)bvec[2 * np + 1][r]);
+                    o[r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
+                }
+                *(h4*)(Cs + ml * CS_LD + wc * NF * 8 + np * 16 + 4 * lq) = o;
+            }
+        } else {
+            const bool has_rv = p.rowvec != nullptr && m < p.M;
+            const half_t* rv = p.rowvec + (size_t)((has_rv ? m : 0) / p.rowvec_div) * p.ldrv;
+            h4 tvec[NF];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int n = n_blk + wc * NF * 16 + nf * 16 + 4 * lq;
+                const half_t* src = (has_rv && n + 4 <= p.N) ? rv + n : p.zeros;
+                tvec[nf] = *(const h4*)src;
+            }
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int nl = wc * NF * 16 + nf * 16 + 4 * lq;
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[mf][nf][r] + (float)bvec[nf][r] + (float)tvec[nf][r];
+                    if (p.act == ACT_SILU)
+                        v = av_silu(v);
+                    else if (p.act == ACT_GELU)
+                        v = av_gelu(v);
+                    o[r] = (half_t)v;
+                }
+                *(h4*)(Cs + ml * CS_LD + nl) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BNO / 8;
+    for (int id = tid; id < BM * CPR; id += NTHREADS) {
+        const int r = id / CPR, cc = id - r * CPR;
+        const int m = m_blk + r;
+        const int n0 = n_out_blk + cc * 8;
+        if (m >= p.M || n0 >= Nout) continue;
+        h8 v = *(const h8*)(Cs + r * CS_LD + cc * 8);
+        if (n0 + 8 <= Nout) {
+            if (p.R != nullptr) {
+                const h8 rr = *(const h8*)(p.R + (size_t)m * p.ldr + n0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+            }
+            *(h8*)(p.C + (size_t)m * p.ldc + n0) = v;
+        } else {
+            for (int e = 0; e < 8 && n0 + e < Nout; ++e) {
+                float x = (float)v[e];
+                if (p.R != nullptr) x += (float)p.R[(size_t)m * p.ldr + n0 + e];
+                p.C[(size_t)m * p.ldc + n0 + e] = (half_t)x;
+            }
+        }
+    }
+}
+
+// one K-tile (64) of MFMA work for a 64 x NF*16 wave tile
+template <int NF>
+__device__ __forceinline__ void mma_tile(f4 (&acc)[4][NF], const char* as, const char* bs, int wr, int wc, int lane) {
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        h8 af[4], bf[NF];
+        const int c = (ks * 4 + lq) ^ (l15 & 7);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) af[mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bf[nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][nf], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int NF, bool GLDS, bool GEGLU, int MODE>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
     constexpr int BM = 128, BN = NF * 32;
     constexpr int A_BYTES = BM * 64 * 2;
@@ -111,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
     const int kc = pc ^ (srow0 & 7);
     RowInfo ri[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ri[i] = make_row(p, m_blk + srow0 + 32 * i);
+    for (int i = 0; i < 4; ++i) ri[i] = make_row<MODE>(p, m_blk + srow0 + 32 * i);
     const half_t* bptr[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -122,16 +251,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
 
     h8 ra[4], rb[NB];
     auto issue = [&](int kt_c, int tap, int kt, int buf) {
+        const ASrc s = a_source(p, kt_c, kc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int sr = src_row(p, ri[i], tap);
-            const half_t* g;
-            if (sr < 0)
-                g = p.zeros;
-            else if (kt_c < p.nt0)
-                g = p.A0 + (size_t)sr * p.lda0 + kt_c * 64 + kc * 8;
-            else
-                g = p.A1 + (size_t)sr * p.lda1 + (kt_c - p.nt0) * 64 + kc * 8;
+            const half_t* g = a_addr(p, s, src_row<MODE>(p, ri[i], tap));
             if constexpr (GLDS)
                 glds16(g, As0 + buf * A_BYTES + (i * 256 + w * 64) * 16);
             else
@@ -159,26 +282,6 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int l15 = lane & 15, lq = lane >> 4;
-    auto compute = [&](int buf) {
-        const char* as = As0 + buf * A_BYTES;
-        const char* bs = Bs0 + buf * B_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 af[4], bf[NF];
-            const int c = (ks * 4 + lq) ^ (l15 & 7);
-#pragma unroll
-            for (int mf = 0; mf < 4; ++mf) af[mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) bf[nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
-#pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf)
-                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][nf], 0, 0, 0);
-        }
-    };
-
     const int ntap = p.nt0 + p.nt1;
     const int nk = p.taps * ntap;
     int tap = 0, kt_c = 0;
@@ -195,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
         }
         const bool has_next = kt + 1 < nk;
         if (has_next) issue(nkt_c, ntp, kt + 1, cur ^ 1);
-        compute(cur);
+        mma_tile<NF>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
         if constexpr (!GLDS) {
             if (has_next) commit(cur ^ 1);
         } else {
@@ -205,89 +308,110 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
         kt_c = nkt_c;
         tap = ntp;
     }
+    epilogue<NF, GEGLU, BM, 256>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid);
+}
 
-    // ---------------- epilogue: registers -> (bias, temb, act) -> fp16 tile in LDS -> (+residual) -> global
-    constexpr int BNO = GEGLU ? BN / 2 : BN;
-    constexpr int CS_LD = BNO + 8;
-    half_t* const Cs = (half_t*)smem;
-    const int Nout = GEGLU ? p.N / 2 : p.N;
-    const int n_out_blk = GEGLU ? n_blk / 2 : n_blk;
+// ---------------------------------------------------------------------------------------------------------
+// Large-M variant (see file header).  All LDS lives in ONE __shared__ array and every operand goes through LDS-DMA
+// so that hipcc does not insert vmcnt(0) drains into the K loop (checked in the .s: the loop body holds exactly one
+// counted s_waitcnt vmcnt and one s_barrier).
+template <int NF, bool GEGLU, int MODE>
+__global__ __launch_bounds__(512) void gemm_mfma3_kernel(const GemmK p) {
+    constexpr int BM = 256, BN = NF * 32, STAGES = 3;
+    constexpr int A_BYTES = BM * 64 * 2;
+    constexpr int B_BYTES = BN * 64 * 2;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NBI = (BN * 8 + 511) / 512;  // B LDS-DMA instructions per thread per tile
+    constexpr int REM = BN * 8 - (NBI - 1) * 512;  // chunks covered by the last one (multiple of 64)
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    const int m_blk = mt * BM, n_blk = nt * BN;
+
+    const int srow0 = tid >> 3;  // 0..63
+    const int pc = tid & 7;
+    const int kc = pc ^ (srow0 & 7);
+    RowInfo ri[4];
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int ml = wr * 64 + mf * 16 + l15;
-        const int m = m_blk + ml;
-        const half_t* rv = nullptr;
-        if (p.rowvec != nullptr && m < p.M) rv = p.rowvec + (size_t)(m / p.rowvec_div) * p.ldrv;
-        if constexpr (GEGLU) {
+    for (int i = 0; i < 4; ++i) ri[i] = make_row<MODE>(p, m_blk + srow0 + 64 * i);
+    const half_t* bptr[NBI];
+    int blds[NBI];
 #pragma unroll
-            for (int np = 0; np < NF / 2; ++np) {
-                const int nh = n_blk + wc * NF * 16 + np * 32 + 4 * lq;  // packed row of h; gate = +16
-                h4 o;
+    for (int i = 0; i < NBI; ++i) {
+        // waves beyond REM chunks of the last instruction re-load the same chunks (same bytes, benign)
+        const int chunk = (i < NBI - 1) ? i * 512 + tid : (NBI - 1) * 512 + (tid % REM);
+        const int row = chunk >> 3;
+        int n = n_blk + row;
+        n = n < p.N ? n : p.N - 1;
+        bptr[i] = p.W + (size_t)n * p.Ktot + ((chunk & 7) ^ (row & 7)) * 8;
+        blds[i] = A_BYTES + (chunk - lane) * 16;  // wave-uniform LDS-DMA base (lane-linear destination)
+    }
+
+    auto issue = [&](int kt_c, int tap, int kt, int stage) {
+        char* st = smem + stage * STAGE_BYTES;
+        const ASrc s = a_source(p, kt_c, kc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float hv = acc[mf][2 * np][r], gv = acc[mf][2 * np + 1][r];
-                    if (p.bias != nullptr) {
-                        hv += (float)p.bias[nh + r];
-                        gv += (float)p.bias[nh + 16 + r];
-                    }
-                    // torch: proj output is rounded to fp16 before chunk / gelu / mul
-                    hv = (float)(half_t)hv;
-                    gv = (float)(half_t)gv;
-                    o[r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
-                }
-                *(h4*)(Cs + ml * CS_LD + wc * NF * 8 + np * 16 + 4 * lq) = o;
-            }
-        } else {
+        for (int i = 0; i < 4; ++i) glds16(a_addr(p, s, src_row<MODE>(p, ri[i], tap)), st + (i * 512 + w * 64) * 16);
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) {
-                const int nl = wc * NF * 16 + nf * 16 + 4 * lq;
-                const int n = n_blk + nl;
-                h4 o;
+        for (int i = 0; i < NBI; ++i) glds16(bptr[i] + (size_t)kt * 64, st + __builtin_amdgcn_readfirstlane(blds[i]));
+    };
+
+    f4 acc[4][NF];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[mf][nf][r];
-                    if (n + r < p.N) {
-                        if (p.bias != nullptr) v += (float)p.bias[n + r];
-                        if (rv != nullptr) v += (float)rv[n + r];
-                    }
-                    if (p.act == ACT_SILU)
-                        v = av_silu(v);
-                    else if (p.act == ACT_GELU)
-                        v = av_gelu(v);
-                    o[r] = (half_t)v;
-                }
-                *(h4*)(Cs + ml * CS_LD + nl) = o;
-            }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int LPT = 4 + NBI;  // LDS-DMA instructions per thread per K-tile
+    static_assert(LPT == 6 || LPT == 7, "vmcnt immediates below assume 6 or 7 loads per tile");
+    const int ntap = p.nt0 + p.nt1;
+    const int nk = p.taps * ntap;
+    int i_ktc = 0, i_tap = 0;  // (tile-in-tap, tap) of the next tile to issue
+    auto advance = [&]() {
+        if (++i_ktc == ntap) {
+            i_ktc = 0;
+            ++i_tap;
         }
+    };
+    issue(i_ktc, i_tap, 0, 0);
+    advance();
+    if (nk > 1) {
+        issue(i_ktc, i_tap, 1, 1);
+        advance();
+    }
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt was issued two iterations ago; only tile kt+1's LPT loads may still be in flight
+        if (kt + 1 < nk) {
+            if constexpr (LPT == 7)
+                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // everyone's tile kt landed; everyone finished reading stage (kt-1)%3
+        if (kt + 2 < nk) {
+            int s2 = stage + 2;
+            if (s2 >= STAGES) s2 -= STAGES;
+            issue(i_ktc, i_tap, kt + 2, s2);
+            advance();
+        }
+        mma_tile<NF>(acc, smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wr, wc, lane);
+        if (++stage == STAGES) stage = 0;
     }
     __syncthreads();
-    constexpr int CPR = BNO / 8;
-    for (int id = tid; id < BM * CPR; id += 256) {
-        const int r = id / CPR, cc = id - r * CPR;
-        const int m = m_blk + r;
-        const int n0 = n_out_blk + cc * 8;
-        if (m >= p.M || n0 >= Nout) continue;
-        h8 v = *(const h8*)(Cs + r * CS_LD + cc * 8);
-        if (n0 + 8 <= Nout) {
-            if (p.R != nullptr) {
-                const h8 rr = *(const h8*)(p.R + (size_t)m * p.ldr + n0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
-            }
-            *(h8*)(p.C + (size_t)m * p.ldc + n0) = v;
-        } else {
-            for (int e = 0; e < 8 && n0 + e < Nout; ++e) {
-                float x = (float)v[e];
-                if (p.R != nullptr) x += (float)p.R[(size_t)m * p.ldr + n0 + e];
-                p.C[(size_t)m * p.ldc + n0 + e] = (half_t)x;
-            }
-        }
-    }
+    epilogue<NF, GEGLU, BM, 512>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Reference-grade kernel: one thread per output element, any shape.  Used for the tiny once-per-clip
-// conditioning layers (Cin = 4/16/32 ...) and as the on-device cross-check of the MFMA kernel in the tests.
+// conditioning layers (Cin = 4/16/32 ...) and as the on-device cross-check of the MFMA kernels in the tests.
+template <int MODE>
 __global__ void gemm_naive_kernel(const GemmK p) {
     const bool geglu = p.act == ACT_GEGLU;
     const int Nout = geglu ? p.N / 2 : p.N;
@@ -295,11 +419,11 @@ __global__ void gemm_naive_kernel(const GemmK p) {
     if (idx >= (long long)p.M * Nout) return;
     const int m = (int)(idx / Nout), j = (int)(idx - (long long)m * Nout);
     const int n = geglu ? 32 * (j / 16) + (j % 16) : j;
-    const RowInfo ri = make_row(p, m);
+    const RowInfo ri = make_row<MODE>(p, m);
     const int K = p.C0 + p.C1;
     float a0 = 0.f, a1 = 0.f;
     for (int tap = 0; tap < p.taps; ++tap) {
-        const int sr = src_row(p, ri, tap);
+        const int sr = src_row<MODE>(p, ri, tap);
         if (sr < 0) continue;
         const half_t* w0 = p.W + (size_t)n * p.Ktot + (size_t)tap * K;
         const half_t* w1 = w0 + (size_t)16 * p.Ktot;
@@ -350,10 +474,44 @@ static const half_t* zero_line() {
     return z;
 }
 
-template <int NF, bool GLDS, bool GEGLU>
-static void launch_mfma(const GemmK& k, hipStream_t s) {
-    const int tilesM = (k.M + 127) / 128;
-    hipLaunchKernelGGL((gemm_mfma_kernel<NF, GLDS, GEGLU>), dim3(tilesM * k.tilesN), dim3(256), 0, s, k);
+template <int MODE>
+static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s) {
+    const bool geglu = d->act == ACT_GEGLU;
+    if (!fast) {
+        const int Nout = geglu ? d->N / 2 : d->N;
+        const long long total = (long long)d->M * Nout;
+        hipLaunchKernelGGL(gemm_naive_kernel<MODE>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
+        return av_launch_status("gemm_naive");
+    }
+    const bool glds = (d->flags & 2) != 0;
+    const int nf = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
+    k.tilesN = (d->N + nf * 32 - 1) / (nf * 32);
+    if (glds && !(d->flags & 4) && d->M >= 8192) {  // large M: 256-row tile, 3-stage LDS-DMA ring
+        const dim3 grid(((d->M + 255) / 256) * k.tilesN);
+        if (geglu)
+            hipLaunchKernelGGL((gemm_mfma3_kernel<4, true, MODE>), grid, dim3(512), 0, s, k);
+        else if (nf == 5)
+            hipLaunchKernelGGL((gemm_mfma3_kernel<5, false, MODE>), grid, dim3(512), 0, s, k);
+        else
+            hipLaunchKernelGGL((gemm_mfma3_kernel<4, false, MODE>), grid, dim3(512), 0, s, k);
+        return av_launch_status("gemm_mfma3");
+    }
+    const dim3 grid(((d->M + 127) / 128) * k.tilesN);
+#define AV_LAUNCH2(NF_, GEGLU_)                                                                          \
+    do {                                                                                                 \
+        if (glds)                                                                                        \
+            hipLaunchKernelGGL((gemm_mfma_kernel<NF_, true, GEGLU_, MODE>), grid, dim3(256), 0, s, k);   \
+        else                                                                                             \
+            hipLaunchKernelGGL((gemm_mfma_kernel<NF_, false, GEGLU_, MODE>), grid, dim3(256), 0, s, k);  \
+    } while (0)
+    if (geglu)
+        AV_LAUNCH2(4, true);
+    else if (nf == 5)
+        AV_LAUNCH2(5, false);
+    else
+        AV_LAUNCH2(4, false);
+#undef AV_LAUNCH2
+    return av_launch_status("gemm_mfma");
 }
 
 extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
@@ -368,6 +526,7 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
         AV_CHECK(d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && (d->stride == 1 || d->stride == 2),
                  "gemm: bad conv geometry");
         AV_CHECK(d->M % (d->Ho * d->Wo) == 0, "gemm: M not a multiple of Ho*Wo");
+        AV_CHECK(d->up == 0 || d->up == 1, "gemm: up must be 0 or 1");
     }
     if (d->mode == MODE_TEMPORAL) {
         AV_CHECK(d->F > 0 && d->HW > 0 && d->M % (d->F * d->HW) == 0, "gemm: bad temporal geometry");
@@ -378,7 +537,7 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     }
     GemmK k;
     k.A0 = (const half_t*)d->A0;
-    k.A1 = (const half_t*)d->A1;
+    k.A1 = d->C1 > 0 ? (const half_t*)d->A1 : (const half_t*)d->A0;
     k.W = (const half_t*)d->W;
     k.C = (half_t*)d->C;
     k.bias = (const half_t*)d->bias;
@@ -387,7 +546,7 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     k.zeros = zero_line();
     AV_CHECK(k.zeros != nullptr, "gemm: zero line symbol unavailable");
     k.M = d->M; k.N = d->N; k.C0 = d->C0; k.C1 = d->C1;
-    k.lda0 = d->lda0; k.lda1 = d->lda1; k.ldc = d->ldc; k.ldr = d->ldr; k.ldrv = d->ldrv;
+    k.lda0 = d->lda0; k.lda1 = d->C1 > 0 ? d->lda1 : d->lda0; k.ldc = d->ldc; k.ldr = d->ldr; k.ldrv = d->ldrv;
     k.rowvec_div = d->rowvec_div > 0 ? d->rowvec_div : 1;
     k.mode = d->mode; k.Hi = d->Hi; k.Wi = d->Wi; k.Ho = d->Ho; k.Wo = d->Wo; k.stride = d->stride; k.up = d->up;
     k.F = d->F; k.HW = d->HW; k.act = d->act;
@@ -395,29 +554,17 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     k.Ktot = k.taps * (d->C0 + d->C1);
     k.nt0 = d->C0 / 64;
     k.nt1 = d->C1 / 64;
+    k.tilesN = 1;
+    k.vec_epi = (((uintptr_t)d->bias & 7) == 0) && (((uintptr_t)d->rowvec & 7) == 0) && (d->ldrv % 4 == 0) && (d->N % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
 
     const bool geglu = d->act == ACT_GEGLU;
-    bool fast = !(d->flags & 1) && d->C0 % 64 == 0 && d->C1 % 64 == 0 && d->lda0 % 8 == 0 &&
-                (d->C1 == 0 || d->lda1 % 8 == 0) && d->ldc % 8 == 0 && av_aligned16(d->A0) && av_aligned16(d->A1) &&
-                av_aligned16(d->W) && av_aligned16(d->C) && (d->R == nullptr || (d->ldr % 8 == 0 && av_aligned16(d->R))) &&
-                (!geglu || d->N % 128 == 0);
-    if (!fast) {
-        const int Nout = geglu ? d->N / 2 : d->N;
-        const long long total = (long long)d->M * Nout;
-        hipLaunchKernelGGL(gemm_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
-        return av_launch_status("gemm_naive");
-    }
-    const bool glds = (d->flags & 2) != 0;
-    if (geglu) {
-        k.tilesN = d->N / 128;
-        if (glds) launch_mfma<4, true, true>(k, s); else launch_mfma<4, false, true>(k, s);
-    } else if (d->N % 160 == 0) {
-        k.tilesN = d->N / 160;
-        if (glds) launch_mfma<5, true, false>(k, s); else launch_mfma<5, false, false>(k, s);
-    } else {
-        k.tilesN = (d->N + 127) / 128;
-        if (glds) launch_mfma<4, true, false>(k, s); else launch_mfma<4, false, false>(k, s);
-    }
-    return av_launch_status("gemm_mfma");
+    const bool fast = !(d->flags & 1) && d->C0 % 64 == 0 && d->C1 % 64 == 0 && d->lda0 % 8 == 0 &&
+                      (d->C1 == 0 || d->lda1 % 8 == 0) && d->ldc % 8 == 0 && av_aligned16(d->A0) &&
+                      (d->C1 == 0 || av_aligned16(d->A1)) && av_aligned16(d->W) && av_aligned16(d->C) &&
+                      (d->R == nullptr || (d->ldr % 8 == 0 && av_aligned16(d->R))) && (!geglu || d->N % 128 == 0) &&
+                      k.vec_epi;
+    if (d->mode == MODE_CONV2D) return dispatch<MODE_CONV2D>(k, d, fast, s);
+    if (d->mode == MODE_TEMPORAL) return dispatch<MODE_TEMPORAL>(k, d, fast, s);
+    return dispatch<MODE_LINEAR>(k, d, fast, s);
 }

@@ -4,21 +4,21 @@
 // i2vgen-xl/pnp_utils.py:48,104), Transformer2DModel.norm, TemporalConvLayer / TransformerTemporalModel.norm
 // (5-D: statistics over all frames of a clip) and conv_norm_out.  The input may be the channel concat [X0 | X1]
 // (skip connection of the up blocks, consisti2v/.../videoldm_unet_blocks.py:721-745) without materialising it.
-// Two kernels: (1) partial sums per (stat-group, channel-group) reduced through LDS then global atomics into a
-// zeroed scratch, (2) normalise + affine (+ SiLU) -> fp16.  Algorithmic traffic: 2 reads + 1 write of X.
+// Three kernels, no atomics (bit-reproducible): (1) partial sums per (stat group, row chunk, channel group) reduced
+// through LDS, (2) chunk reduction -> (mean, rstd), (3) normalise + affine (+ SiLU) -> fp16.
+// Algorithmic traffic: 2 reads + 1 write of X.
 #include "common.h"
 
-__global__ void gn_stats_kernel(const half_t* __restrict__ X0, const half_t* __restrict__ X1, int C0, int C1,
-                                float* __restrict__ stats, int rows_per_group, int G, int rows_chunk, int rpb) {
-    __shared__ float ssum[64], ssq[64];
+#define GN_MAX_CHUNKS 256
+
+// (1) per-(stat group, row chunk) partial sums, reduced deterministically through LDS (no atomics)
+__global__ void gn_partial_kernel(const half_t* __restrict__ X0, const half_t* __restrict__ X1, int C0, int C1,
+                                  float* __restrict__ partial, int rows_per_group, int G, int rows_chunk, int rpb,
+                                  int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [rpb][C][2]
     const int C = C0 + C1, V = C >> 3, cpg = C / G;
     const int sg = blockIdx.x, chunk = blockIdx.y;
     const int tid = threadIdx.x;
-    if (tid < 64) {
-        ssum[tid] = 0.f;
-        ssq[tid] = 0.f;
-    }
-    __syncthreads();
     const int rl = tid / V, v = tid - rl * V;
     if (rl < rpb) {
         const int r_begin = chunk * rows_chunk;
@@ -32,9 +32,23 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ X0, const half_t* __r
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-        const size_t row0 = (size_t)sg * rows_per_group;
-        for (int r = r_begin + rl; r < r_end; r += rpb) {
-            const h8 x = *(const h8*)(base + (row0 + r) * ld + cc);
+        const half_t* ptr = base + ((size_t)sg * rows_per_group) * ld + cc;
+        int r = r_begin + rl;
+        for (; r + 3 * rpb < r_end; r += 4 * rpb) {  // 4 independent 16-byte loads in flight
+            h8 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = *(const h8*)(ptr + (size_t)(r + u * rpb) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)x[u][e];
+                    s[e] += f;
+                    q[e] += f * f;
+                }
+        }
+        for (; r < r_end; r += rpb) {
+            const h8 x = *(const h8*)(ptr + (size_t)r * ld);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)x[e];
@@ -42,36 +56,62 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ X0, const half_t* __r
                 q[e] += f * f;
             }
         }
-        int g = c0 / cpg;
-        float as = 0.f, aq = 0.f;
+        float* dst = red + ((size_t)rl * C + c0) * 2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ge = (c0 + e) / cpg;
-            if (ge != g) {
-                atomicAdd(&ssum[g], as);
-                atomicAdd(&ssq[g], aq);
-                as = aq = 0.f;
-                g = ge;
-            }
-            as += s[e];
-            aq += q[e];
-        }
-        atomicAdd(&ssum[g], as);
-        atomicAdd(&ssq[g], aq);
+        for (int e = 0; e < 8; e += 2) *(f4*)(dst + 2 * e) = (f4){s[e], q[e], s[e + 1], q[e + 1]};
     }
     __syncthreads();
     if (tid < G) {
-        atomicAdd(&stats[((size_t)sg * G + tid) * 2 + 0], ssum[tid]);
-        atomicAdd(&stats[((size_t)sg * G + tid) * 2 + 1], ssq[tid]);
+        float as = 0.f, aq = 0.f;
+        for (int rr = 0; rr < rpb; ++rr) {
+            const float* src = red + ((size_t)rr * C + tid * cpg) * 2;
+            for (int c = 0; c < cpg; ++c) {
+                as += src[2 * c];
+                aq += src[2 * c + 1];
+            }
+        }
+        float* o = partial + (((size_t)sg * nchunks + chunk) * G + tid) * 2;
+        o[0] = as;
+        o[1] = aq;
     }
 }
 
+// (2) reduce the chunks -> (mean, rstd) per (stat group, channel group)
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mr, int nchunks, int G,
+                                   float inv_cnt, float eps) {
+    __shared__ float rs[256], rq[256];
+    const int sg = blockIdx.x, tid = threadIdx.x;
+    const int parts = 256 / G;  // G <= 64
+    const int g = tid % G, part = tid / G;
+    float as = 0.f, aq = 0.f;
+    if (part < parts)
+        for (int c = part; c < nchunks; c += parts) {
+            const float* src = partial + (((size_t)sg * nchunks + c) * G + g) * 2;
+            as += src[0];
+            aq += src[1];
+        }
+    rs[tid] = as;
+    rq[tid] = aq;
+    __syncthreads();
+    if (tid < G) {
+        float s = 0.f, q = 0.f;
+        for (int p2 = 0; p2 < parts; ++p2) {
+            s += rs[p2 * G + tid];
+            q += rq[p2 * G + tid];
+        }
+        const float mean = s * inv_cnt;
+        const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
+        mr[((size_t)sg * G + tid) * 2 + 0] = mean;
+        mr[((size_t)sg * G + tid) * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+// (3) normalise + affine (+ SiLU)
 __global__ void gn_apply_kernel(const half_t* __restrict__ X0, const half_t* __restrict__ X1, int C0, int C1,
                                 half_t* __restrict__ Y, const half_t* __restrict__ gamma,
-                                const half_t* __restrict__ beta, const float* __restrict__ stats, long long M,
-                                int rows_per_group, int G, float eps, int silu) {
+                                const half_t* __restrict__ beta, const float* __restrict__ mr, long long M,
+                                int rows_per_group, int G, int silu) {
     const int C = C0 + C1, V = C >> 3, cpg = C / G;
-    const float inv_cnt = 1.0f / ((float)rows_per_group * (float)cpg);
     const long long total = M * V;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -94,11 +134,8 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ X0, const half_t* __r
             const int ge = (c0 + e) / cpg;
             if (ge != g) {
                 g = ge;
-                const float s = stats[((size_t)sg * G + g) * 2 + 0];
-                const float q = stats[((size_t)sg * G + g) * 2 + 1];
-                mean = s * inv_cnt;
-                const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
-                rstd = rsqrtf(var + eps);
+                mean = mr[((size_t)sg * G + g) * 2 + 0];
+                rstd = mr[((size_t)sg * G + g) * 2 + 1];
             }
             float f = ((float)x[e] - mean) * rstd * (float)ga[e] + (float)be[e];
             if (silu) f = av_silu(f);
@@ -106,6 +143,11 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ X0, const half_t* __r
         }
         *(h8*)(Y + row * C + c0) = y;
     }
+}
+
+extern "C" int64_t anyv2v_groupnorm_scratch_floats(int32_t M, int32_t rows_per_group, int32_t G) {
+    const int64_t nsg = rows_per_group > 0 ? M / rows_per_group : 0;
+    return nsg * G * 2 * (int64_t)(1 + GN_MAX_CHUNKS);
 }
 
 extern "C" int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y,
@@ -123,30 +165,32 @@ extern "C" int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, 
     const int nsg = M / rows_per_group;
     const int V = C / 8;
     AV_CHECK(V <= 1024, "groupnorm: C too large (%d)", C);
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)nsg * G * 2 * sizeof(float), s);
-    if (e != hipSuccess) {
-        anyv2v_set_error("groupnorm memset: %s", hipGetErrorString(e));
-        return (int)e;
-    }
     int rpb = 256 / V;
     if (rpb < 1) rpb = 1;
     int threads = V * rpb;
     if (threads < 64) threads = 64;
-    int nchunks = (2048 + nsg - 1) / nsg;
-    int max_chunks = (rows_per_group + rpb * 4 - 1) / (rpb * 4);  // >= 4 row-iterations per thread
+    if (threads < G) threads = G;
+    int nchunks = (1536 + nsg - 1) / nsg;
+    int max_chunks = (rows_per_group + rpb * 8 - 1) / (rpb * 8);  // >= 8 row-iterations per thread
     if (max_chunks < 1) max_chunks = 1;
     if (nchunks > max_chunks) nchunks = max_chunks;
-    if (nchunks > 65535) nchunks = 65535;
+    if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
     const int rows_chunk = (rows_per_group + nchunks - 1) / nchunks;
     nchunks = (rows_per_group + rows_chunk - 1) / rows_chunk;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsg, nchunks), dim3(threads), 0, s, (const half_t*)X0, (const half_t*)X1,
-                       C0, C1, stats, rows_per_group, G, rows_chunk, rpb);
+    float* mr = stats;                              // [nsg][G][2] (mean, rstd)
+    float* partial = stats + (size_t)nsg * G * 2;   // [nsg][nchunks][G][2]
+    const size_t lds = (size_t)rpb * C * 2 * sizeof(float);
+    AV_CHECK(lds <= 64 * 1024, "groupnorm: LDS reduction buffer too large");
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nsg, nchunks), dim3(threads), lds, s, (const half_t*)X0,
+                       (const half_t*)X1, C0, C1, partial, rows_per_group, G, rows_chunk, rpb, nchunks);
+    const float inv_cnt = 1.0f / ((float)rows_per_group * (float)(C / G));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nsg), dim3(256), 0, s, (const float*)partial, mr, nchunks, G, inv_cnt, eps);
     const long long total = (long long)M * V;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const half_t*)X0, (const half_t*)X1,
-                       C0, C1, (half_t*)Y, (const half_t*)gamma, (const half_t*)beta, (const float*)stats,
-                       (long long)M, rows_per_group, G, eps, silu);
+                       C0, C1, (half_t*)Y, (const half_t*)gamma, (const half_t*)beta, (const float*)mr,
+                       (long long)M, rows_per_group, G, silu);
     return av_launch_status("groupnorm");
 }
 

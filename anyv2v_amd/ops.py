@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -14,7 +15,7 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 
 # global knobs (tests flip them to cross-check kernel variants)
 FORCE_NAIVE = False   # route GEMM / attention through the reference-grade kernels
-USE_GLDS = False      # LDS-DMA staging variant of the GEMM
+USE_GLDS = os.environ.get("ANYV2V_GLDS", "1") == "1"   # LDS-DMA (global_load_lds) staging variant of the GEMM
 
 
 def _stream() -> int:
@@ -79,6 +80,10 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     return out
 
 
+def gn_scratch_floats(M: int, rows_per_group: int, groups: int = 32) -> int:
+    return (M // rows_per_group) * groups * 2 * 257  # == anyv2v_groupnorm_scratch_floats (1 + 256 chunks)
+
+
 def groupnorm(x0: torch.Tensor, gamma, beta, stats: torch.Tensor, rows_per_group: int, *, x1=None, groups: int = 32,
               eps: float = 1e-5, silu: bool = False, out=None):
     lib = _lib.load()
@@ -93,8 +98,8 @@ def groupnorm(x0: torch.Tensor, gamma, beta, stats: torch.Tensor, rows_per_group
     if out is None:
         out = torch.empty((M, C0 + C1), dtype=torch.float16, device=x0.device)
     assert out.is_contiguous()
-    need = (M // rows_per_group) * groups * 2
-    assert stats.dtype == torch.float32 and stats.numel() >= need
+    need = gn_scratch_floats(M, rows_per_group, groups)
+    assert stats.dtype == torch.float32 and stats.numel() >= need, "GroupNorm scratch too small"
     _lib.check(lib.anyv2v_groupnorm_f16(_p(x0), _p(x1), C0, C1, _p(out), _p(gamma), _p(beta), _p(stats), M,
                                         rows_per_group, groups, eps, int(silu), _stream()), "anyv2v_groupnorm_f16")
     return out

@@ -652,7 +652,7 @@ class I2VGenXLUNet(nn.Module):
         ctx.B, ctx.F, ctx.H, ctx.W = B, F, H, W
         HW = H * W
         T = B * F * HW
-        ctx.stats = torch.empty(B * F * cfg.norm_num_groups * 2, dtype=torch.float32, device=dev)
+        ctx.stats = torch.empty(ops.gn_scratch_floats(B * F, 1, cfg.norm_num_groups), dtype=torch.float32, device=dev)
         ctx.t_buf = torch.zeros(B, dtype=torch.float32, device=dev)
         boc0, cd = cfg.block_out_channels[0], cfg.cross_attention_dim
         # fps embedding

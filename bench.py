@@ -95,12 +95,12 @@ def cpu_baseline():
     (1 clip x 8 frames x 256x256), extrapolated to the 50+50-step job: frames/s = 8 / (50 * (t1 + t3))."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import pnp_oracle
-    from oracle.unet_oracle import UNetConfig, build_oracle, random_state_dict
+    from oracle.unet_oracle import UNetConfig, build_random_oracle
     import gpu_checks as gc
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     cfg = UNetConfig.i2vgen_xl()
-    oracle = build_oracle(cfg, random_state_dict(cfg, 0), dtype=torch.float32)
+    oracle = build_random_oracle(cfg, 0)
     inp = gc.config1_inputs(cfg, 3, 8, 32)
     kw = lambda s: dict(fps=inp["fps"][s], image_latents=inp["image_latents"][s], image_embeddings=inp["image_embeddings"][s],
                         encoder_hidden_states=inp["encoder_hidden_states"][s])

@@ -66,8 +66,10 @@ int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream);
  * Statistics are taken over `rows_per_group` consecutive rows x (C/G) channels: rows_per_group = H*W
  * gives the 4-D per-frame GroupNorm (ResnetBlock2D.norm1/norm2 pnp_utils.py:48,104; Transformer2DModel.norm),
  * rows_per_group = F*H*W the 5-D per-clip one (TemporalConvLayer, TransformerTemporalModel.norm).
- * `stats` is caller-provided scratch of (M/rows_per_group)*G*2 floats.
+ * `stats` is caller-provided scratch of anyv2v_groupnorm_scratch_floats(M, rows_per_group, G) floats (mean/rstd
+ * plus per-chunk partial sums; the reduction uses no atomics, so results are bit-reproducible).
  */
+int64_t anyv2v_groupnorm_scratch_floats(int32_t M, int32_t rows_per_group, int32_t G);
 int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y, const void* gamma,
                          const void* beta, float* stats, int32_t M, int32_t rows_per_group, int32_t G, float eps,
                          int32_t silu, void* stream);

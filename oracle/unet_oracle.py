@@ -531,6 +531,27 @@ def build_oracle(cfg: UNetConfig, state_dict, dtype=torch.float32, device="cpu")
     return m.to(dtype).eval()
 
 
+def build_random_oracle(cfg: UNetConfig, seed: int = 0) -> I2VGenXLUNetOracle:
+    """fp32 oracle with in-place random init (same law as ``random_state_dict``; values differ).  Fast path for the
+    CPU-baseline timing in bench.py, where only the arithmetic volume matters."""
+    with torch.device("meta"):
+        m = I2VGenXLUNetOracle(cfg)
+    m = m.to_empty(device="cpu")
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(".bias"):
+                p.normal_(0.0, 0.02)
+            elif p.dim() == 1:
+                p.normal_(1.0, 0.05)
+            else:
+                fan_in = 1
+                for d in p.shape[1:]:
+                    fan_in *= d
+                p.normal_(0.0, 1.0 / math.sqrt(fan_in))
+    return m.eval()
+
+
 def param_count(cfg: UNetConfig) -> int:
     with torch.device("meta"):
         m = I2VGenXLUNetOracle(cfg)

@@ -20,6 +20,7 @@ if ROOT not in sys.path:
 from anyv2v_amd import ops  # noqa: E402
 
 DEV = "cuda"
+_GLDS_DEFAULT = ops.USE_GLDS
 
 
 def _rel(a: torch.Tensor, b: torch.Tensor):
@@ -99,6 +100,8 @@ def check_gemm(variants=("reg", "glds", "naive")):
     out = []
     cases = [  # (M, N, K)
         (300, 320, 320), (1000, 512, 512), (257, 64, 128), (128, 4, 320), (4096, 1280, 1280), (77, 640, 1024),
+        # M >= 8192 -> the 256-row 3-stage LDS-DMA kernel (glds variant); ragged M / N tails, 1 and 2 K-tiles
+        (8300, 320, 320), (20001, 640, 1280), (9000, 512, 64), (8192, 4, 128), (12345, 160, 192),
     ]
     for var in variants:
         ops.USE_GLDS = var == "glds"
@@ -121,18 +124,19 @@ def check_gemm(variants=("reg", "glds", "naive")):
         dst = torch.zeros(400, 640, dtype=torch.float16, device=DEV)
         ops.gemm(big[:, 320:640], w, out=dst[:, 320:], naive=naive)
         out.append(_res(f"gemm[{var}] strided views", dst[:, 320:], _gemm_ref(big[:, 320:640], w), 4e-3))
-        # GEGLU
-        M, dim, inner = 333, 128, 512
-        a = rnd(M, dim)
-        wfull, bfull = rnd(2 * inner, dim, scale=1 / math.sqrt(dim)), rnd(2 * inner, scale=0.1)
-        wh, wg = wfull[:inner].view(inner // 16, 16, dim), wfull[inner:].view(inner // 16, 16, dim)
-        wp = torch.stack([wh, wg], 1).reshape(2 * inner, dim).contiguous()
-        bp = torch.stack([bfull[:inner].view(-1, 16), bfull[inner:].view(-1, 16)], 1).reshape(-1).contiguous()
-        y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU, naive=naive)
-        proj = a.float() @ wfull.float().t() + bfull.float()
-        ref = proj[:, :inner] * F.gelu(proj[:, inner:])
-        out.append(_res(f"gemm[{var}] GEGLU", y, ref, 6e-3))
-    ops.USE_GLDS = False
+        # GEGLU (small M -> 128-row kernel, large M -> 256-row kernel)
+        for M in (333, 9001):
+            dim, inner = 128, 512
+            a = rnd(M, dim)
+            wfull, bfull = rnd(2 * inner, dim, scale=1 / math.sqrt(dim)), rnd(2 * inner, scale=0.1)
+            wh, wg = wfull[:inner].view(inner // 16, 16, dim), wfull[inner:].view(inner // 16, 16, dim)
+            wp = torch.stack([wh, wg], 1).reshape(2 * inner, dim).contiguous()
+            bp = torch.stack([bfull[:inner].view(-1, 16), bfull[inner:].view(-1, 16)], 1).reshape(-1).contiguous()
+            y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU, naive=naive)
+            proj = a.float() @ wfull.float().t() + bfull.float()
+            ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+            out.append(_res(f"gemm[{var}] GEGLU M{M}", y, ref, 6e-3))
+    ops.USE_GLDS = _GLDS_DEFAULT
     return out
 
 
@@ -187,18 +191,41 @@ def check_conv(variants=("reg", "glds", "naive")):
         ref = F.conv3d(x5, w3.float(), b3.float(), padding=(1, 0, 0)) + x5
         ref = ref.squeeze(-1).permute(0, 2, 3, 1).reshape(B * Fr * HW, C)
         out.append(_res(f"temporal conv[{var}] +res", y, ref, 4e-3))
+        # large M (>= 8192 rows) -> 256-row 3-stage kernel: conv s1 two-source + temb + res, upsample, temporal
+        n, ci, c1, co, H, W = 6, 64, 128, 160, 40, 36
+        x, x1 = rnd(n, ci, H, W), rnd(n, c1, H, W)
+        w2, b = rnd(co, ci + c1, 3, 3, scale=1 / math.sqrt(9 * (ci + c1))), rnd(co)
+        temb, res = rnd(3, co), rnd(n * H * W, co)
+        y = ops.gemm(_to_tokens(x), _pack_conv(w2), a1=_to_tokens(x1), bias=b, rowvec=temb, rowvec_div=2 * H * W,
+                     residual=res, mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0), naive=naive)
+        ref = F.conv2d(torch.cat([x, x1], 1).float(), w2.float(), b.float(), padding=1)
+        ref = _to_tokens(ref + temb.float().repeat_interleave(2, 0)[:, :, None, None]) + res.float()
+        out.append(_res(f"conv3x3[{var}] large-M two-source +bias+temb+res", y, ref, 4e-3))
+        xs = rnd(3, 64, 30, 30)
+        ws = rnd(320, 64, 3, 3, scale=1 / math.sqrt(9 * 64))
+        y = ops.gemm(_to_tokens(xs), _pack_conv(ws), mode=ops.MODE_CONV2D, conv=(30, 30, 60, 60, 1, 1), M=3 * 3600, naive=naive)
+        ref = _to_tokens(F.conv2d(F.interpolate(xs.float(), scale_factor=2.0, mode="nearest"), ws.float(), padding=1))
+        out.append(_res(f"conv3x3[{var}] large-M upsample x2", y, ref, 4e-3))
+        B, Fr, HW, C = 2, 8, 600, 128
+        xt = rnd(B * Fr * HW, C)
+        w3, b3 = rnd(C, C, 3, 1, 1, scale=1 / math.sqrt(3 * C)), rnd(C)
+        wp = w3[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, -1).contiguous()
+        y = ops.gemm(xt, wp, bias=b3, mode=ops.MODE_TEMPORAL, temporal=(Fr, HW), residual=xt, naive=naive)
+        x5 = xt.view(B, Fr, HW, C).permute(0, 3, 1, 2).unsqueeze(-1).float()
+        ref = (F.conv3d(x5, w3.float(), b3.float(), padding=(1, 0, 0)) + x5).squeeze(-1).permute(0, 2, 3, 1).reshape(B * Fr * HW, C)
+        out.append(_res(f"temporal conv[{var}] large-M +res", y, ref, 4e-3))
     # tiny-channel conv goes through the reference-grade kernel automatically
     x, w, b = rnd(2, 4, 8, 8), rnd(16, 4, 3, 3, scale=0.2), rnd(16)
     y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, act=ops.ACT_SILU, mode=ops.MODE_CONV2D, conv=(8, 8, 8, 8, 1, 0))
     out.append(_res("conv3x3 Cin=4 (naive path) + silu", y, _to_tokens(F.silu(F.conv2d(x.float(), w.float(), b.float(), padding=1))), 4e-3))
-    ops.USE_GLDS = False
+    ops.USE_GLDS = _GLDS_DEFAULT
     return out
 
 
 # ------------------------------------------------------------------------------------------------ norms
 def check_norms():
     out = []
-    stats = torch.zeros(4096, dtype=torch.float32, device=DEV)
+    stats = torch.zeros(ops.gn_scratch_floats(64, 1), dtype=torch.float32, device=DEV)
     for (n, c, hw, silu, eps) in [(6, 320, 100, True, 1e-5), (3, 64, 64, False, 1e-6), (4, 1280, 64, True, 1e-5)]:
         x = rnd(n * hw, c) + 0.5
         ga, be = rnd(c) + 1.0, rnd(c)
@@ -496,7 +523,7 @@ def check_loops_mini():
         if graphs:
             res_graph = res.clone()
         elif DEV != "cpu":
-            out.append(_res("pipeline graph replay == eager", res_graph.cpu(), res.cpu(), 1e-3))
+            out.append(_res("pipeline graph replay == eager", res_graph.cpu(), res.cpu(), 1e-3))  # no atomics anywhere: deterministic
     os.environ["ANYV2V_NO_GRAPH"] = "0"
     return out
 
