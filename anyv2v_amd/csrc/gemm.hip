@@ -196,24 +196,64 @@ __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char*
     }
 }
 
+// Incremental gather addressing: inside one (tap, source) run consecutive K-tiles only advance the channel offset
+// (+128 bytes); the row -> shifted-row math is redone only when the tap or the source changes (wave-uniform branch).
+template <int MODE>
+struct AGen {
+    const half_t* ap[4];
+    int astep[4];  // halves to advance per K-tile: 64, or 0 for rows that read the zero line
+    int ktc, tap;
+    __device__ __forceinline__ void recompute(const GemmK& p, const RowInfo (&ri)[4], int kc) {
+        const ASrc s = a_source(p, ktc, kc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sr = src_row<MODE>(p, ri[i], tap);
+            ap[i] = a_addr(p, s, sr);
+            astep[i] = sr < 0 ? 0 : 64;
+        }
+    }
+    __device__ __forceinline__ void start(const GemmK& p, const RowInfo (&ri)[4], int kc) {
+        ktc = 0;
+        tap = 0;
+        recompute(p, ri, kc);
+    }
+    __device__ __forceinline__ void next(const GemmK& p, const RowInfo (&ri)[4], int kc, int ntap) {
+        if (++ktc == ntap) {
+            ktc = 0;
+            ++tap;
+        }
+        if (ktc == 0 || ktc == p.nt0) {
+            recompute(p, ri, kc);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ap[i] += astep[i];
+        }
+    }
+};
+
+// half a K-tile (one 32-deep K-step) of MFMA work for a 64 x NF*16 wave tile
+template <int NF>
+__device__ __forceinline__ void mma_half(f4 (&acc)[4][NF], const char* as, const char* bs, int wr, int wc, int lane,
+                                         int ks) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    h8 af[4], bf[NF];
+    const int c = (ks * 4 + lq) ^ (l15 & 7);
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) af[mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) bf[nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][nf], 0, 0, 0);
+}
+
 // one K-tile (64) of MFMA work for a 64 x NF*16 wave tile
 template <int NF>
 __device__ __forceinline__ void mma_tile(f4 (&acc)[4][NF], const char* as, const char* bs, int wr, int wc, int lane) {
-    const int l15 = lane & 15, lq = lane >> 4;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        h8 af[4], bf[NF];
-        const int c = (ks * 4 + lq) ^ (l15 & 7);
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) af[mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bf[nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][nf], 0, 0, 0);
-    }
+    mma_half<NF>(acc, as, bs, wr, wc, lane, 0);
+    mma_half<NF>(acc, as, bs, wr, wc, lane, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -250,24 +290,26 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
     }
 
     h8 ra[4], rb[NB];
-    auto issue = [&](int kt_c, int tap, int kt, int buf) {
-        const ASrc s = a_source(p, kt_c, kc);
+    const int ntap = p.nt0 + p.nt1;
+    AGen<MODE> gen;
+    gen.start(p, ri, kc);
+    auto issue = [&](int buf) {  // loads the generator's current tile, then advances it
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const half_t* g = a_addr(p, s, src_row<MODE>(p, ri[i], tap));
             if constexpr (GLDS)
-                glds16(g, As0 + buf * A_BYTES + (i * 256 + w * 64) * 16);
+                glds16(gen.ap[i], As0 + buf * A_BYTES + (i * 256 + w * 64) * 16);
             else
-                ra[i] = *(const h8*)g;
+                ra[i] = *(const h8*)gen.ap[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const half_t* g = bptr[i] + (size_t)kt * 64;
             if constexpr (GLDS)
-                glds16(g, Bs0 + buf * B_BYTES + (i * 256 + w * 64) * 16);
+                glds16(bptr[i], Bs0 + buf * B_BYTES + (i * 256 + w * 64) * 16);
             else
-                rb[i] = *(const h8*)g;
+                rb[i] = *(const h8*)bptr[i];
+            bptr[i] += 64;
         }
+        gen.next(p, ri, kc, ntap);
     };
     auto commit = [&](int buf) {
 #pragma unroll
@@ -282,22 +324,15 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int ntap = p.nt0 + p.nt1;
     const int nk = p.taps * ntap;
-    int tap = 0, kt_c = 0;
-    issue(0, 0, 0, 0);
+    issue(0);
     if constexpr (!GLDS) commit(0);
     if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        int nkt_c = kt_c + 1, ntp = tap;
-        if (nkt_c == ntap) {
-            nkt_c = 0;
-            ++ntp;
-        }
         const bool has_next = kt + 1 < nk;
-        if (has_next) issue(nkt_c, ntp, kt + 1, cur ^ 1);
+        if (has_next) issue(cur ^ 1);
         mma_tile<NF>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
         if constexpr (!GLDS) {
             if (has_next) commit(cur ^ 1);
@@ -305,8 +340,6 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        kt_c = nkt_c;
-        tap = ntp;
     }
     epilogue<NF, GEGLU, BM, 256>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid);
 }
@@ -315,7 +348,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
 // Large-M variant (see file header).  All LDS lives in ONE __shared__ array and every operand goes through LDS-DMA
 // so that hipcc does not insert vmcnt(0) drains into the K loop (checked in the .s: the loop body holds exactly one
 // counted s_waitcnt vmcnt and one s_barrier).
-template <int NF, bool GEGLU, int MODE>
+template <int NF, bool GEGLU, int MODE, int SCHED>
 __global__ __launch_bounds__(512) void gemm_mfma3_kernel(const GemmK p) {
     constexpr int BM = 256, BN = NF * 32, STAGES = 3;
     constexpr int A_BYTES = BM * 64 * 2;
@@ -351,13 +384,22 @@ __global__ __launch_bounds__(512) void gemm_mfma3_kernel(const GemmK p) {
         blds[i] = A_BYTES + (chunk - lane) * 16;  // wave-uniform LDS-DMA base (lane-linear destination)
     }
 
-    auto issue = [&](int kt_c, int tap, int kt, int stage) {
+    int blds_s[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) blds_s[i] = __builtin_amdgcn_readfirstlane(blds[i]);
+    const int ntap = p.nt0 + p.nt1;
+    AGen<MODE> gen;
+    gen.start(p, ri, kc);
+    auto issue = [&](int stage) {  // LDS-DMA of the generator's current tile into `stage`, then advance
         char* st = smem + stage * STAGE_BYTES;
-        const ASrc s = a_source(p, kt_c, kc);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(a_addr(p, s, src_row<MODE>(p, ri[i], tap)), st + (i * 512 + w * 64) * 16);
+        for (int i = 0; i < 4; ++i) glds16(gen.ap[i], st + (i * 512 + w * 64) * 16);
 #pragma unroll
-        for (int i = 0; i < NBI; ++i) glds16(bptr[i] + (size_t)kt * 64, st + __builtin_amdgcn_readfirstlane(blds[i]));
+        for (int i = 0; i < NBI; ++i) {
+            glds16(bptr[i], st + blds_s[i]);
+            bptr[i] += 64;
+        }
+        gen.next(p, ri, kc, ntap);
     };
 
     f4 acc[4][NF];
@@ -368,21 +410,9 @@ __global__ __launch_bounds__(512) void gemm_mfma3_kernel(const GemmK p) {
 
     constexpr int LPT = 4 + NBI;  // LDS-DMA instructions per thread per K-tile
     static_assert(LPT == 6 || LPT == 7, "vmcnt immediates below assume 6 or 7 loads per tile");
-    const int ntap = p.nt0 + p.nt1;
     const int nk = p.taps * ntap;
-    int i_ktc = 0, i_tap = 0;  // (tile-in-tap, tap) of the next tile to issue
-    auto advance = [&]() {
-        if (++i_ktc == ntap) {
-            i_ktc = 0;
-            ++i_tap;
-        }
-    };
-    issue(i_ktc, i_tap, 0, 0);
-    advance();
-    if (nk > 1) {
-        issue(i_ktc, i_tap, 1, 1);
-        advance();
-    }
+    issue(0);
+    if (nk > 1) issue(1);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt was issued two iterations ago; only tile kt+1's LPT loads may still be in flight
@@ -395,13 +425,17 @@ __global__ __launch_bounds__(512) void gemm_mfma3_kernel(const GemmK p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // everyone's tile kt landed; everyone finished reading stage (kt-1)%3
-        if (kt + 2 < nk) {
-            int s2 = stage + 2;
-            if (s2 >= STAGES) s2 -= STAGES;
-            issue(i_ktc, i_tap, kt + 2, s2);
-            advance();
+        int s2 = stage + 2;
+        if (s2 >= STAGES) s2 -= STAGES;
+        const char* as = smem + stage * STAGE_BYTES;
+        if constexpr (SCHED == 0) {
+            if (kt + 2 < nk) issue(s2);
+            mma_tile<NF>(acc, as, as + A_BYTES, wr, wc, lane);
+        } else {  // issue the prefetch between the two K-steps: its address math / DMA issue sits behind 20 MFMAs
+            mma_half<NF>(acc, as, as + A_BYTES, wr, wc, lane, 0);
+            if (kt + 2 < nk) issue(s2);
+            mma_half<NF>(acc, as, as + A_BYTES, wr, wc, lane, 1);
         }
-        mma_tile<NF>(acc, smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wr, wc, lane);
         if (++stage == STAGES) stage = 0;
     }
     __syncthreads();
@@ -488,12 +522,20 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     k.tilesN = (d->N + nf * 32 - 1) / (nf * 32);
     if (glds && !(d->flags & 4) && d->M >= 8192) {  // large M: 256-row tile, 3-stage LDS-DMA ring
         const dim3 grid(((d->M + 255) / 256) * k.tilesN);
-        if (geglu)
-            hipLaunchKernelGGL((gemm_mfma3_kernel<4, true, MODE>), grid, dim3(512), 0, s, k);
-        else if (nf == 5)
-            hipLaunchKernelGGL((gemm_mfma3_kernel<5, false, MODE>), grid, dim3(512), 0, s, k);
+#define AV_LAUNCH3(SCHED_)                                                                             \
+    do {                                                                                               \
+        if (geglu)                                                                                     \
+            hipLaunchKernelGGL((gemm_mfma3_kernel<4, true, MODE, SCHED_>), grid, dim3(512), 0, s, k);  \
+        else if (nf == 5)                                                                              \
+            hipLaunchKernelGGL((gemm_mfma3_kernel<5, false, MODE, SCHED_>), grid, dim3(512), 0, s, k); \
+        else                                                                                           \
+            hipLaunchKernelGGL((gemm_mfma3_kernel<4, false, MODE, SCHED_>), grid, dim3(512), 0, s, k); \
+    } while (0)
+        if (d->flags & 8)
+            AV_LAUNCH3(1);
         else
-            hipLaunchKernelGGL((gemm_mfma3_kernel<4, false, MODE>), grid, dim3(512), 0, s, k);
+            AV_LAUNCH3(0);
+#undef AV_LAUNCH3
         return av_launch_status("gemm_mfma3");
     }
     const dim3 grid(((d->M + 127) / 128) * k.tilesN);

@@ -15,6 +15,7 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 
 # global knobs (tests flip them to cross-check kernel variants)
 FORCE_NAIVE = False   # route GEMM / attention through the reference-grade kernels
+GEMM_FLAGS = int(os.environ.get("ANYV2V_GEMM_FLAGS", "0"))  # bit2 (4): no 256-row kernel; bit3 (8): mid-tile prefetch issue
 USE_GLDS = os.environ.get("ANYV2V_GLDS", "1") == "1"   # LDS-DMA (global_load_lds) staging variant of the GEMM
 
 
@@ -75,7 +76,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     elif mode == MODE_TEMPORAL:
         d.F, d.HW = temporal
     d.act = act
-    d.flags = (1 if (naive or FORCE_NAIVE) else 0) | (2 if USE_GLDS else 0)
+    d.flags = (1 if (naive or FORCE_NAIVE) else 0) | (2 if USE_GLDS else 0) | GEMM_FLAGS
     _lib.check(lib.anyv2v_gemm_f16(C.byref(d), _stream()), "anyv2v_gemm_f16")
     return out
 

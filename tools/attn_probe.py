@@ -54,6 +54,8 @@ def gemm_case(tag, M, N, K, iters, mode=0, conv=None, flags_glds=True, act=0):
 
 N, h, S = 48, 5, 4096
 C = 64 * h
+if "--gemm-only" in sys.argv:
+    N = 1
 q_rand = torch.randn(N * S, 3 * C, device=dev).half()
 attn_case("randn, 1 iter at a time", N, h, S, q_rand, 1)
 attn_case("randn, 5 back-to-back", N, h, S, q_rand, 5)
@@ -67,16 +69,21 @@ attn_case("S=1024 h=10 randn 20", 48, 10, 1024, torch.randn(48 * 1024, 3 * 640, 
 
 T = 48 * 4096
 H = 64
-for glds in (True, False):
-    gemm_case("conv3x3 320->320 @64x64", T, 320, 320, 10, mode=1, conv=(H, H, H, H, 1, 0, T), flags_glds=glds)
-    gemm_case("linear 320->320", T, 320, 320, 20, flags_glds=glds)
-    gemm_case("linear 320->960 (qkv)", T, 960, 320, 20, flags_glds=glds)
-    gemm_case("linear 1280->320 (ff down)", T, 320, 1280, 10, flags_glds=glds)
-    gemm_case("geglu 320->2560", T, 2560, 320, 10, flags_glds=glds, act=3)
-    gemm_case("conv3x3 640->640 @32x32", T // 4, 640, 640, 10, mode=1, conv=(32, 32, 32, 32, 1, 0, T // 4), flags_glds=glds)
-    gemm_case("conv3x3 1280->1280 @16x16", T // 16, 1280, 1280, 10, mode=1, conv=(16, 16, 16, 16, 1, 0, T // 16), flags_glds=glds)
-    gemm_case("conv3x3 1280->1280 @8x8", T // 64, 1280, 1280, 10, mode=1, conv=(8, 8, 8, 8, 1, 0, T // 64), flags_glds=glds)
-    gemm_case("linear 1280->1280 @16x16", T // 16, 1280, 1280, 20, flags_glds=glds)
+if "--gemm-only" in sys.argv:
+    lines.clear()
+for glds, flags in ((True, 0), (True, 8), (True, 4), (False, 0)):
+    ops.GEMM_FLAGS = flags
+    tag = f"[glds={int(glds)} flags={flags}] "
+    gemm_case(tag + "conv3x3 320->320 @64x64", T, 320, 320, 10, mode=1, conv=(H, H, H, H, 1, 0, T), flags_glds=glds)
+    gemm_case(tag + "linear 320->320", T, 320, 320, 20, flags_glds=glds)
+    gemm_case(tag + "linear 320->960 (qkv)", T, 960, 320, 20, flags_glds=glds)
+    gemm_case(tag + "linear 1280->320 (ff down)", T, 320, 1280, 10, flags_glds=glds)
+    gemm_case(tag + "geglu 320->2560", T, 2560, 320, 10, flags_glds=glds, act=3)
+    gemm_case(tag + "conv3x3 640->640 @32x32", T // 4, 640, 640, 10, mode=1, conv=(32, 32, 32, 32, 1, 0, T // 4), flags_glds=glds)
+    gemm_case(tag + "conv3x3 1280->1280 @16x16", T // 16, 1280, 1280, 10, mode=1, conv=(16, 16, 16, 16, 1, 0, T // 16), flags_glds=glds)
+    gemm_case(tag + "conv3x3 1280->1280 @8x8", T // 64, 1280, 1280, 10, mode=1, conv=(8, 8, 8, 8, 1, 0, T // 64), flags_glds=glds)
+    gemm_case(tag + "linear 1280->1280 @16x16", T // 16, 1280, 1280, 20, flags_glds=glds)
+ops.GEMM_FLAGS = 0
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", "attn_probe.txt"), "w").write("\n".join(lines) + "\n")
