@@ -202,6 +202,197 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(const AttnK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// v2: same math / fragment layouts as flash_attn_d64_kernel, but K and V tiles are fetched by LDS-DMA
+// (global_load_lds, 16 B per lane) into a 4-stage LDS ring three tiles ahead, with counted s_waitcnt vmcnt and ONE
+// raw s_barrier per tile -- the v1 kernel's single register-prefetched tile exposed the global latency on every tile
+// (~5000 cycles per 64-key tile for 512 cycles of MFMA).  Both tiles stay ROW-MAJOR in LDS ([64 key][64 d], 16-byte
+// chunks XOR-swizzled on the DMA *source* side): K fragments are ds_read_b128 as before (swizzle (key>>1)&7), and
+// the V^T fragments of O^T = V^T P^T come from ds_read_b64_tr_b16 (hardware 4x16 transpose, swizzle key&7) -- no
+// register transposition, no LDS stores at all in the main loop.
+typedef __fp16 fp16x4v_t __attribute__((__vector_size__(8)));
+
+__device__ __forceinline__ void glds16_attn(const half_t* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __attribute__((aligned(256))) half_t g_attn_zero_line[128];
+
+template <int STAGES>
+__global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
+    constexpr int TILE_BYTES = 8192, STAGE_BYTES = 2 * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int qt = bid % p.q_tiles;
+    const int bh = bid / p.q_tiles;
+    const int h = bh % p.heads;
+    const int i = bh / p.heads;
+
+    const int iq = p.qk_mod > 0 ? i % p.qk_mod : i;
+    const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
+    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
+    const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+
+    const int q0 = qt * 128 + w * 32;
+    const bool wave_active = q0 < p.Sq;
+    const int qrow = q0 + l31;
+    h8 qf[4];
+    {
+        const int qr = qrow < p.Sq ? qrow : p.Sq - 1;
+        const half_t* qp = p.Q + (qbase + (long long)qr * p.q_seq) * p.ldq + h * 64 + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h8*)(qp + 16 * ks);
+    }
+
+    // DMA assignment: instruction t (0,1), chunk slot = t*256 + tid -> row = slot >> 3, physical chunk = tid & 7
+    const int drow = tid >> 3, dpc = tid & 7;
+    const half_t* kp[2];
+    const half_t* vp[2];
+    const int ntiles = (p.Sk + 63) / 64;
+    auto set_src = [&](int key0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = drow + 32 * t;
+            const int key = key0 + row;
+            const bool ok = key < p.Sk;
+            const half_t* ks_ = p.K + (kbase + (long long)key * p.kv_seq) * p.ldk + h * 64 + ((dpc ^ ((row >> 1) & 7)) << 3);
+            const half_t* vs_ = p.V + (vbase + (long long)key * p.kv_seq) * p.ldv + h * 64 + ((dpc ^ (row & 7)) << 3);
+            kp[t] = ok ? ks_ : zeros;
+            vp[t] = ok ? vs_ : zeros;
+        }
+    };
+    auto issue = [&](int tile, int stage) {
+        set_src(tile * 64);
+        char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            glds16_attn(kp[t], st + (t * 256 + w * 64) * 16);
+            glds16_attn(vp[t], st + TILE_BYTES + (t * 256 + w * 64) * 16);
+        }
+    };
+
+    f16v oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float c = p.scale_log2;
+
+    // V^T fragment addressing (ds_read_b64_tr_b16): lane i16 of a 16-lane group supplies &V[kb + (i16>>2)][dcol + 4(i16&3)]
+    const int i16 = lane & 15;
+    const int vrow = 4 * hi + (i16 >> 2);                          // + 16 t (+8 for the second read)
+    const int vfl = vrow & 7;                                      // row swizzle (key & 7), constant per lane
+    const int vc0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);      // 16-byte chunk within the 32-d half
+    int voff[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) voff[db] = vrow * 128 + (((4 * db + vc0) ^ vfl) << 4) + (i16 & 1) * 8;
+
+    for (int t = 0; t < PRE && t < ntiles; ++t) issue(t, t);
+    int stage = 0;
+    for (int j = 0; j < ntiles; ++j) {
+        const int ahead = ntiles - 1 - j;  // tiles issued after tile j that may still be in flight (<= PRE - 1)
+        if (PRE >= 3 && ahead >= 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead >= 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + PRE < ntiles) issue(j + PRE, (stage + PRE) % STAGES);
+        if (wave_active) {
+            const char* Ks = smem + stage * STAGE_BYTES;
+            const char* Vs = Ks + TILE_BYTES;
+            f16v sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                const int key = 32 * kb + l31;
+                const char* krow = Ks + key * 128;
+                const int fk = (key >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const h8 kf = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                }
+            }
+            if (j == ntiles - 1 && (p.Sk & 63) != 0) {  // key tail: only the last tile can hold masked keys
+                const int key_base = j * 64 + 4 * hi;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) sacc[kb][r] = -1e30f;
+            }
+            float mx = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f((m_run - m_new) * c);
+            const float mc = m_new * c;
+            m_run = m_new;
+            float psum = 0.f;
+            h8 pf[4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = exp2f(fmaf(sacc[kb][r], c, -mc));
+                    psum += pv;
+                    pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                oacc[0][r] *= alpha;
+                oacc[1][r] *= alpha;
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const char* a0 = Vs + voff[db] + t * 2048;
+                    const fp16x4v_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v_t*)a0);
+                    const fp16x4v_t r1 =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v_t*)(a0 + 1024));
+                    h8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vf[e] = (half_t)r0[e];
+                        vf[4 + e] = (half_t)r1[e];
+                    }
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t], oacc[db], 0, 0, 0);
+                }
+            }
+        }
+        if (++stage == STAGES) stage = 0;
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (wave_active && qrow < p.Sq) {
+        const float inv = 1.0f / l_tot;
+        half_t* op = p.O + (obase + (long long)qrow * p.q_seq) * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[db][4 * g + e] * inv);
+                *(h4*)(op + 32 * db + 8 * g) = o;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Short-sequence attention (S <= 16, head_dim 64): the temporal self-attention of TransformerTemporalModel at the
 // benchmark's 16 frames (pnp_utils.py:247-334).  HBM-bound (4 x 2 KiB per (clip, pixel, head)); one WAVE owns one
 // (batch element, head):
@@ -377,8 +568,21 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     }
     const long long nwg = (long long)k.batch * k.heads * k.q_tiles;
     AV_CHECK(nwg < (1ll << 31), "attention: grid too large");
-    hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nwg), dim3(256), 0, s, k);
-    return av_launch_status("flash_attn_d64");
+    if (d->flags & 4) {  // v1: register-staged single-tile prefetch (kept for A/B and as a cross-check)
+        hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nwg), dim3(256), 0, s, k);
+        return av_launch_status("flash_attn_d64");
+    }
+    static const half_t* zeros = nullptr;
+    if (zeros == nullptr) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_attn_zero_line)) == hipSuccess) zeros = (const half_t*)ptr;
+    }
+    AV_CHECK(zeros != nullptr, "attention: zero line symbol unavailable");
+    if (d->flags & 8)
+        hipLaunchKernelGGL(flash_attn_d64_v2_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    else
+        hipLaunchKernelGGL(flash_attn_d64_v2_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    return av_launch_status("flash_attn_d64_v2");
 }
 
 extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream) {

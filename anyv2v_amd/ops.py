@@ -15,7 +15,8 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 
 # global knobs (tests flip them to cross-check kernel variants)
 FORCE_NAIVE = False   # route GEMM / attention through the reference-grade kernels
-GEMM_FLAGS = int(os.environ.get("ANYV2V_GEMM_FLAGS", "0"))  # bit2 (4): no 256-row kernel; bit3 (8): mid-tile prefetch issue
+ATTN_FLAGS = int(os.environ.get("ANYV2V_ATTN_FLAGS", "0"))  # bit1 (2): no short kernel; bit2 (4): v1 flash; bit3 (8): 4 stages
+GEMM_FLAGS = int(os.environ.get("ANYV2V_GEMM_FLAGS", "4"))  # bit2 (4): no 256-row kernel; bit3 (8): mid-tile prefetch issue
 USE_GLDS = os.environ.get("ANYV2V_GLDS", "1") == "1"   # LDS-DMA (global_load_lds) staging variant of the GEMM
 
 
@@ -130,7 +131,7 @@ def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_stri
     d.q_outer, d.q_inner, d.q_seq = q_strides
     d.kv_outer, d.kv_inner, d.kv_seq = kv_strides
     d.kv_div, d.qk_mod, d.scale = kv_div, qk_mod, scale
-    d.flags = 1 if (naive or FORCE_NAIVE) else 0
+    d.flags = (1 if (naive or FORCE_NAIVE) else 0) | ATTN_FLAGS
     if head_dim == 64:
         _lib.check(lib.anyv2v_attention_f16(C.byref(d), _stream()), "anyv2v_attention_f16")
     else:
