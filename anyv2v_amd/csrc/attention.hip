@@ -218,6 +218,26 @@ __device__ __forceinline__ void glds16_attn(const half_t* g, char* lds_wave_base
 
 __device__ __attribute__((aligned(256))) half_t g_attn_zero_line[128];
 
+// ds_read_b64_tr_b16 through inline asm: with the builtin hipcc treats the read as possibly aliasing the LDS-DMA
+// writes still in flight and drains them with s_waitcnt vmcnt(0) every tile (seen in the .s), which defeats the
+// prefetch ring.  An asm load is invisible to the compiler's waitcnt bookkeeping, so every consumer below sits
+// behind an explicit s_waitcnt lgkmcnt(N) + sched_barrier (MI355X guide 5.7, form iii).
+template <int OFF>
+__device__ __forceinline__ fp16x4v_t lds_tr16(unsigned lds_addr) {
+    fp16x4v_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(OFF));
+    return r;
+}
+__device__ __forceinline__ h8 join8(fp16x4v_t a, fp16x4v_t b) {
+    h8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = (half_t)a[e];
+        v[4 + e] = (half_t)b[e];
+    }
+    return v;
+}
+
 template <int STAGES>
 __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
     constexpr int TILE_BYTES = 8192, STAGE_BYTES = 2 * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
@@ -329,6 +349,14 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                     for (int r = 0; r < 16; ++r)
                         if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) sacc[kb][r] = -1e30f;
             }
+            // V^T fragments of the first d-half: issued now, they land while the softmax runs on the VALU
+            const unsigned vs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Vs;
+            const unsigned va0 = vs_lds + voff[0], va1 = vs_lds + voff[1];
+            fp16x4v_t v0[8], v1[8];
+            v0[0] = lds_tr16<0>(va0);     v0[1] = lds_tr16<1024>(va0);
+            v0[2] = lds_tr16<2048>(va0);  v0[3] = lds_tr16<3072>(va0);
+            v0[4] = lds_tr16<4096>(va0);  v0[5] = lds_tr16<5120>(va0);
+            v0[6] = lds_tr16<6144>(va0);  v0[7] = lds_tr16<7168>(va0);
             float mx = -1e30f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -336,7 +364,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f((m_run - m_new) * c);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);  // raw v_exp_f32: args <= 0, flush-to-zero is fine
             const float mc = m_new * c;
             m_run = m_new;
             float psum = 0.f;
@@ -345,7 +373,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = exp2f(fmaf(sacc[kb][r], c, -mc));
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mc));
                     psum += pv;
                     pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
                 }
@@ -355,23 +383,21 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                 oacc[0][r] *= alpha;
                 oacc[1][r] *= alpha;
             }
+            // second d-half: issue, then wait for the first half only (8 newer reads may stay in flight)
+            v1[0] = lds_tr16<0>(va1);     v1[1] = lds_tr16<1024>(va1);
+            v1[2] = lds_tr16<2048>(va1);  v1[3] = lds_tr16<3072>(va1);
+            v1[4] = lds_tr16<4096>(va1);  v1[5] = lds_tr16<5120>(va1);
+            v1[6] = lds_tr16<6144>(va1);  v1[7] = lds_tr16<7168>(va1);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
+            for (int t = 0; t < 4; ++t)
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(v0[2 * t], v0[2 * t + 1]), pf[t], oacc[0], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const char* a0 = Vs + voff[db] + t * 2048;
-                    const fp16x4v_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v_t*)a0);
-                    const fp16x4v_t r1 =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v_t*)(a0 + 1024));
-                    h8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        vf[e] = (half_t)r0[e];
-                        vf[4 + e] = (half_t)r1[e];
-                    }
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t], oacc[db], 0, 0, 0);
-                }
-            }
+            for (int t = 0; t < 4; ++t)
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(v1[2 * t], v1[2 * t + 1]), pf[t], oacc[1], 0, 0, 0);
         }
         if (++stage == STAGES) stage = 0;
     }
