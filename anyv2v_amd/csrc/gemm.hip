@@ -249,11 +249,40 @@ __device__ __forceinline__ void mma_half(f4 (&acc)[4][NF], const char* as, const
             acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][nf], 0, 0, 0);
 }
 
-// one K-tile (64) of MFMA work for a 64 x NF*16 wave tile
+// one K-tile (64) of MFMA work for a 64 x NF*16 wave tile: all 2*(4+NF) fragment reads are issued first, so the
+// compiler can retire them with counted lgkmcnt waits while the MFMAs of the first K-step already run (loading per
+// K-step made it emit a full lgkmcnt(0) in front of every MFMA batch).
 template <int NF>
 __device__ __forceinline__ void mma_tile(f4 (&acc)[4][NF], const char* as, const char* bs, int wr, int wc, int lane) {
-    mma_half<NF>(acc, as, bs, wr, wc, lane, 0);
-    mma_half<NF>(acc, as, bs, wr, wc, lane, 1);
+    const int l15 = lane & 15, lq = lane >> 4;
+    h8 af[2][4], bf[2][NF];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = (ks * 4 + lq) ^ (l15 & 7);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bf[ks][nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) af[ks][mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], acc[mf][nf], 0, 0, 0);
+    // scheduling contract for this region: all fragment reads first, then the MFMAs (hipcc otherwise sinks each read
+    // next to its consumer and drains with lgkmcnt(0) four to six times per tile)
+    // K-step 0 fragments, then K-step 0 MFMAs with the K-step 1 reads slotted in (1 read per 2 MFMAs), then the rest
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);
+#pragma unroll
+    for (int i = 0; i < 4 + NF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NF - 2 * (4 + NF), 0);
+    // keep the MFMAs above the caller's end-of-tile s_waitcnt (an asm "memory" clobber does not order register-only MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
