@@ -120,6 +120,16 @@ def cpu_baseline():
             "seconds_B1": round(t1, 3), "seconds_B3": round(t3, 3)}
 
 
+def finish_distributed(dist, dt, latents, world, device):
+    """The one collective of the sharded job -- all_gather of every rank's edited latents (512 KiB per rank at
+    16f x 512^2; RCCL over xGMI on the GPU node, gloo in the CPU test) -- plus MAX over ranks of the timed region."""
+    out = [torch.empty_like(latents) for _ in range(world)]
+    dist.all_gather(out, latents)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,12 +210,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        # the one collective of the sharded job: all-gather of the edited latents (512 KiB per rank) over RCCL/xGMI
-        out = [torch.empty_like(s_pnp[2:3]) for _ in range(world)]
-        dist.all_gather(out, s_pnp[2:3].contiguous())
-        tmax = torch.tensor([dt], device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, _gathered = finish_distributed(dist, dt, s_pnp[2:3].contiguous(), world, device)
     finite = bool(torch.isfinite(s_pnp.float()).all() and torch.isfinite(s_inv.float()).all())
 
     if rank == 0:

@@ -160,3 +160,25 @@ def test_all_gather_of_edited_latents_world2_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert a == b == [0.0 + 2 + 4, 1.0 + 3]  # rank0 got entries 0,2,4; rank1 got 1,3
+
+
+def _bench_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo")
+    lat = torch.full((1, 4, 2, 3, 3), float(rank + 1), dtype=torch.float16)
+    dt, got = bench.finish_distributed(dist, 1.0 + rank, lat, world, "cpu")
+    torch.save((dt, [float(g.mean()) for g in got]), os.path.join(out_dir, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_distributed_epilogue_world2_gloo(tmp_path):
+    """bench.py's N>1 path: MAX-over-ranks timing + the one all_gather (RCCL on the node, gloo here)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        dt, means = torch.load(tmp_path / f"b{r}.pt")
+        assert dt == 2.0 and means == [1.0, 2.0]

@@ -1,0 +1,55 @@
+"""Summarise a rocprofv3 kernel trace (CSV) into the tables committed under profiles/.
+
+    python tools/summarize_profile.py <dir-with-*_kernel_trace.csv> [--steps N] > profiles/rNN_<name>.md
+
+Two tables: time per kernel name, and time per (kernel, grid) -- the latter separates e.g. the graded spatial
+self-attention launches (7680 workgroups, S=4096) from cross-attention launches of the same kernel.
+"""
+import collections
+import csv
+import glob
+import sys
+
+
+def short(name: str) -> str:
+    name = name.replace("void ", "")
+    for pat in ("(GemmK)", "(AttnK)", "(AttnK, _Float16 const*)"):
+        name = name.replace(pat, "")
+    if name.startswith("_Z"):
+        import re
+        m = re.match(r"_Z\d+([A-Za-z0-9_]+?)(?:ILi|PK|P|i|x|f)", name)
+        if m:
+            name = m.group(1)
+    return name[:72]
+
+
+def main():
+    d = sys.argv[1]
+    steps = None
+    if "--steps" in sys.argv:
+        steps = float(sys.argv[sys.argv.index("--steps") + 1])
+    files = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
+    assert files, "no *_kernel_trace.csv under " + d
+    by_name = collections.defaultdict(lambda: [0, 0.0])
+    by_grid = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            n = short(r["Kernel_Name"])
+            by_name[n][0] += 1
+            by_name[n][1] += us
+            wg = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) // max(1, int(r["Workgroup_Size_X"]))
+            by_grid[(n, wg)].append(us)
+    total = sum(v[1] for v in by_name.values())
+    print(f"total kernel time {total / 1e3:.2f} ms over {sum(v[0] for v in by_name.values())} launches" +
+          (f" ({total / 1e3 / steps:.2f} ms per bench step incl. warm-up/capture launches)" if steps else ""))
+    print("\n| kernel | launches | total ms | % | avg us |\n|---|---:|---:|---:|---:|")
+    for n, (c, us) in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:24]:
+        print(f"| `{n}` | {c} | {us / 1e3:.2f} | {100 * us / total:.1f} | {us / c:.1f} |")
+    print("\n| kernel | workgroups | launches | avg us | min us | max us | total ms |\n|---|---:|---:|---:|---:|---:|---:|")
+    for (n, wg), v in sorted(by_grid.items(), key=lambda kv: -sum(kv[1]))[:40]:
+        print(f"| `{n}` | {wg} | {len(v)} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {sum(v) / 1e3:.2f} |")
+
+
+if __name__ == "__main__":
+    main()
