@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
         ("stride", C.c_int32), ("up", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32),
         ("act", C.c_int32), ("flags", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -34,6 +34,8 @@ struct GemmK {
     int mode, Hi, Wi, Ho, Wo, stride, up, F, HW, act;
     int taps, Ktot, nt0, nt1, tilesN;
     int vec_epi;  // bias / rowvec may be read as 8-byte vectors
+    int splits;   // split-K factor (128-row kernel only): each split writes an fp32 partial tile, reduced afterwards
+    float* partial;  // [splits][M][N] fp32 workspace
 };
 
 struct RowInfo {
@@ -110,12 +112,25 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 // (+residual) -> coalesced 16-byte stores.  Caller guarantees all waves are done with the pipeline LDS.
 template <int NF, bool GEGLU, int BM, int NTHREADS>
 __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char* smem, int m_blk, int n_blk, int wr,
-                                         int wc, int lane, int tid) {
+                                         int wc, int lane, int tid, int split = 0) {
     constexpr int BN = NF * 32;
     constexpr int BNO = GEGLU ? BN / 2 : BN;
     constexpr int CS_LD = BNO + 8;
     half_t* const Cs = (half_t*)smem;
     const int l15 = lane & 15, lq = lane >> 4;
+    if (p.splits > 1) {  // split-K: raw fp32 partial tile; bias / temb / activation / residual happen in the reduce kernel
+        float* dst = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int m = m_blk + wr * 64 + mf * 16 + l15;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int n = n_blk + wc * NF * 16 + nf * 16 + 4 * lq;
+                if (m < p.M && n + 4 <= p.N) *(f4*)(dst + (size_t)m * p.N + n) = acc[mf][nf];
+            }
+        }
+        return;
+    }
     const int Nout = GEGLU ? p.N / 2 : p.N;
     const int n_out_blk = GEGLU ? n_blk / 2 : n_blk;
     // All epilogue operands are fetched with unconditional 8-byte loads (absent / out-of-range -> the zero line),
@@ -212,9 +227,9 @@ struct AGen {
             astep[i] = sr < 0 ? 0 : 64;
         }
     }
-    __device__ __forceinline__ void start(const GemmK& p, const RowInfo (&ri)[4], int kc) {
-        ktc = 0;
-        tap = 0;
+    __device__ __forceinline__ void start(const GemmK& p, const RowInfo (&ri)[4], int kc, int kt0 = 0, int ntap = 1) {
+        tap = kt0 / ntap;
+        ktc = kt0 - tap * ntap;
         recompute(p, ri, kc);
     }
     __device__ __forceinline__ void next(const GemmK& p, const RowInfo (&ri)[4], int kc, int ntap) {
@@ -300,6 +315,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
     int bid = blockIdx.x;
     const int nwg = gridDim.x;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);  // XCD-contiguous tile order (bijective)
+    const int ntiles = nwg / p.splits;
+    const int split = bid / ntiles;  // split-K: this block covers K-tiles [kt_begin, kt_end) of its output tile
+    bid -= split * ntiles;
     const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
     const int m_blk = mt * BM, n_blk = nt * BN;
 
@@ -320,8 +338,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
 
     h8 ra[4], rb[NB];
     const int ntap = p.nt0 + p.nt1;
+    const int nk_all = p.taps * ntap;
+    const int kt_begin = (int)(((long long)nk_all * split) / p.splits);
+    const int kt_end = (int)(((long long)nk_all * (split + 1)) / p.splits);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bptr[i] += (size_t)kt_begin * 64;
     AGen<MODE> gen;
-    gen.start(p, ri, kc);
+    gen.start(p, ri, kc, kt_begin, ntap);
     auto issue = [&](int buf) {  // loads the generator's current tile, then advances it
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.taps * ntap;
+    const int nk = kt_end - kt_begin;
     issue(0);
     if constexpr (!GLDS) commit(0);
     if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
         }
         __syncthreads();
     }
-    epilogue<NF, GEGLU, BM, 256>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid);
+    epilogue<NF, GEGLU, BM, 256>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid, split);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -527,6 +550,46 @@ __global__ void gemm_naive_kernel(const GemmK p) {
     p.C[(size_t)m * p.ldc + j] = (half_t)v;
 }
 
+// split-K second pass: sum the fp32 partial tiles in a fixed order (deterministic), then the usual epilogue
+__global__ void gemm_splitk_reduce_kernel(const GemmK p) {
+    const int N8 = p.N >> 3;
+    const long long total = (long long)p.M * N8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / N8), n0 = (int)(idx - (long long)m * N8) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int s = 0; s < p.splits; ++s) {
+            const float* src = p.partial + ((size_t)s * p.M + m) * p.N + n0;
+            const f4 a = *(const f4*)src, b = *(const f4*)(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += a[e];
+                v[4 + e] += b[e];
+            }
+        }
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (p.bias != nullptr) x += (float)p.bias[n0 + e];
+            if (p.rowvec != nullptr) x += (float)p.rowvec[(size_t)(m / p.rowvec_div) * p.ldrv + n0 + e];
+            if (p.act == ACT_SILU)
+                x = av_silu(x);
+            else if (p.act == ACT_GELU)
+                x = av_gelu(x);
+            o[e] = (half_t)x;
+        }
+        if (p.R != nullptr) {
+            const h8 rr = *(const h8*)(p.R + (size_t)m * p.ldr + n0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+        }
+        *(h8*)(p.C + (size_t)m * p.ldc + n0) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 static const half_t* zero_line() {
     static const half_t* z = nullptr;
@@ -567,7 +630,20 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
 #undef AV_LAUNCH3
         return av_launch_status("gemm_mfma3");
     }
-    const dim3 grid(((d->M + 127) / 128) * k.tilesN);
+    const int tiles = ((d->M + 127) / 128) * k.tilesN;
+    // split-K for launches that cannot fill the chip (512 block slots) and have a long K loop (the 8x8 / 16x16-level
+    // convs: 64..256 tiles x 180..360 K-tiles); needs the caller's fp32 workspace
+    const int nk = k.taps * (k.nt0 + k.nt1);
+    if (glds && !geglu && !(d->flags & 16) && d->workspace != nullptr && tiles < 384 && nk >= 16 && d->N % 8 == 0) {
+        int splits = (512 + tiles - 1) / tiles;
+        if (splits > 8) splits = 8;
+        if (splits > nk / 8) splits = nk / 8;
+        if (splits >= 2 && (size_t)splits * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes) {
+            k.splits = splits;
+            k.partial = (float*)d->workspace;
+        }
+    }
+    const dim3 grid(tiles * k.splits);
 #define AV_LAUNCH2(NF_, GEGLU_)                                                                          \
     do {                                                                                                 \
         if (glds)                                                                                        \
@@ -582,6 +658,12 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     else
         AV_LAUNCH2(4, false);
 #undef AV_LAUNCH2
+    if (k.splits > 1) {
+        const long long total = (long long)d->M * (d->N / 8);
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k);
+    }
     return av_launch_status("gemm_mfma");
 }
 
@@ -626,6 +708,8 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     k.nt0 = d->C0 / 64;
     k.nt1 = d->C1 / 64;
     k.tilesN = 1;
+    k.splits = 1;
+    k.partial = nullptr;
     k.vec_epi = (((uintptr_t)d->bias & 7) == 0) && (((uintptr_t)d->rowvec & 7) == 0) && (d->ldrv % 4 == 0) && (d->N % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
 

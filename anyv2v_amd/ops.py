@@ -34,6 +34,18 @@ def _rowmajor(t: torch.Tensor, name: str):
     assert t.is_cuda, f"{name}: device tensor expected"
 
 
+_WS = {}
+
+
+def _workspace(device) -> torch.Tensor:
+    """Persistent fp32 scratch for split-K partial tiles (64 MiB per device; allocated once, outside any graph capture
+    because the first GEMM of a process always runs eagerly during warm-up)."""
+    key = str(device)
+    if key not in _WS:
+        _WS[key] = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)
+    return _WS[key]
+
+
 def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowvec=None,
          rowvec_div: int = 0, residual=None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
          mode: int = MODE_LINEAR, conv=None, temporal=None, M: Optional[int] = None, naive: bool = False):
@@ -78,6 +90,8 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         d.F, d.HW = temporal
     d.act = act
     d.flags = (1 if (naive or FORCE_NAIVE) else 0) | (2 if USE_GLDS else 0) | GEMM_FLAGS
+    ws = _workspace(a0.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _lib.check(lib.anyv2v_gemm_f16(C.byref(d), _stream()), "anyv2v_gemm_f16")
     return out
 

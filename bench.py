@@ -89,6 +89,19 @@ def roofline_conv(device):
             "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
 
 
+def effective_cpus() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU box shows 256 hardware
+    threads but runs under a 16-CPU cgroup quota; 256 torch threads there get CFS-throttled to a crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline():
     """The oracle (fp32 PyTorch restatement of the reference UNet + the PnP hooks) timed on this host's cores on a
     bounded sample: ONE inversion step (B=1) + ONE PnP step (B=3, all hooks on) of BASELINE config 1
@@ -97,7 +110,7 @@ def cpu_baseline():
     from oracle import pnp_oracle
     from oracle.unet_oracle import UNetConfig, build_random_oracle
     import gpu_checks as gc
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     torch.set_num_threads(cores)
     cfg = UNetConfig.i2vgen_xl()
     oracle = build_random_oracle(cfg, 0)

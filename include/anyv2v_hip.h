@@ -56,7 +56,10 @@ typedef struct AnyV2VGemmDesc {
     int32_t Hi, Wi, Ho, Wo, stride, up; /* mode 1 */
     int32_t F, HW;                      /* mode 2: frames per clip, pixels per frame */
     int32_t act;
-    int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging */
+    int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging; bit2: no 256-row
+                            kernel; bit3: mid-tile prefetch issue; bit4: no split-K */
+    void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
+    int64_t workspace_bytes;
 } AnyV2VGemmDesc;
 
 int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream);

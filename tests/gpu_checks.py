@@ -23,6 +23,21 @@ DEV = "cuda"
 _GLDS_DEFAULT = ops.USE_GLDS
 
 
+def _effective_cpus() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+# the CPU oracle: never more torch threads than the cgroup CPU quota (the GPU box: 256 hw threads, quota 16)
+torch.set_num_threads(min(torch.get_num_threads(), _effective_cpus()))
+
+
 def _rel(a: torch.Tensor, b: torch.Tensor):
     a, b = a.float(), b.float()
     denom = b.abs().max().clamp_min(1e-6)
