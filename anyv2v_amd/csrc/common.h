@@ -38,7 +38,21 @@ static inline int av_launch_status(const char* what) {
 static inline bool av_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ float av_silu(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float av_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (torch F.gelu default).  erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, two orders below fp16
+// resolution) on the raw v_rcp / v_exp instructions: ~14 VALU ops instead of libm erff's ~35 with branches -- the GEGLU
+// epilogue evaluates it for every element of the [tokens, 4*dim] feed-forward activations.
+__device__ __forceinline__ float av_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = fmaf(-p * t, e, 1.0f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float av_gelu(float x) { return 0.5f * x * (1.0f + av_erf(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
