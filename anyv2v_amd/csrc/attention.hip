@@ -238,9 +238,18 @@ __device__ __forceinline__ h8 join8(fp16x4v_t a, fp16x4v_t b) {
     return v;
 }
 
-template <int STAGES>
+// NV = number of V / O streams that share one S = Q K^T and one softmax:
+//   NV = 1 : plain attention (and PnP aliasing through qk_mod);
+//   NV = 3 : the PnP injection step computed the way the reference's semantics allow: on
+//            injection steps the uncond / cond branches use the SOURCE branch's Q and K (pnp_utils.py:189-196), so
+//            P = softmax(Q_src K_src^T) is identical for all three branches -- one block computes it once per KV
+//            tile and applies it to V_src, V_uncond, V_cond (1/3 of the QK^T MFMAs and 1/3 of the exp/VALU work,
+//            which is what bounds this kernel at head_dim 64).  Exact: same products, same order per branch.
+template <int STAGES, int NV>
 __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
-    constexpr int TILE_BYTES = 8192, STAGE_BYTES = 2 * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
+    constexpr int TILE_BYTES = 8192, STAGE_BYTES = (1 + NV) * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
+    constexpr int LPT = 2 * (1 + NV);                                                      // LDS-DMA per thread per tile
+    static_assert((PRE == 2 && LPT == 4) || PRE == 1, "vmcnt immediates below");
     __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -251,13 +260,18 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     const int qt = bid % p.q_tiles;
     const int bh = bid / p.q_tiles;
     const int h = bh % p.heads;
-    const int i = bh / p.heads;
+    const int i = bh / p.heads;  // NV == 3: index of the source-branch element; branches are i + b * qk_mod
 
-    const int iq = p.qk_mod > 0 ? i % p.qk_mod : i;
+    const int iq = (NV == 1 && p.qk_mod > 0) ? i % p.qk_mod : i;
     const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
-    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
     const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    long long obase[NV], vbase[NV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b) {
+        const int ib = i + b * (NV == 1 ? 0 : p.qk_mod);
+        obase[b] = attn_row(ib, p.inner, p.q_outer, p.q_inner);
+        vbase[b] = attn_row(ib / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    }
 
     const int q0 = qt * 128 + w * 32;
     const bool wave_active = q0 < p.Sq;
@@ -270,36 +284,43 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h8*)(qp + 16 * ks);
     }
 
-    // DMA assignment: instruction t (0,1), chunk slot = t*256 + tid -> row = slot >> 3, physical chunk = tid & 7
+    // DMA assignment: instruction t (0,1), chunk slot = t*256 + tid -> row = slot >> 3, physical chunk = tid & 7.
+    // Source pointers advance by 64 keys per tile (incremental: no 64-bit multiplies in the loop).
     const int drow = tid >> 3, dpc = tid & 7;
-    const half_t* kp[2];
-    const half_t* vp[2];
     const int ntiles = (p.Sk + 63) / 64;
-    auto set_src = [&](int key0) {
+    const half_t* kcur[2];
+    const half_t* vcur[NV][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = drow + 32 * t;
-            const int key = key0 + row;
-            const bool ok = key < p.Sk;
-            const half_t* ks_ = p.K + (kbase + (long long)key * p.kv_seq) * p.ldk + h * 64 + ((dpc ^ ((row >> 1) & 7)) << 3);
-            const half_t* vs_ = p.V + (vbase + (long long)key * p.kv_seq) * p.ldv + h * 64 + ((dpc ^ (row & 7)) << 3);
-            kp[t] = ok ? ks_ : zeros;
-            vp[t] = ok ? vs_ : zeros;
-        }
-    };
-    auto issue = [&](int tile, int stage) {
-        set_src(tile * 64);
+    for (int t = 0; t < 2; ++t) {
+        const int row = drow + 32 * t;
+        kcur[t] = p.K + (kbase + (long long)row * p.kv_seq) * p.ldk + h * 64 + ((dpc ^ ((row >> 1) & 7)) << 3);
+#pragma unroll
+        for (int b = 0; b < NV; ++b)
+            vcur[b][t] = p.V + (vbase[b] + (long long)row * p.kv_seq) * p.ldv + h * 64 + ((dpc ^ (row & 7)) << 3);
+    }
+    const long long kstep = 64ll * p.kv_seq * p.ldk, vstep = 64ll * p.kv_seq * p.ldv;
+    int issue_key0 = 0;
+    auto issue = [&](int stage) {
         char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            glds16_attn(kp[t], st + (t * 256 + w * 64) * 16);
-            glds16_attn(vp[t], st + TILE_BYTES + (t * 256 + w * 64) * 16);
+            const bool ok = issue_key0 + drow + 32 * t < p.Sk;  // only the last tile can be ragged
+            glds16_attn(ok ? kcur[t] : zeros, st + (t * 256 + w * 64) * 16);
+            kcur[t] += kstep;
+#pragma unroll
+            for (int b = 0; b < NV; ++b) {
+                glds16_attn(ok ? vcur[b][t] : zeros, st + (1 + b) * TILE_BYTES + (t * 256 + w * 64) * 16);
+                vcur[b][t] += vstep;
+            }
         }
+        issue_key0 += 64;
     };
 
-    f16v oacc[2];
+    f16v oacc[NV][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+    for (int b = 0; b < NV; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[b][0][r] = oacc[b][1][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
     const float c = p.scale_log2;
 
@@ -312,21 +333,18 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
 #pragma unroll
     for (int db = 0; db < 2; ++db) voff[db] = vrow * 128 + (((4 * db + vc0) ^ vfl) << 4) + (i16 & 1) * 8;
 
-    for (int t = 0; t < PRE && t < ntiles; ++t) issue(t, t);
+    for (int t = 0; t < PRE && t < ntiles; ++t) issue(t);
     int stage = 0;
     for (int j = 0; j < ntiles; ++j) {
         const int ahead = ntiles - 1 - j;  // tiles issued after tile j that may still be in flight (<= PRE - 1)
-        if (PRE >= 3 && ahead >= 2)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead >= 1)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (PRE >= 2 && ahead >= 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // PRE == 2 implies LPT == 4 (NV == 1)
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (j + PRE < ntiles) issue(j + PRE, (stage + PRE) % STAGES);
+        if (j + PRE < ntiles) issue((stage + PRE) % STAGES);
         if (wave_active) {
             const char* Ks = smem + stage * STAGE_BYTES;
-            const char* Vs = Ks + TILE_BYTES;
             f16v sacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -349,14 +367,17 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                     for (int r = 0; r < 16; ++r)
                         if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) sacc[kb][r] = -1e30f;
             }
-            // V^T fragments of the first d-half: issued now, they land while the softmax runs on the VALU
-            const unsigned vs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Vs;
-            const unsigned va0 = vs_lds + voff[0], va1 = vs_lds + voff[1];
-            fp16x4v_t v0[8], v1[8];
-            v0[0] = lds_tr16<0>(va0);     v0[1] = lds_tr16<1024>(va0);
-            v0[2] = lds_tr16<2048>(va0);  v0[3] = lds_tr16<3072>(va0);
-            v0[4] = lds_tr16<4096>(va0);  v0[5] = lds_tr16<5120>(va0);
-            v0[6] = lds_tr16<6144>(va0);  v0[7] = lds_tr16<7168>(va0);
+            // V^T fragments of the first (branch, d-half) unit: issued now, they land while the softmax runs on the VALU
+            const unsigned ks_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ks;
+            fp16x4v_t va[8], vb[8];
+#define AV_TR8(dst, base)                                                                              \
+    dst[0] = lds_tr16<0>(base);    dst[1] = lds_tr16<1024>(base); dst[2] = lds_tr16<2048>(base);        \
+    dst[3] = lds_tr16<3072>(base); dst[4] = lds_tr16<4096>(base); dst[5] = lds_tr16<5120>(base);        \
+    dst[6] = lds_tr16<6144>(base); dst[7] = lds_tr16<7168>(base)
+#define AV_PV4(acc, src)                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) acc =                                                \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(src[2 * t], src[2 * t + 1]), pf[t], acc, 0, 0, 0)
+            AV_TR8(va, ks_lds + TILE_BYTES + voff[0]);
             float mx = -1e30f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -364,40 +385,52 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);  // raw v_exp_f32: args <= 0, flush-to-zero is fine
             const float mc = m_new * c;
-            m_run = m_new;
             float psum = 0.f;
             h8 pf[4];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mc));
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mc));  // raw v_exp_f32 (args <= 0)
                     psum += pv;
                     pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
                 }
-            l_run = l_run * alpha + psum;
+            // rescale only when some row's running max actually moved (exact; after the first few tiles it rarely does)
+            if (__any(m_new != m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                oacc[0][r] *= alpha;
-                oacc[1][r] *= alpha;
+                for (int b = 0; b < NV; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        oacc[b][0][r] *= alpha;
+                        oacc[b][1][r] *= alpha;
+                    }
+                m_run = m_new;
             }
-            // second d-half: issue, then wait for the first half only (8 newer reads may stay in flight)
-            v1[0] = lds_tr16<0>(va1);     v1[1] = lds_tr16<1024>(va1);
-            v1[2] = lds_tr16<2048>(va1);  v1[3] = lds_tr16<3072>(va1);
-            v1[4] = lds_tr16<4096>(va1);  v1[5] = lds_tr16<5120>(va1);
-            v1[6] = lds_tr16<6144>(va1);  v1[7] = lds_tr16<7168>(va1);
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            l_run += psum;
+            // O^T += V^T P^T, one (branch, d-half) unit at a time; the next unit's transpose reads are in flight
+            // while the current unit's 4 MFMAs run (two register sets, counted lgkmcnt)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(v0[2 * t], v0[2 * t + 1]), pf[t], oacc[0], 0, 0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(v1[2 * t], v1[2 * t + 1]), pf[t], oacc[1], 0, 0, 0);
+            for (int b = 0; b < NV; ++b) {
+                const unsigned vbase_lds = ks_lds + (1 + b) * TILE_BYTES;
+                AV_TR8(vb, vbase_lds + voff[1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                AV_PV4(oacc[b][0], va);
+                if (b + 1 < NV) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    AV_TR8(va, vbase_lds + TILE_BYTES + voff[0]);
+                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                AV_PV4(oacc[b][1], vb);
+            }
+#undef AV_TR8
+#undef AV_PV4
         }
         if (++stage == STAGES) stage = 0;
     }
@@ -405,16 +438,19 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (wave_active && qrow < p.Sq) {
         const float inv = 1.0f / l_tot;
-        half_t* op = p.O + (obase + (long long)qrow * p.q_seq) * p.ldo + h * 64 + 4 * hi;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int b = 0; b < NV; ++b) {
+            half_t* op = p.O + (obase[b] + (long long)qrow * p.q_seq) * p.ldo + h * 64 + 4 * hi;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                h4 o;
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[db][4 * g + e] * inv);
-                *(h4*)(op + 32 * db + 8 * g) = o;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[b][db][4 * g + e] * inv);
+                    *(h4*)(op + 32 * db + 8 * g) = o;
+                }
+        }
     }
 }
 
@@ -604,10 +640,13 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
         if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_attn_zero_line)) == hipSuccess) zeros = (const half_t*)ptr;
     }
     AV_CHECK(zeros != nullptr, "attention: zero line symbol unavailable");
-    if (d->flags & 8)
-        hipLaunchKernelGGL(flash_attn_d64_v2_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
-    else
-        hipLaunchKernelGGL(flash_attn_d64_v2_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    if (k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8)) {
+        // PnP injection step: one softmax per source element, three V / O streams (flag bit3 forces the aliasing form)
+        const long long nwg3 = (long long)k.qk_mod * k.heads * k.q_tiles;
+        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
+        return av_launch_status("flash_attn_d64_v2<pnp3>");
+    }
+    hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
     return av_launch_status("flash_attn_d64_v2");
 }
 

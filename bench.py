@@ -55,21 +55,34 @@ def measure_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters  # ms per launch, HIP events on the launching stream
 
 
-def roofline_spatial_attention(device):
-    """Spatial self-attention at the PnP-step shape (N=48 images, 5 heads, S=4096, d=64): 4*N*h*S^2*d FLOP."""
+def roofline_spatial_attention(device, pnp=False):
+    """Spatial self-attention at the PnP-step shape (N=48 images, 5 heads, S=4096, d=64): 4*N*h*S^2*d FLOP.
+
+    pnp=False: the plain launch (every branch its own Q, K, V) -- flash_attn_d64_v2_kernel<3,1>; algorithmic FLOP ==
+    executed FLOP.  `traffic` is the HBM byte count per launch from the PMC passes recorded in
+    profiles/r01_attention_pmc.md (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not re-measured here.
+    pnp=True: the launch the edit loop actually issues on injection steps (Q/K of all three branches alias the source
+    branch) -- flash_attn_d64_v2_kernel<2,3> shares one S/softmax over three V streams, so it executes 2/3 of the
+    reference op's MFMA FLOP; `achieved` prices the reference op's algorithmic FLOP (as the contract defines it) and
+    `executed_tflops` the MFMA work the kernel really issues."""
     from anyv2v_amd import ops
     N, h, S, d = 48, 5, 4096, 64
     C = h * d
     qkv = (torch.randn(N * S, 3 * C, device=device) * 1.0).to(torch.float16)
     o = torch.empty(N * S, C, dtype=torch.float16, device=device)
     fn = lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=N, heads=h, Sq=S, Sk=S, inner=1,
-                               q_strides=(S, 0, 1), kv_strides=(S, 0, 1))
+                               q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=N // 3 if pnp else 0)
     ms = measure_kernel(fn)
     flops = 4.0 * N * h * S * S * d
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "flash_attn_d64_kernel (spatial self-attn, N=48 h=5 S=4096 d=64)",
-            "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
+    r = {"bound": "mfma", "kernel": ("flash_attn_d64_v2_kernel<2,3> (spatial self-attn under PnP q/k injection, shared softmax, "
+                                     if pnp else "flash_attn_d64_v2_kernel<3,1> (spatial self-attn, ") + "N=48 h=5 S=4096 d=64)",
+         "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
+         "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
+         "traffic": None if pnp else 503459840}
+    if pnp:
+        r["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
+    return r
 
 
 def roofline_conv(device):
@@ -243,6 +256,7 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             line["roofline"] = roofline_spatial_attention(device)
+            line["roofline_pnp"] = roofline_spatial_attention(device, pnp=True)
             line["roofline_gemm"] = roofline_conv(device)
         if world == 1 and not args.no_cpu_baseline:
             del pipe, e_inv, e_pnp

@@ -295,6 +295,27 @@ def check_attention(naive_too=True):
         c3 = b // 3
         q[c3:2 * c3], k[c3:2 * c3], q[2 * c3:], k[2 * c3:] = q[:c3], k[:c3], q[:c3], k[:c3]  # pnp_utils.py:192-196
         out.append(_res(f"attn[{tag}] spatial PnP q/k injection", o, _sdpa(q, k, v).transpose(1, 2).reshape(b * S, C), 6e-3))
+        # shared-softmax PnP kernel (one S/P per source element, three V streams): ragged and multi-tile shapes, and
+        # agreement with the aliasing form of the same launch (flag bit3), which runs the plain kernel per branch
+        for (b, h, S) in [(3, 1, 333), (6, 5, 1024), (48, 1, 130)]:
+            C = 64 * h
+            qkv = rnd(b * S, 3 * C, scale=1.0)
+            o = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
+            kw = dict(batch=b, heads=h, Sq=S, Sk=S, inner=1, q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=b // 3)
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, naive=naive, **kw)
+            q, k, v = (qkv[:, i * C:(i + 1) * C].view(b, S, h, 64).transpose(1, 2).clone() for i in range(3))
+            c3 = b // 3
+            q[c3:2 * c3], k[c3:2 * c3], q[2 * c3:], k[2 * c3:] = q[:c3], k[:c3], q[:c3], k[:c3]
+            out.append(_res(f"attn[{tag}] PnP shared-softmax b{b} h{h} S{S}", o,
+                            _sdpa(q, k, v).transpose(1, 2).reshape(b * S, C), 6e-3))
+            if not naive:
+                o2 = torch.zeros_like(o)
+                saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | 8
+                try:
+                    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o2, **kw)
+                finally:
+                    ops.ATTN_FLAGS = saved
+                out.append(_res(f"attn PnP shared-softmax == aliasing form b{b} h{h} S{S}", o, o2.float(), 1e-6))
         # cross-attention: Sk=145, K/V shared by the F frames of a clip
         B_, Fr, S, h, Sk = 2, 3, 100, 2, 145
         C = 64 * h

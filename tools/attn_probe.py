@@ -27,14 +27,14 @@ def timeit(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def attn_case(tag, N, h, S, iters, Sk=None, kv_div=1):
+def attn_case(tag, N, h, S, iters, Sk=None, kv_div=1, qk_mod=0):
     C = 64 * h
     Sk = Sk or S
     q = torch.randn(N * S, 3 * C, device=dev).half()
     o = torch.empty(N * S, C, dtype=torch.float16, device=dev)
     if Sk == S:
         fn = lambda: ops.attention(q[:, :C], q[:, C:2 * C], q[:, 2 * C:], o, batch=N, heads=h, Sq=S, Sk=S, inner=1,
-                                   q_strides=(S, 0, 1), kv_strides=(S, 0, 1))
+                                   q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=qk_mod)
     else:
         kv = torch.randn((N // kv_div) * Sk, 2 * C, device=dev).half()
         fn = lambda: ops.attention(q[:, :C], kv[:, :C], kv[:, C:], o, batch=N, heads=h, Sq=S, Sk=Sk, inner=1,
@@ -45,9 +45,12 @@ def attn_case(tag, N, h, S, iters, Sk=None, kv_div=1):
     print(lines[-1], flush=True)
 
 
-for flags, name in ((0, "v2 3-stage"), (8, "v2 4-stage"), (4, "v1 reg-staged")):
+for flags, name in ((0, "v2"), (8, "v2 pnp as aliasing"), (4, "v1 reg-staged")):
     ops.ATTN_FLAGS = flags
     attn_case(f"[{name}] spatial 64x64 B=3", 48, 5, 4096, 10)
+    if flags != 4:
+        attn_case(f"[{name}] spatial 64x64 B=3 PnP inject", 48, 5, 4096, 10, qk_mod=16)
+        attn_case(f"[{name}] spatial 32x32 B=3 PnP inject", 48, 10, 1024, 20, qk_mod=16)
     if quick:
         continue
     attn_case(f"[{name}] spatial 64x64 B=1", 16, 5, 4096, 10)
