@@ -12,8 +12,10 @@
 // XOR-swizzled by (row & 7): conflict-free for the ds_read_b128 fragment reads (MI355X guide, T2); with LDS-DMA the
 // swizzle is applied on the global SOURCE address (destination stays lane-linear, guide rule 21).
 //   gemm_mfma_kernel  : 128 x NF*32 x 64, 4 waves 2x2, 2 LDS stages (register- or LDS-DMA-staged), 2 blocks/CU.
-//   gemm_mfma3_kernel : 256 x NF*32 x 64, 8 waves 4x2, 3 LDS stages by LDS-DMA two K-tiles ahead, counted
-//                       s_waitcnt vmcnt(N) + one raw s_barrier per K-tile (guide T3/T4) -- the large-M workhorse.
+//   gemm_big_kernel   : 256 x 320 x 64, 8 waves 4x2 (wave tile 64 x 160), 2 LDS stages by LDS-DMA, persistent
+//                       blocks with cross-tile prefetch and a wave-private epilogue -- the large-M workhorse.
+#include <type_traits>
+
 #include "common.h"
 
 enum { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_TEMPORAL = 2 };
@@ -36,6 +38,7 @@ struct GemmK {
     int vec_epi;  // bias / rowvec may be read as 8-byte vectors
     int splits;   // split-K factor (128-row kernel only): each split writes an fp32 partial tile, reduced afterwards
     float* partial;  // [splits][M][N] fp32 workspace
+    long long* trace;  // debug (flags bit5): 32 timestamps per block, see tools/gemm_trace.py
 };
 
 struct RowInfo {
@@ -112,7 +115,7 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 // (+residual) -> coalesced 16-byte stores.  Caller guarantees all waves are done with the pipeline LDS.
 template <int NF, bool GEGLU, int BM, int NTHREADS>
 __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char* smem, int m_blk, int n_blk, int wr,
-                                         int wc, int lane, int tid, int split = 0) {
+                                         int wc, int lane, int tid, int split = 0, long long* tr = nullptr) {
     constexpr int BN = NF * 32;
     constexpr int BNO = GEGLU ? BN / 2 : BN;
     constexpr int CS_LD = BNO + 8;
@@ -133,8 +136,24 @@ __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char*
     }
     const int Nout = GEGLU ? p.N / 2 : p.N;
     const int n_out_blk = GEGLU ? n_blk / 2 : n_blk;
-    // All epilogue operands are fetched with unconditional 8-byte loads (absent / out-of-range -> the zero line),
-    // so the loads of a row fragment are in flight together instead of one branch + vmcnt(0) per element.
+    constexpr int CPR = BNO / 8;                // 16-byte chunks per output-tile row
+    constexpr int NIT = BM * CPR / NTHREADS;    // chunks per thread in the store phase
+    static_assert(BM * CPR % NTHREADS == 0, "store phase assumes an exact chunk split");
+    const bool full_chunks = (Nout & 7) == 0;   // wave-uniform; false only for the tiny-N layers (conv_out, N = 4)
+    // Every global operand of the epilogue is requested up front, in one batch, so that their latencies overlap each
+    // other and the convert / LDS-staging work below (in-kernel timestamps showed the previous form -- loads next to
+    // their consumers -- spending 5-7 us per block in serialized L2 round trips, and 8-9 us in the residual loop):
+    //   residual chunks of the store phase -> rr[], bias -> bvec[], temb row vector -> tvec[][] (only when present).
+    h8 rr[NIT];
+    if (p.R != nullptr && full_chunks) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * NTHREADS;
+            const int r = id / CPR, cc = id - r * CPR;
+            const int m = m_blk + r, n0 = n_out_blk + cc * 8;
+            rr[it] = *(const h8*)((m < p.M && n0 < Nout) ? p.R + (size_t)m * p.ldr + n0 : p.zeros);
+        }
+    }
     h4 bvec[NF];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
@@ -142,11 +161,27 @@ __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char*
         const half_t* src = (p.bias != nullptr && n + 4 <= p.N) ? p.bias + n : p.zeros;
         bvec[nf] = *(const h4*)src;
     }
+    h4 tvec[GEGLU ? 1 : 4][GEGLU ? 1 : NF];
+    const bool has_rowvec = !GEGLU && p.rowvec != nullptr;
+    if constexpr (!GEGLU) {
+        if (has_rowvec) {
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int ml = wr * 64 + mf * 16 + l15;
-        const int m = m_blk + ml;
-        if constexpr (GEGLU) {
+            for (int mf = 0; mf < 4; ++mf) {
+                const int m = m_blk + wr * 64 + mf * 16 + l15;
+                const bool ok = m < p.M;
+                const half_t* rv = p.rowvec + (size_t)((ok ? m : 0) / p.rowvec_div) * p.ldrv;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    const int n = n_blk + wc * NF * 16 + nf * 16 + 4 * lq;
+                    tvec[mf][nf] = *(const h4*)((ok && n + 4 <= p.N) ? rv + n : p.zeros);
+                }
+            }
+        }
+    }
+    if constexpr (GEGLU) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int ml = wr * 64 + mf * 16 + l15;
 #pragma unroll
             for (int np = 0; np < NF / 2; ++np) {
                 h4 o;
@@ -159,54 +194,67 @@ __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char*
                 }
                 *(h4*)(Cs + ml * CS_LD + wc * NF * 8 + np * 16 + 4 * lq) = o;
             }
-        } else {
-            const bool has_rv = p.rowvec != nullptr && m < p.M;
-            const half_t* rv = p.rowvec + (size_t)((has_rv ? m : 0) / p.rowvec_div) * p.ldrv;
-            h4 tvec[NF];
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) {
-                const int n = n_blk + wc * NF * 16 + nf * 16 + 4 * lq;
-                const half_t* src = (has_rv && n + 4 <= p.N) ? rv + n : p.zeros;
-                tvec[nf] = *(const h4*)src;
-            }
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) {
-                const int nl = wc * NF * 16 + nf * 16 + 4 * lq;
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[mf][nf][r] + (float)bvec[nf][r] + (float)tvec[nf][r];
-                    if (p.act == ACT_SILU)
-                        v = av_silu(v);
-                    else if (p.act == ACT_GELU)
-                        v = av_gelu(v);
-                    o[r] = (half_t)v;
-                }
-                *(h4*)(Cs + ml * CS_LD + nl) = o;
-            }
         }
+    } else {
+        // The activation switch is hoisted out of the element loops (one wave-uniform branch per tile): left inside,
+        // hipcc if-converts it and evaluates SiLU *and* erf-GELU for all 80 outputs of every thread (measured 5-7 us
+        // per block on plain linear layers).
+        auto stage = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int ml = wr * 64 + mf * 16 + l15;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    const int nl = wc * NF * 16 + nf * 16 + 4 * lq;
+                    h4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[mf][nf][r] + (float)bvec[nf][r];
+                        if (has_rowvec) v += (float)tvec[mf][nf][r];
+                        if constexpr (ACT == ACT_SILU) v = av_silu(v);
+                        if constexpr (ACT == ACT_GELU) v = av_gelu(v);
+                        o[r] = (half_t)v;
+                    }
+                    *(h4*)(Cs + ml * CS_LD + nl) = o;
+                }
+            }
+        };
+        if (p.act == ACT_SILU)
+            stage(std::integral_constant<int, ACT_SILU>{});
+        else if (p.act == ACT_GELU)
+            stage(std::integral_constant<int, ACT_GELU>{});
+        else
+            stage(std::integral_constant<int, ACT_NONE>{});
     }
+    if (tr != nullptr && tid == 0) tr[24] = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();
-    constexpr int CPR = BNO / 8;
-    for (int id = tid; id < BM * CPR; id += NTHREADS) {
+    if (tr != nullptr && tid == 0) tr[25] = (long long)__builtin_amdgcn_s_memtime();
+    if (full_chunks) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * NTHREADS;
+            const int r = id / CPR, cc = id - r * CPR;
+            const int m = m_blk + r, n0 = n_out_blk + cc * 8;
+            h8 v = *(const h8*)(Cs + r * CS_LD + cc * 8);
+            if (p.R != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[it][e]);
+            }
+            if (m < p.M && n0 < Nout) *(h8*)(p.C + (size_t)m * p.ldc + n0) = v;
+        }
+        return;
+    }
+    for (int id = tid; id < BM * CPR; id += NTHREADS) {  // ragged N: element-wise tail
         const int r = id / CPR, cc = id - r * CPR;
         const int m = m_blk + r;
         const int n0 = n_out_blk + cc * 8;
         if (m >= p.M || n0 >= Nout) continue;
-        h8 v = *(const h8*)(Cs + r * CS_LD + cc * 8);
-        if (n0 + 8 <= Nout) {
-            if (p.R != nullptr) {
-                const h8 rr = *(const h8*)(p.R + (size_t)m * p.ldr + n0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
-            }
-            *(h8*)(p.C + (size_t)m * p.ldc + n0) = v;
-        } else {
-            for (int e = 0; e < 8 && n0 + e < Nout; ++e) {
-                float x = (float)v[e];
-                if (p.R != nullptr) x += (float)p.R[(size_t)m * p.ldr + n0 + e];
-                p.C[(size_t)m * p.ldc + n0 + e] = (half_t)x;
-            }
+        const h8 v = *(const h8*)(Cs + r * CS_LD + cc * 8);
+        for (int e = 0; e < 8 && n0 + e < Nout; ++e) {
+            float x = (float)v[e];
+            if (p.R != nullptr) x += (float)p.R[(size_t)m * p.ldr + n0 + e];
+            p.C[(size_t)m * p.ldc + n0 + e] = (half_t)x;
         }
     }
 }
@@ -246,38 +294,42 @@ struct AGen {
     }
 };
 
-// half a K-tile (one 32-deep K-step) of MFMA work for a 64 x NF*16 wave tile
-template <int NF>
-__device__ __forceinline__ void mma_half(f4 (&acc)[4][NF], const char* as, const char* bs, int wr, int wc, int lane,
-                                         int ks) {
-    const int l15 = lane & 15, lq = lane >> 4;
-    h8 af[4], bf[NF];
-    const int c = (ks * 4 + lq) ^ (l15 & 7);
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) af[mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) bf[nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][nf], 0, 0, 0);
-}
-
 // one K-tile (64) of MFMA work for a 64 x NF*16 wave tile: all 2*(4+NF) fragment reads are issued first, so the
 // compiler can retire them with counted lgkmcnt waits while the MFMAs of the first K-step already run (loading per
 // K-step made it emit a full lgkmcnt(0) in front of every MFMA batch).
-template <int NF>
+// KO (debug knock-outs, tools/gemm_trace.py): 4 = no fragment reads (register constants), 5 = no MFMAs
+template <int NF, int KO = 0>
 __device__ __forceinline__ void mma_tile(f4 (&acc)[4][NF], const char* as, const char* bs, int wr, int wc, int lane) {
     const int l15 = lane & 15, lq = lane >> 4;
     h8 af[2][4], bf[2][NF];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int c = (ks * 4 + lq) ^ (l15 & 7);
+        if constexpr (KO == 4) {
+            h8 x;
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bf[ks][nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
+            for (int e = 0; e < 8; ++e) x[e] = (half_t)(float)(lane + e);
+            asm volatile("" : "+v"(x));
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) af[ks][mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
+            for (int nf = 0; nf < NF; ++nf) bf[ks][nf] = x;
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) af[ks][mf] = x;
+        } else {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bf[ks][nf] = *(const h8*)(bs + ((wc * NF * 16 + nf * 16 + l15) * 8 + c) * 16);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) af[ks][mf] = *(const h8*)(as + ((wr * 64 + mf * 16 + l15) * 8 + c) * 16);
+        }
+    }
+    if constexpr (KO == 5) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) asm volatile("" ::"v"(bf[ks][nf]));
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) asm volatile("" ::"v"(af[ks][mf]));
+        }
+        return;
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -286,6 +338,10 @@ __device__ __forceinline__ void mma_tile(f4 (&acc)[4][NF], const char* as, const
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], acc[mf][nf], 0, 0, 0);
+    if constexpr (KO == 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     // scheduling contract for this region: all fragment reads first, then the MFMAs (hipcc otherwise sinks each read
     // next to its consumer and drains with lgkmcnt(0) four to six times per tile)
     // K-step 0 fragments, then K-step 0 MFMAs with the K-step 1 reads slotted in (1 read per 2 MFMAs), then the rest
@@ -301,8 +357,9 @@ __device__ __forceinline__ void mma_tile(f4 (&acc)[4][NF], const char* as, const
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int NF, bool GLDS, bool GEGLU, int MODE>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
+// KO (debug knock-outs): 2 = K loop issues only the W tiles, 3 = K loop issues no loads, 4 / 5 see mma_tile
+template <int NF, bool GLDS, bool GEGLU, int MODE, bool TRACE = false, int KO = 0>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK p) {
     constexpr int BM = 128, BN = NF * 32;
     constexpr int A_BYTES = BM * 64 * 2;
     constexpr int B_BYTES = BN * 64 * 2;
@@ -314,6 +371,15 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     int bid = blockIdx.x;
     const int nwg = gridDim.x;
+    long long* tr = nullptr;
+    if constexpr (TRACE) {
+        tr = p.trace + (size_t)blockIdx.x * 32;
+        if (tid == 0) {
+            tr[0] = ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+            tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
+            tr[2] = (long long)__builtin_amdgcn_s_memtime();
+        }
+    }
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);  // XCD-contiguous tile order (bijective)
     const int ntiles = nwg / p.splits;
     const int split = bid / ntiles;  // split-K: this block covers K-tiles [kt_begin, kt_end) of its output tile
@@ -345,13 +411,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
     for (int i = 0; i < NB; ++i) bptr[i] += (size_t)kt_begin * 64;
     AGen<MODE> gen;
     gen.start(p, ri, kc, kt_begin, ntap);
-    auto issue = [&](int buf) {  // loads the generator's current tile, then advances it
+    auto issue = [&](int buf, bool with_a = true) {  // loads the generator's current tile, then advances it
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if constexpr (GLDS)
-                glds16(gen.ap[i], As0 + buf * A_BYTES + (i * 256 + w * 64) * 16);
-            else
+            if constexpr (GLDS) {
+                if (with_a) glds16(gen.ap[i], As0 + buf * A_BYTES + (i * 256 + w * 64) * 16);
+            } else {
                 ra[i] = *(const h8*)gen.ap[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -381,117 +448,262 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmK p) {
     if constexpr (!GLDS) commit(0);
     if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (TRACE) if (tid == 0) tr[3] = (long long)__builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool has_next = kt + 1 < nk;
-        if (has_next) issue(cur ^ 1);
-        mma_tile<NF>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
+        if (has_next && KO != 3) issue(cur ^ 1, KO != 2);
+        mma_tile<NF, KO>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
+        if constexpr (TRACE) if (tid == 0 && kt < 8) tr[4 + kt] = (long long)__builtin_amdgcn_s_memtime();
         if constexpr (!GLDS) {
             if (has_next) commit(cur ^ 1);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        if constexpr (TRACE) if (tid == 0 && kt < 8) tr[12 + kt] = (long long)__builtin_amdgcn_s_memtime();
     }
-    epilogue<NF, GEGLU, BM, 256>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid, split);
+    if constexpr (TRACE) if (tid == 0) tr[20] = (long long)__builtin_amdgcn_s_memtime();
+    epilogue<NF, GEGLU, BM, 256>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid, split, tr);
+    if constexpr (TRACE) {
+        if (tid == 0) tr[26] = (long long)__builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            tr[21] = (long long)__builtin_amdgcn_s_memtime();
+            tr[22] = (long long)__builtin_amdgcn_s_memrealtime();
+            tr[23] = nk;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Large-M variant (see file header).  All LDS lives in ONE __shared__ array and every operand goes through LDS-DMA
-// so that hipcc does not insert vmcnt(0) drains into the K loop (checked in the .s: the loop body holds exactly one
-// counted s_waitcnt vmcnt and one s_barrier).
-template <int NF, bool GEGLU, int MODE, int SCHED>
-__global__ __launch_bounds__(512) void gemm_mfma3_kernel(const GemmK p) {
-    constexpr int BM = 256, BN = NF * 32, STAGES = 3;
-    constexpr int A_BYTES = BM * 64 * 2;
-    constexpr int B_BYTES = BN * 64 * 2;
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int NBI = (BN * 8 + 511) / 512;  // B LDS-DMA instructions per thread per tile
-    constexpr int REM = BN * 8 - (NBI - 1) * 512;  // chunks covered by the last one (multiple of 64)
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+// Large-M persistent kernel: 256 x 320 x 64 block tile, 8 waves 4(M) x 2(N), wave tile 64 x 160 (4 x 10 MFMA 16x16x32
+// fragments, 160 accumulator registers), two LDS stages of 72 KB filled by LDS-DMA.
+//
+// Why this shape (measured on the 128-row kernel with in-kernel timestamps and knock-outs, tools/gemm_trace.py):
+// removing the MFMAs from its K loop saved 19 %, removing the LDS-DMA loads 45 % -- the loop is bound by the operand
+// stream (14 KB of L2->LDS traffic and 14 DMA instructions per MFLOP), not by the matrix cores.  A 256 x 320 tile
+// halves both (7 KB and 7 DMA instructions per MFLOP) and cuts fragment re-reads from LDS by 28 %.  All channel
+// counts of the UNet are multiples of 320, so the 320-wide tile has no N waste.
+//
+// One block per CU (147 KB of LDS), grid = min(tiles, 256) persistent blocks walking tiles in XCD-contiguous order.
+// The first K-tile of a block's NEXT output tile is requested during the last K-tile of the current one, so the
+// prologue latency is paid once per block, and the epilogue runs wave-privately (16-row slabs staged through the
+// just-consumed LDS stage, no block barriers) while that prefetch is in flight.
+// One K-tile (64) for the 64 x 160 wave tile, written in the exact order it should issue (sched_barrier pins it):
+//  * weight fragments roll: bf[nf] is read two fragments ahead of its four MFMAs, so at most three are live; the
+//    activation fragments of the next K-step are read during the last four fragment groups (44 fragment registers
+//    live next to the 160 accumulators, instead of 112 when hipcc hoists all 28 reads of the tile to the top);
+//  * the next tile's nine LDS-DMA pieces are threaded through the first half of the MFMA stream, one per four MFMAs
+//    (they have to sit here textually: an LDS-DMA load writes LDS, so hipcc never moves it across a ds_read).
+template <int MF, typename PieceFn>
+__device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, const char* bs, int wr, int wc, int lane,
+                                             PieceFn&& piece) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    const char* a0 = as + (wr * MF * 16 + l15) * 128;
+    const char* b0 = bs + (wc * 160 + l15) * 128;
+    const int c0 = ((0 * 4 + lq) ^ (l15 & 7)) * 16, c1 = ((1 * 4 + lq) ^ (l15 & 7)) * 16;
+    h8 af[2][MF], bf[2][10];
+#define AV_RA(ks, mf) af[ks][mf] = *(const h8*)(a0 + (mf) * 2048 + ((ks) ? c1 : c0))
+#define AV_RB(ks, nf) bf[ks][nf] = *(const h8*)(b0 + (nf) * 2048 + ((ks) ? c1 : c0))
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) AV_RA(0, mf);
+    AV_RB(0, 0);
+    AV_RB(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    int q = 0, npiece = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int nf = 0; nf < 10; ++nf) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], acc[mf][nf], 0, 0, 0);
+            q += MF;
+            __builtin_amdgcn_sched_barrier(0);
+            if (nf + 2 < 10) {
+                AV_RB(ks, nf + 2);
+            } else if (ks == 0) {
+                AV_RB(1, nf + 2 - 10);
+            }
+            if (ks == 0 && nf >= 10 - MF) AV_RA(1, nf - (10 - MF));
+            if (npiece < MF + 5) piece(npiece++);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef AV_RA
+#undef AV_RB
+}
+
+template <int MF, bool GEGLU, int MODE>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
+    constexpr int BM = 64 * MF, BN = 320;  // four wave rows of MF 16-row fragments
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int SLAB_LD = (GEGLU ? 80 : 160) + 8;          // halves; 16-byte aligned rows
+    constexpr int SLAB_BYTES = 16 * SLAB_LD * 2;             // per wave
+    static_assert(8 * SLAB_BYTES <= STAGE_BYTES, "epilogue slabs must fit in one pipeline stage");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-    int bid = blockIdx.x;
-    const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
-    const int m_blk = mt * BM, n_blk = nt * BN;
+    const int G = gridDim.x;
+    const int b0 = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous
+    const int tilesM = (p.M + BM - 1) / BM;
+    const int ntiles = tilesM * p.tilesN;
 
-    const int srow0 = tid >> 3;  // 0..63
-    const int pc = tid & 7;
-    const int kc = pc ^ (srow0 & 7);
-    RowInfo ri[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ri[i] = make_row<MODE>(p, m_blk + srow0 + 64 * i);
-    const half_t* bptr[NBI];
-    int blds[NBI];
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-        // waves beyond REM chunks of the last instruction re-load the same chunks (same bytes, benign)
-        const int chunk = (i < NBI - 1) ? i * 512 + tid : (NBI - 1) * 512 + (tid % REM);
-        const int row = chunk >> 3;
-        int n = n_blk + row;
-        n = n < p.N ? n : p.N - 1;
-        bptr[i] = p.W + (size_t)n * p.Ktot + ((chunk & 7) ^ (row & 7)) * 8;
-        blds[i] = A_BYTES + (chunk - lane) * 16;  // wave-uniform LDS-DMA base (lane-linear destination)
-    }
-
-    int blds_s[NBI];
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) blds_s[i] = __builtin_amdgcn_readfirstlane(blds[i]);
+    const int srow0 = tid >> 3, pc = tid & 7, kc = pc ^ (srow0 & 7);
     const int ntap = p.nt0 + p.nt1;
+    const int nk = p.taps * ntap;
+
+    // ---- producer state (the tile whose K-tiles are being requested; runs ahead of the consumer by one K-tile) ----
+    RowInfo ri[4];  // (entries >= MF unused)
+    const half_t* bptr;               // W row (n_blk + srow0); the other four rows sit 64 * Ktot halves apart
+    const size_t brow = (size_t)64 * p.Ktot;
     AGen<MODE> gen;
-    gen.start(p, ri, kc);
-    auto issue = [&](int stage) {  // LDS-DMA of the generator's current tile into `stage`, then advance
-        char* st = smem + stage * STAGE_BYTES;
+    auto producer_start = [&](int tile) {
+        const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(gen.ap[i], st + (i * 512 + w * 64) * 16);
-#pragma unroll
-        for (int i = 0; i < NBI; ++i) {
-            glds16(bptr[i], st + blds_s[i]);
-            bptr[i] += 64;
-        }
+        for (int i = 0; i < 4; ++i) ri[i] = make_row<MODE>(p, i < MF ? mt * BM + srow0 + 64 * i : p.M);
+        bptr = p.W + (size_t)(nt * BN + srow0) * p.Ktot + kc * 8;
+        gen.start(p, ri, kc);
+    };
+    auto advance = [&]() {
+        bptr += 64;
         gen.next(p, ri, kc, ntap);
     };
-
-    f4 acc[4][NF];
+    auto issue = [&](int stage) {
+        char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MF; ++i) glds16(gen.ap[i], st + (i * 512 + w * 64) * 16);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 5; ++i) glds16(bptr + i * brow, st + A_BYTES + (i * 512 + w * 64) * 16);
+        advance();
+    };
 
-    constexpr int LPT = 4 + NBI;  // LDS-DMA instructions per thread per K-tile
-    static_assert(LPT == 6 || LPT == 7, "vmcnt immediates below assume 6 or 7 loads per tile");
-    const int nk = p.taps * ntap;
+    f4 acc[MF][10];
+    int tile = b0;
+    if (tile >= ntiles) return;
+    producer_start(tile);
     issue(0);
-    if (nk > 1) issue(1);
     int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt was issued two iterations ago; only tile kt+1's LPT loads may still be in flight
-        if (kt + 1 < nk) {
-            if constexpr (LPT == 7)
-                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool landed = false;
+    bool rederive = false;  // producer state is not carried across an epilogue (register pressure): re-derive it  // the current tile's first K-tile was already waited for (before the previous epilogue)
+    while (true) {
+        const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+        const int m_wave = mt * BM + wr * MF * 16;
+        const int n_wave = nt * BN + wc * 160;
+        const int next_tile = tile + G;
+        const bool has_next = next_tile < ntiles;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (rederive) {
+            producer_start(tile);
+            advance();  // K-tile 0 of this tile was requested during the previous tile's last K-tile
         }
-        __builtin_amdgcn_s_barrier();  // everyone's tile kt landed; everyone finished reading stage (kt-1)%3
-        int s2 = stage + 2;
-        if (s2 >= STAGES) s2 -= STAGES;
-        const char* as = smem + stage * STAGE_BYTES;
-        if constexpr (SCHED == 0) {
-            if (kt + 2 < nk) issue(s2);
-            mma_tile<NF>(acc, as, as + A_BYTES, wr, wc, lane);
-        } else {  // issue the prefetch between the two K-steps: its address math / DMA issue sits behind 20 MFMAs
-            mma_half<NF>(acc, as, as + A_BYTES, wr, wc, lane, 0);
-            if (kt + 2 < nk) issue(s2);
-            mma_half<NF>(acc, as, as + A_BYTES, wr, wc, lane, 1);
+
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt > 0 || !landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // K-tile kt landed for everyone; everyone is done with the other stage
+            const bool last = kt + 1 == nk;
+            if (last && has_next) producer_start(next_tile);  // the pieces below then fetch K-tile 0 of the next tile
+            const bool fetch = !last || has_next;
+            const char* as = smem + stage * STAGE_BYTES;
+            char* st = smem + (stage ^ 1) * STAGE_BYTES;
+            mma_tile_big<MF>(acc, as, as + A_BYTES, wr, wc, lane, [&](int i) {
+                if (i < MF)
+                    glds16(fetch ? gen.ap[i] : p.zeros, st + (i * 512 + w * 64) * 16);
+                else
+                    glds16(fetch ? bptr + (i - MF) * brow : p.zeros, st + A_BYTES + ((i - MF) * 512 + w * 64) * 16);
+            });
+            if (fetch) advance();
+            stage ^= 1;
         }
-        if (++stage == STAGES) stage = 0;
+        // `stage` now names the buffer holding the prefetched K-tile 0 of the next tile; stage ^ 1 was just consumed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // settle the prefetch BEFORE the stores below enter the queue
+        __builtin_amdgcn_s_barrier();                     // every wave is done reading the consumed stage
+        landed = true;
+        rederive = true;
+
+        // ---------------- wave-private epilogue: 4 slabs of 16 rows x 160 (GEGLU: 80) output columns ----------------
+        // the epilogue's lane-derived offsets must not be hoisted out of the tile loop (they would live across the K loop
+        // and spill): launder the lane id once per tile
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int l15 = lane_e & 15, lq = lane_e >> 4;
+        half_t* const slab = (half_t*)(smem + (stage ^ 1) * STAGE_BYTES + w * SLAB_BYTES);
+        constexpr int OUT_W = GEGLU ? 80 : 160;       // output columns of this wave
+        constexpr int CPRW = OUT_W / 8;               // 16-byte chunks per slab row
+        constexpr int NIT = (16 * CPRW + 63) / 64;    // store iterations per slab (5, or 3 with a half-empty last one)
+        const int n_out_wave = GEGLU ? n_wave / 2 : n_wave;
+        // (dispatch guarantees N % 320 == 0 and act in {none, GEGLU}; rows are guarded: M need not be a multiple of BM)
+        h4 bvec[10];
+#pragma unroll
+        for (int nf = 0; nf < 10; ++nf)
+            bvec[nf] = *(const h4*)(p.bias != nullptr ? p.bias + n_wave + nf * 16 + 4 * lq : p.zeros);
+        const bool has_res = p.R != nullptr;
+        h8 rr[2][NIT];
+        auto res_load = [&](int mf, h8 (&dst)[NIT]) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 64 + lane_e;
+                const int row = c / CPRW, cc = c - row * CPRW;
+                const bool ok = (16 * CPRW % 64 == 0 || c < 16 * CPRW) && m_wave + mf * 16 + row < p.M;
+                dst[it] = *(const h8*)(ok ? p.R + (size_t)(m_wave + mf * 16 + row) * p.ldr + n_out_wave + cc * 8 : p.zeros);
+            }
+        };
+        if (has_res) res_load(0, rr[0]);
+        // per 16-row slab: (+bias, +temb row vector | GEGLU) -> fp16 -> LDS (turns lane-owns-4-channels into
+        // row-contiguous 16-byte chunks) -> (+residual) -> store.  The residual of slab mf+1 is requested before slab
+        // mf's round trip; the accumulators of finished slabs free the registers for it.
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            if (has_res && mf + 1 < MF) res_load(mf + 1, rr[(mf + 1) & 1]);
+            if constexpr (GEGLU) {
+#pragma unroll
+                for (int np = 0; np < 5; ++np) {
+                    h4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float hv = (float)(half_t)(acc[mf][2 * np][r] + (float)bvec[2 * np][r]);
+                        const float gv = (float)(half_t)(acc[mf][2 * np + 1][r] + (float)bvec[2 * np + 1][r]);
+                        o[r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
+                    }
+                    *(h4*)(slab + l15 * SLAB_LD + np * 16 + 4 * lq) = o;
+                }
+            } else {
+                const bool has_rv = p.rowvec != nullptr;
+                const int mrow = m_wave + mf * 16 + l15;
+                const half_t* rv = has_rv ? p.rowvec + (size_t)((mrow < p.M ? mrow : 0) / p.rowvec_div) * p.ldrv + n_wave + 4 * lq
+                                          : p.zeros;
+#pragma unroll
+                for (int nf = 0; nf < 10; ++nf) {
+                    h4 tv = (h4){0, 0, 0, 0};
+                    if (has_rv) tv = *(const h4*)(rv + nf * 16);
+                    h4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[mf][nf][r] + (float)bvec[nf][r] + (float)tv[r]);
+                    *(h4*)(slab + l15 * SLAB_LD + nf * 16 + 4 * lq) = o;
+                }
+            }
+            // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the read-back
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 64 + lane_e;
+                const int row = c / CPRW, cc = c - row * CPRW;
+                const bool ok = (16 * CPRW % 64 == 0 || c < 16 * CPRW) && m_wave + mf * 16 + row < p.M;
+                h8 v = *(const h8*)(slab + (ok ? row * SLAB_LD + cc * 8 : 0));
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[mf & 1][it][e]);
+                }
+                if (ok) *(h8*)(p.C + (size_t)(m_wave + mf * 16 + row) * p.ldc + n_out_wave + cc * 8) = v;
+            }
+        }
+
+        if (!has_next) break;
+        tile = next_tile;
     }
-    __syncthreads();
-    epilogue<NF, GEGLU, BM, 512>(p, acc, smem, m_blk, n_blk, wr, wc, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -612,23 +824,26 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     const bool glds = (d->flags & 2) != 0;
     const int nf = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
     k.tilesN = (d->N + nf * 32 - 1) / (nf * 32);
-    if (glds && !(d->flags & 4) && d->M >= 8192) {  // large M: 256-row tile, 3-stage LDS-DMA ring
-        const dim3 grid(((d->M + 255) / 256) * k.tilesN);
-#define AV_LAUNCH3(SCHED_)                                                                             \
-    do {                                                                                               \
-        if (geglu)                                                                                     \
-            hipLaunchKernelGGL((gemm_mfma3_kernel<4, true, MODE, SCHED_>), grid, dim3(512), 0, s, k);  \
-        else if (nf == 5)                                                                              \
-            hipLaunchKernelGGL((gemm_mfma3_kernel<5, false, MODE, SCHED_>), grid, dim3(512), 0, s, k); \
-        else                                                                                           \
-            hipLaunchKernelGGL((gemm_mfma3_kernel<4, false, MODE, SCHED_>), grid, dim3(512), 0, s, k); \
-    } while (0)
-        if (d->flags & 8)
-            AV_LAUNCH3(1);
-        else
-            AV_LAUNCH3(0);
-#undef AV_LAUNCH3
-        return av_launch_status("gemm_mfma3");
+    if (glds && !(d->flags & 4) && d->N % 320 == 0 && (!geglu || MODE == MODE_LINEAR) && (geglu || d->act == ACT_NONE)) {
+        // large launches: persistent 192 x 320 tiles, one block per CU (see gemm_big_kernel); taken when the tiles fill
+        // the 256 CUs for a whole number of rounds well enough (>= 75 %), or when forced (flags bit3)
+        constexpr int BMB = 192;
+        const int tiles_big = ((d->M + BMB - 1) / BMB) * (d->N / 320);
+        const int rounds = (tiles_big + 255) / 256;
+        const bool fills = tiles_big >= 224 && tiles_big * 4 >= rounds * 256 * 3;
+        if (fills || (d->flags & 8)) {
+            k.tilesN = d->N / 320;
+            const dim3 grid(tiles_big < 256 ? tiles_big : 256);
+            if constexpr (MODE == MODE_LINEAR) {
+                if (geglu)
+                    hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR>), grid, dim3(512), 0, s, k);
+                else
+                    hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR>), grid, dim3(512), 0, s, k);
+            } else {
+                hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE>), grid, dim3(512), 0, s, k);
+            }
+            return av_launch_status("gemm_big");
+        }
     }
     const int tiles = ((d->M + 127) / 128) * k.tilesN;
     // split-K for launches that cannot fill the chip (512 block slots) and have a long K loop (the 8x8 / 16x16-level
@@ -644,9 +859,28 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         }
     }
     const dim3 grid(tiles * k.splits);
+    if ((d->flags & 32) && glds && k.splits == 1 && d->workspace != nullptr &&
+        (size_t)grid.x * 32 * sizeof(long long) <= (size_t)d->workspace_bytes) {  // debug: per-block phase timestamps
+        k.trace = (long long*)d->workspace;
+        if (geglu)
+            hipLaunchKernelGGL((gemm_mfma_kernel<4, true, true, MODE, true>), grid, dim3(256), 0, s, k);
+        else if (nf == 5)
+            hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, true>), grid, dim3(256), 0, s, k);
+        else
+            hipLaunchKernelGGL((gemm_mfma_kernel<4, true, false, MODE, true>), grid, dim3(256), 0, s, k);
+        return av_launch_status("gemm_mfma<trace>");
+    }
+    const int ko = (d->flags >> 6) & 7;  // debug knock-outs (wrong results by design), NF = 5 plain tiles only
+    if (ko >= 2 && ko <= 5 && glds && !geglu && nf == 5 && k.splits == 1) {
+        if (ko == 2) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 2>), grid, dim3(256), 0, s, k);
+        if (ko == 3) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 3>), grid, dim3(256), 0, s, k);
+        if (ko == 4) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 4>), grid, dim3(256), 0, s, k);
+        if (ko == 5) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 5>), grid, dim3(256), 0, s, k);
+        return av_launch_status("gemm_mfma<knock-out>");
+    }
 #define AV_LAUNCH2(NF_, GEGLU_)                                                                          \
     do {                                                                                                 \
-        if (glds)                                                                                        \
+        if (glds)                                                                                   \
             hipLaunchKernelGGL((gemm_mfma_kernel<NF_, true, GEGLU_, MODE>), grid, dim3(256), 0, s, k);   \
         else                                                                                             \
             hipLaunchKernelGGL((gemm_mfma_kernel<NF_, false, GEGLU_, MODE>), grid, dim3(256), 0, s, k);  \
@@ -710,6 +944,7 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     k.tilesN = 1;
     k.splits = 1;
     k.partial = nullptr;
+    k.trace = nullptr;
     k.vec_epi = (((uintptr_t)d->bias & 7) == 0) && (((uintptr_t)d->rowvec & 7) == 0) && (d->ldrv % 4 == 0) && (d->N % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
 

@@ -56,8 +56,10 @@ typedef struct AnyV2VGemmDesc {
     int32_t Hi, Wi, Ho, Wo, stride, up; /* mode 1 */
     int32_t F, HW;                      /* mode 2: frames per clip, pixels per frame */
     int32_t act;
-    int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging; bit2: no 256-row
-                            kernel; bit3: mid-tile prefetch issue; bit4: no split-K */
+    int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging; bit2: never use the
+                            persistent 192x320 kernel; bit3: always use it when the shape allows; bit4: no split-K;
+                            debug only: bit5 = per-block phase timestamps into the workspace, bits 6-8 = K-loop
+                            knock-outs (wrong results by design) -- see tools/gemm_trace.py */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
 } AnyV2VGemmDesc;

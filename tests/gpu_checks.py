@@ -155,6 +155,74 @@ def check_gemm(variants=("reg", "glds", "naive")):
     return out
 
 
+def check_gemm_big():
+    """Persistent 256x320 kernel (gemm_big_kernel), forced with flag bit3 on shapes small enough for the references:
+    single / multiple rounds per block, every mode, two-source K loop, bias / temb / residual / GEGLU epilogues."""
+    out = []
+    saved = ops.GEMM_FLAGS
+    ops.GEMM_FLAGS = (saved & ~4) | 8
+    try:
+        for (M, N, K, res, rvd) in [(512, 320, 320, True, 0), (1024, 640, 192, False, 128), (256, 960, 64, True, 256),
+                                    (256 * 41, 2560, 128, True, 0), (256 * 300, 320, 64, False, 0)]:
+            a, w, bias = rnd(M, K), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
+            r = rnd(M, N) if res else None
+            rv = rnd(M // rvd, N) if rvd else None
+            y = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r)
+            out.append(_res(f"gemm[big] M{M} N{N} K{K} res={res} rowvec={bool(rvd)}", y, _gemm_ref(a, w, bias, rv, rvd, r), 4e-3))
+            yn = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r, naive=True)
+            out.append(_res(f"gemm[big] == naive kernel M{M} N{N} K{K}", y, yn.float(), 2e-3))
+        # two-source K loop (skip concat)
+        a0, a1 = rnd(768, 128), rnd(768, 64)
+        w = rnd(320, 192, scale=0.1)
+        y = ops.gemm(a0, w, a1=a1)
+        out.append(_res("gemm[big] two-source", y, _gemm_ref(torch.cat([a0, a1], 1), w), 4e-3))
+        # GEGLU, one and several rounds
+        for M in (512, 256 * 70):
+            dim, inner = 128, 640
+            a = rnd(M, dim)
+            wfull, bfull = rnd(2 * inner, dim, scale=1 / math.sqrt(dim)), rnd(2 * inner, scale=0.1)
+            wh, wg = wfull[:inner].view(inner // 16, 16, dim), wfull[inner:].view(inner // 16, 16, dim)
+            wp = torch.stack([wh, wg], 1).reshape(2 * inner, dim).contiguous()
+            bp = torch.stack([bfull[:inner].view(-1, 16), bfull[inner:].view(-1, 16)], 1).reshape(-1).contiguous()
+            y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU)
+            proj = a.float() @ wfull.float().t() + bfull.float()
+            out.append(_res(f"gemm[big] GEGLU M{M}", y, proj[:, :inner] * F.gelu(proj[:, inner:]), 6e-3))
+        # conv 3x3 (stride 1, stride 2, folded upsample) with temb row vector / residual
+        n, ci, co, H, W = 8, 64, 320, 16, 16
+        x, w, b = rnd(n, ci, H, W), rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
+        temb, res = rnd(4, co), rnd(n * H * W, co)
+        y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=2 * H * W, residual=res,
+                     mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0))
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + temb.float().repeat_interleave(2, 0)[:, :, None, None]
+        out.append(_res("conv3x3[big] s1 +bias+temb+res", y, _to_tokens(ref) + res.float(), 4e-3))
+        y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, H // 2, W // 2, 2, 0),
+                     M=n * (H // 2) * (W // 2))
+        out.append(_res("conv3x3[big] stride 2", y, _to_tokens(F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1)), 4e-3))
+        y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, 2 * H, 2 * W, 1, 1),
+                     M=n * 4 * H * W)
+        ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+        out.append(_res("conv3x3[big] nearest-x2 folded", y, _to_tokens(ref), 4e-3))
+        # two-source conv (up-block skip concat)
+        x1 = rnd(n, 128, H, W)
+        w2 = rnd(co, ci + 128, 3, 3, scale=1 / math.sqrt(9 * (ci + 128)))
+        y = ops.gemm(_to_tokens(x), _pack_conv(w2), a1=_to_tokens(x1), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0))
+        ref = F.conv2d(torch.cat([x, x1], 1).float(), w2.float(), b.float(), padding=1)
+        out.append(_res("conv3x3[big] two-source", y, _to_tokens(ref), 4e-3))
+        # temporal (3,1,1) conv with residual
+        B_, Fr, HW, C = 2, 8, 64, 128
+        xt = rnd(B_ * Fr * HW, C)
+        wt, bt, rt = rnd(320, C, 3, scale=1 / math.sqrt(3 * C)), rnd(320), rnd(B_ * Fr * HW, 320)
+        y = ops.gemm(xt, wt.permute(0, 2, 1).reshape(320, 3 * C).contiguous(), bias=bt, residual=rt, mode=ops.MODE_TEMPORAL,
+                     temporal=(Fr, HW))
+        x5 = xt.float().view(B_, Fr, HW, C).permute(0, 3, 1, 2)  # [B, C, F, HW]
+        ref = F.conv1d(x5.permute(0, 3, 1, 2).reshape(B_ * HW, C, Fr), wt.float(), bt.float(), padding=1)
+        ref = ref.view(B_, HW, 320, Fr).permute(0, 3, 1, 2).reshape(B_ * Fr * HW, 320) + rt.float()
+        out.append(_res("temporal conv[big] +res", y, ref, 4e-3))
+    finally:
+        ops.GEMM_FLAGS = saved
+    return out
+
+
 def _to_tokens(x):  # NCHW -> [(n h w), c]
     n, c, h, w = x.shape
     return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
@@ -564,4 +632,4 @@ def check_loops_mini():
     return out
 
 
-ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_conv, check_norms, check_attention, check_elementwise]
+ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_conv, check_norms, check_attention, check_elementwise]

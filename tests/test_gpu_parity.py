@@ -25,6 +25,10 @@ def test_gemm(variant):
     _assert_all(gc.check_gemm((variant,)))
 
 
+def test_gemm_persistent_big_tile():
+    _assert_all(gc.check_gemm_big())
+
+
 @pytest.mark.parametrize("variant", ["reg", "glds", "naive"])
 def test_conv(variant):
     _assert_all(gc.check_conv((variant,)))
