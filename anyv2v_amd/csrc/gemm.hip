@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK p) {
 //  * weight fragments roll: bf[nf] is read two fragments ahead of its four MFMAs, so at most three are live; the
 //    activation fragments of the next K-step are read during the last four fragment groups (44 fragment registers
 //    live next to the 160 accumulators, instead of 112 when hipcc hoists all 28 reads of the tile to the top);
-//  * the next tile's nine LDS-DMA pieces are threaded through the first half of the MFMA stream, one per four MFMAs
+//  * the next tile's LDS-DMA pieces are threaded through the first half of the MFMA stream, one per fragment group
 //    (they have to sit here textually: an LDS-DMA load writes LDS, so hipcc never moves it across a ds_read).
 template <int MF, typename PieceFn>
 __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, const char* bs, int wr, int wc, int lane,
@@ -535,7 +535,7 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
 #undef AV_RB
 }
 
-template <int MF, bool GEGLU, int MODE>
+template <int MF, bool GEGLU, int MODE, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     constexpr int BM = 64 * MF, BN = 320;  // four wave rows of MF 16-row fragments
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -603,8 +603,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
         }
 
         for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 2 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             if (kt > 0 || !landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt == 3) p.trace[(size_t)blockIdx.x * 32 + 29] = (long long)__builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();  // K-tile kt landed for everyone; everyone is done with the other stage
+            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 3 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             const bool last = kt + 1 == nk;
             if (last && has_next) producer_start(next_tile);  // the pieces below then fetch K-tile 0 of the next tile
             const bool fetch = !last || has_next;
@@ -616,9 +619,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
                 else
                     glds16(fetch ? bptr + (i - MF) * brow : p.zeros, st + A_BYTES + ((i - MF) * 512 + w * 64) * 16);
             });
+            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 4 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             if (fetch) advance();
             stage ^= 1;
         }
+        if constexpr (TRACE) if (tid == 0 && tile == b0) p.trace[(size_t)blockIdx.x * 32 + 26] = (long long)__builtin_amdgcn_s_memtime();
         // `stage` now names the buffer holding the prefetched K-tile 0 of the next tile; stage ^ 1 was just consumed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // settle the prefetch BEFORE the stores below enter the queue
         __builtin_amdgcn_s_barrier();                     // every wave is done reading the consumed stage
@@ -701,6 +706,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
             }
         }
 
+        if constexpr (TRACE) {
+            if (tid == 0 && tile == b0) {
+                p.trace[(size_t)blockIdx.x * 32 + 27] = (long long)__builtin_amdgcn_s_memtime();
+                p.trace[(size_t)blockIdx.x * 32 + 28] = nk;
+            }
+        }
         if (!has_next) break;
         tile = next_tile;
     }
@@ -834,6 +845,18 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         if (fills || (d->flags & 8)) {
             k.tilesN = d->N / 320;
             const dim3 grid(tiles_big < 256 ? tiles_big : 256);
+            if ((d->flags & 32) && d->workspace != nullptr && (size_t)grid.x * 32 * sizeof(long long) <= (size_t)d->workspace_bytes) {
+                k.trace = (long long*)d->workspace;  // debug: phase timestamps of each block's first tile
+                if constexpr (MODE == MODE_LINEAR) {
+                    if (geglu)
+                        hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR, true>), grid, dim3(512), 0, s, k);
+                    else
+                        hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR, true>), grid, dim3(512), 0, s, k);
+                } else {
+                    hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, true>), grid, dim3(512), 0, s, k);
+                }
+                return av_launch_status("gemm_big<trace>");
+            }
             if constexpr (MODE == MODE_LINEAR) {
                 if (geglu)
                     hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR>), grid, dim3(512), 0, s, k);
