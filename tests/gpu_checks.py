@@ -223,6 +223,38 @@ def check_gemm_big():
     return out
 
 
+def check_gemm_splitk():
+    """Split-K path (launches that cannot fill the chip and have >= 16 K-tiles; fp32 partial tiles + a second pass that
+    sums them in split order): against torch, against the unsplit kernel (flag bit4), and bit-reproducibility.
+    (A fused last-arriver reduction was tried and dropped: the device-scope fences it needs write back / invalidate the
+    per-XCD L2 on gfx950 and cost far more than the second launch -- DESIGN.md.)"""
+    out = []
+    saved = ops.GEMM_FLAGS
+    try:
+        # 8x8-level conv: M = 3 clips x 16 frames x 64 px, K = 2304 (36 K-tiles), 24 x 2 = 48 tiles -> 4 splits
+        n, ci, co, H, W = 48, 256, 320, 8, 8
+        x, w, b = rnd(n, ci, H, W), rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
+        temb, res = rnd(3, co), rnd(n * H * W, co)
+        kw = dict(bias=b, rowvec=temb, rowvec_div=16 * H * W, residual=res, mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0))
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + temb.float().repeat_interleave(16, 0)[:, :, None, None]
+        ref = _to_tokens(ref) + res.float()
+        xt, wp = _to_tokens(x), _pack_conv(w)
+        ys = [ops.gemm(xt, wp, **kw) for _ in range(3)]
+        out.append(_res("conv3x3[split-K] vs torch", ys[0], ref, 4e-3))
+        out.append(_res("conv3x3[split-K] bit-reproducible", ys[0], ys[2].float(), 0.0))
+        ops.GEMM_FLAGS = saved | 16
+        y_one = ops.gemm(xt, wp, **kw)
+        out.append(_res("conv3x3[split-K] vs unsplit kernel", ys[0], y_one.float(), 2e-3))
+        ops.GEMM_FLAGS = saved
+        # linear, long K, small M
+        a, wl = rnd(1024, 5120), rnd(1280, 5120, scale=1 / math.sqrt(5120))
+        y = ops.gemm(a, wl, bias=rnd(1280) * 0)
+        out.append(_res("gemm[split-K] M1024 N1280 K5120", y, _gemm_ref(a, wl), 4e-3))
+    finally:
+        ops.GEMM_FLAGS = saved
+    return out
+
+
 def _to_tokens(x):  # NCHW -> [(n h w), c]
     n, c, h, w = x.shape
     return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
@@ -632,4 +664,4 @@ def check_loops_mini():
     return out
 
 
-ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_conv, check_norms, check_attention, check_elementwise]
+ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_splitk, check_conv, check_norms, check_attention, check_elementwise]

@@ -29,6 +29,10 @@ def test_gemm_persistent_big_tile():
     _assert_all(gc.check_gemm_big())
 
 
+def test_gemm_split_k():
+    _assert_all(gc.check_gemm_splitk())
+
+
 @pytest.mark.parametrize("variant", ["reg", "glds", "naive"])
 def test_conv(variant):
     _assert_all(gc.check_conv((variant,)))

@@ -12,15 +12,19 @@ import sys
 
 
 def short(name: str) -> str:
+    """Readable kernel label: strip 'void' / argument lists; demangle the few _Z names rocprofv3 leaves mangled
+    (itanium: _Z<len><name>I<template args>E...) keeping integer / bool template arguments."""
+    import re
     name = name.replace("void ", "")
-    for pat in ("(GemmK)", "(AttnK)", "(AttnK, _Float16 const*)"):
-        name = name.replace(pat, "")
-    if name.startswith("_Z"):
-        import re
-        m = re.match(r"_Z\d+([A-Za-z0-9_]+?)(?:ILi|PK|P|i|x|f)", name)
-        if m:
-            name = m.group(1)
-    return name[:72]
+    name = re.sub(r"\((GemmK|AttnK)[^)]*\)$", "", name)
+    m = re.match(r"_Z(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        base = name[m.end():m.end() + n]
+        rest = name[m.end() + n:]
+        args = re.findall(r"L([ib])(\d+)E", rest.split("Ev")[0]) if rest.startswith("I") else []
+        name = base + ("<" + ", ".join(("true" if v == "1" else "false") if t == "b" else v for t, v in args) + ">" if args else "")
+    return name[:80]
 
 
 def main():
