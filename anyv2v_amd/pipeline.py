@@ -414,10 +414,22 @@ class I2VGenXLPipeline:
             traj = LatentTrajectory.load(ddim_inv_latents_path, device=device, timesteps=ts)
         t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, nb).contiguous()
         coef_table = self.scheduler.coefficient_table(ts, device)
+        # Exact work elimination (SURVEY A.5 probe "branches 1,2 of a B=3 forward equal a B=2 forward"): on a step that lies
+        # outside every injection schedule nothing reads the source branch, so the step runs on the [negative, editing]
+        # slots only.  Both engines share the `sample` storage, so they can alternate freely.
+        skip_src = cfg_on and nb == 3 and os.environ.get("ANYV2V_SRC_SKIP", "1") == "1"
+        eng_nosrc = None
         for i, t in enumerate(ts):
-            sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)
             pnp_utils.register_time(self, t)  # host-side only: python int, no device sync (:1143)
-            eng.step(t_table[i], coef_table[i], key=("pnp",) + pnp_utils.injection_state(self))
+            state = pnp_utils.injection_state(self)
+            if skip_src and not any(state):
+                if eng_nosrc is None:
+                    cond2 = {k: v[1:].contiguous() for k, v in cond.items()}
+                    eng_nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale, dup_slots=[0])
+                eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-nosrc",))
+                continue
+            sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)
+            eng.step(t_table[i], coef_table[i], key=("pnp",) + state)
         return self._finish(sample[nb - 1:nb].clone(), output_type, decode_chunk_size, return_dict)
 
     def _finish(self, latents, output_type, decode_chunk_size, return_dict):

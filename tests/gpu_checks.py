@@ -660,6 +660,27 @@ def check_loops_mini():
             res_graph = res.clone()
         elif DEV != "cpu":
             out.append(_res("pipeline graph replay == eager", res_graph.cpu(), res.cpu(), 1e-3))  # no atomics anywhere: deterministic
+        if graphs or DEV == "cpu":
+            # schedules that end early: the last steps lie outside every schedule, where the pipeline runs the
+            # [negative, editing] branches only (exact: nothing reads the source branch there)
+            def edit(skip):
+                os.environ["ANYV2V_SRC_SKIP"] = "1" if skip else "0"
+                pnp_utils.register_conv_injection(pipe, k(0.2))
+                pnp_utils.register_spatial_attention_pnp(pipe, k(0.4))
+                pnp_utils.register_temp_attention_pnp(pipe, k(0.5))
+                return pipe.sample_with_pnp(prompt_embeds=ehs[2:3].to(DEV), negative_prompt_embeds=ehs[1:2].to(DEV),
+                                            image_embeddings=ie[2:3].to(DEV), image_latents=il[2:3].to(DEV), height=hw * 8,
+                                            width=hw * 8, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=9.0,
+                                            target_fps=8, latents=traj[T].clone(), output_type="latent",
+                                            ddim_init_latents_t_idx=0, ddim_inv_latents_path=traj,
+                                            ddim_inv_prompt_embeds=ehs[:1].to(DEV), ddim_inv_image_embeddings=ie[:1].to(DEV),
+                                            ddim_inv_image_latents=il[:1].to(DEV)).frames
+            r_skip, r_full = edit(True), edit(False)
+            os.environ["ANYV2V_SRC_SKIP"] = "1"
+            pnp_oracle.init_pnp(oracle, n_steps, 0.2, 0.4, 0.5)
+            edited_o2 = pnp_oracle.pnp_loop(oracle, traj_o[T].clone(), traj_o, cond_all, n_steps, 9.0, t_idx=0)
+            out.append(_res(f"sample_with_pnp early-ending schedules [{tag}] vs oracle", r_skip.cpu(), edited_o2, 8e-2))
+            out.append(_res(f"source-branch skip on schedule-free steps == full B=3 steps [{tag}]", r_skip.cpu(), r_full.cpu(), 2e-2))  # not bitwise: GEMM tiling (and the CPU BLAS in the emulation) depends on M
     os.environ["ANYV2V_NO_GRAPH"] = "0"
     return out
 
