@@ -115,7 +115,7 @@ def check_gemm(variants=("reg", "glds", "naive")):
     out = []
     cases = [  # (M, N, K)
         (300, 320, 320), (1000, 512, 512), (257, 64, 128), (128, 4, 320), (4096, 1280, 1280), (77, 640, 1024),
-        # M >= 8192 -> the 256-row 3-stage LDS-DMA kernel (glds variant); ragged M / N tails, 1 and 2 K-tiles
+        # large M with ragged M / N tails, 1 and 2 K-tiles (128-row kernel; N = 320 / 640 may take the persistent one)
         (8300, 320, 320), (20001, 640, 1280), (9000, 512, 64), (8192, 4, 128), (12345, 160, 192),
     ]
     for var in variants:
@@ -139,7 +139,7 @@ def check_gemm(variants=("reg", "glds", "naive")):
         dst = torch.zeros(400, 640, dtype=torch.float16, device=DEV)
         ops.gemm(big[:, 320:640], w, out=dst[:, 320:], naive=naive)
         out.append(_res(f"gemm[{var}] strided views", dst[:, 320:], _gemm_ref(big[:, 320:640], w), 4e-3))
-        # GEGLU (small M -> 128-row kernel, large M -> 256-row kernel)
+        # GEGLU at small and large M
         for M in (333, 9001):
             dim, inner = 128, 512
             a = rnd(M, dim)
@@ -306,7 +306,7 @@ def check_conv(variants=("reg", "glds", "naive")):
         ref = F.conv3d(x5, w3.float(), b3.float(), padding=(1, 0, 0)) + x5
         ref = ref.squeeze(-1).permute(0, 2, 3, 1).reshape(B * Fr * HW, C)
         out.append(_res(f"temporal conv[{var}] +res", y, ref, 4e-3))
-        # large M (>= 8192 rows) -> 256-row 3-stage kernel: conv s1 two-source + temb + res, upsample, temporal
+        # large M (>= 8192 rows): conv s1 two-source + temb + res, upsample, temporal
         n, ci, c1, co, H, W = 6, 64, 128, 160, 40, 36
         x, x1 = rnd(n, ci, H, W), rnd(n, c1, H, W)
         w2, b = rnd(co, ci + c1, 3, 3, scale=1 / math.sqrt(9 * (ci + c1))), rnd(co)
