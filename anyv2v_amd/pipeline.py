@@ -51,7 +51,7 @@ class _StepEngine:
     step is overwritten by the caller with the source trajectory before each step.
     """
 
-    def __init__(self, pipe, sample, cond, b_unc, b_cond, guidance, dup_slots):
+    def __init__(self, pipe, sample, cond, b_unc, b_cond, guidance, dup_slots, shared_stem=False):
         self.pipe, self.unet = pipe, pipe.unet
         self.sample = sample
         self.cond = cond
@@ -67,6 +67,11 @@ class _StepEngine:
             unet.pack()
         self.ctx = unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
                                       cond["image_embeddings"])
+        # PnP edit batch [source, negative, editing]: slots 1 and 2 hold the same latent (dup_slots) and -- checked here,
+        # once -- the same image latents and fps, so the UNet may share their stem (exact; unet._forward_core)
+        self.ctx.shared_stem = bool(shared_stem and B == 3 and os.environ.get("ANYV2V_SHARED_STEM", "1") == "1"
+                                    and torch.equal(cond["image_latents"][1], cond["image_latents"][2])
+                                    and torch.equal(cond["fps"][1], cond["fps"][2]))
 
     def _body(self):
         vtok = self.unet._forward_core(self.ctx, self.sample)
@@ -406,7 +411,7 @@ class I2VGenXLPipeline:
         cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
                     image_embeddings=ie_all.contiguous())
         eng = _StepEngine(self, sample, cond, b_unc=1 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
-                          dup_slots=range(1, nb - 1))
+                          dup_slots=range(1, nb - 1), shared_stem=cfg_on)
         # source trajectory resident in HBM (in-memory hand-off from invert(), or read once from the reference's files)
         if isinstance(ddim_inv_latents_path, LatentTrajectory):
             traj = ddim_inv_latents_path

@@ -19,6 +19,8 @@ The attribute paths the reference hooks rely on (``pnp_utils.py:20-27,130,239,34
 """
 from __future__ import annotations
 
+import copy
+
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -153,6 +155,15 @@ class SiLU(nn.Module):
 class Identity(nn.Module):
     def forward(self, x, *a, **k):
         return x
+
+
+def expand_shared(x, full_ctx):
+    """Shared-stem batch [source, shared] -> full batch [source, negative, editing]: the last batch element is repeated."""
+    n = x.shape[0] // 2
+    out = torch.empty((3 * n, x.shape[1]), dtype=x.dtype, device=x.device)
+    out[:2 * n].copy_(x)
+    out[2 * n:].copy_(x[n:])
+    return out
 
 
 # ------------------------------------------------------------------------------------------- attention
@@ -304,9 +315,15 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def run(self, ctx, x, geom: Geom):
+    def run(self, ctx, x, geom: Geom, expand=None):
+        """``expand`` = (full ctx, full geometry): the block was entered with the shared-stem batch (see
+        ``I2VGenXLUNet._forward_core``); after self-attention the tokens are expanded to the full batch, where the
+        branches start to differ (cross-attention context)."""
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.attn1.run(ctx, h, geom, residual=x)
+        if expand is not None:
+            ctx, geom = expand
+            x = expand_shared(x, ctx)
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         kv = ctx.kv_for(self.attn2) if self.attn2.is_cross else None
         x = self.attn2.run(ctx, h, geom, residual=x, kv=kv)
@@ -323,14 +340,20 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
         self.proj_out = Linear(inner, in_channels)
 
-    def run(self, ctx, x, H, W):
+    def run(self, ctx, x, H, W, full_ctx=None):
+        """``full_ctx``: ``x`` holds the shared-stem batch of ``ctx``; the output has the full batch of ``full_ctx``."""
         HW = H * W
         h = ops.groupnorm(x, self.norm.weight, self.norm.bias, ctx.stats, HW, groups=self.norm.num_groups,
                           eps=self.norm.eps)
         h = ops.gemm(h, self.proj_in.weight, bias=self.proj_in.bias)
         geom = Geom("spatial", ctx.B, ctx.F, HW)
-        for blk in self.transformer_blocks:
-            h = blk.run(ctx, h, geom)
+        for i, blk in enumerate(self.transformer_blocks):
+            if full_ctx is not None and i == 0:
+                h = blk.run(ctx, h, geom, expand=(full_ctx, Geom("spatial", full_ctx.B, full_ctx.F, HW)))
+                ctx, geom = full_ctx, Geom("spatial", full_ctx.B, full_ctx.F, HW)
+                x = expand_shared(x, full_ctx)
+            else:
+                h = blk.run(ctx, h, geom)
         return ops.gemm(h, self.proj_out.weight, bias=self.proj_out.bias, residual=x)
 
 
@@ -455,13 +478,15 @@ class DownBlock3D(nn.Module):
                 self.temp_attentions.append(TransformerTemporalModel(heads, cfg.attention_head_dim, cout, g))
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_downsample else None
 
-    def run(self, ctx, x, H, W):
+    def run(self, ctx, x, H, W, stem_ctx=None):
+        """``stem_ctx``: ``x`` arrives with the shared-stem batch; layer 0 runs on it up to its first cross-attention."""
         outs = []
         for i in range(len(self.resnets)):
-            x = self.resnets[i].run(ctx, x, None, H, W)
-            x = self.temp_convs[i].run(ctx, x, H, W)
+            c = stem_ctx if (stem_ctx is not None and i == 0) else ctx
+            x = self.resnets[i].run(c, x, None, H, W)
+            x = self.temp_convs[i].run(c, x, H, W)
             if self.has_cross_attention:
-                x = self.attentions[i].run(ctx, x, H, W)
+                x = self.attentions[i].run(c, x, H, W, full_ctx=ctx if c is not ctx else None)
                 x = self.temp_attentions[i].run(ctx, x, H, W)
             outs.append(x)
         if self.downsamplers is not None:
@@ -710,6 +735,9 @@ class I2VGenXLUNet(nn.Module):
         ops.copy_cols(h, 0, ctx.xin, cfg.in_channels, cfg.in_channels)
         ctx.key = key
         ctx._keepalive = (ehs, image_latents, image_embeddings, fps)  # pin the tensors the key points at
+        ctx.shared_stem = False   # set by the pipeline for the PnP edit batch (see _forward_core)
+        ctx.stem_ctx = copy.copy(ctx)  # same buffers, batch 2: geometry of the shared stem
+        ctx.stem_ctx.B = 2
         self._ctx = ctx
         return ctx
 
@@ -737,14 +765,26 @@ class I2VGenXLUNet(nn.Module):
         emb = ops.gemm(te, self.time_embedding["linear_2"].weight, bias=self.time_embedding["linear_2"].bias,
                        residual=ctx.fps_emb)
         ctx.temb_all = ops.gemm(ops.silu(emb), self._w_temb_all, bias=self._b_temb_all)
-        # stem
-        ops.ncfhw_to_tokens(sample, ctx.xin, col0=0)
-        x = self.conv_in.tokens(ctx.xin, H, W)
-        x = self.transformer_in.run(ctx, x, H, W)
-        skips = [x]
+        ctx.stem_ctx.temb_all = ctx.temb_all
+        # stem.  With ``ctx.shared_stem`` (PnP edit batch [source, negative, editing]: the last two share latent, image
+        # latents, fps and timestep and differ only in the cross-attention context) everything up to the first
+        # cross-attention -- conv_in, transformer_in, the first ResNet / temporal-conv / self-attention of
+        # down_blocks[0] -- runs on [source, shared] and is expanded where the branches start to differ (exact).
+        stem = ctx.stem_ctx if (getattr(ctx, "shared_stem", False) and B == 3 and self.down_blocks[0].has_cross_attention) else None
+        if stem is not None:
+            T2 = 2 * F * H * W
+            ops.ncfhw_to_tokens(sample[:2], ctx.xin[:T2], col0=0)
+            x = self.conv_in.tokens(ctx.xin[:T2], H, W)
+            x = self.transformer_in.run(stem, x, H, W)
+            skips = [expand_shared(x, ctx)]
+        else:
+            ops.ncfhw_to_tokens(sample, ctx.xin, col0=0)
+            x = self.conv_in.tokens(ctx.xin, H, W)
+            x = self.transformer_in.run(ctx, x, H, W)
+            skips = [x]
         h_, w_ = H, W
-        for blk in self.down_blocks:
-            x, outs, h_, w_ = blk.run(ctx, x, h_, w_)
+        for bi, blk in enumerate(self.down_blocks):
+            x, outs, h_, w_ = blk.run(ctx, x, h_, w_, stem_ctx=stem if bi == 0 else None)
             skips.extend(outs)
         x = self.mid_block.run(ctx, x, h_, w_)
         for blk in self.up_blocks:

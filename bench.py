@@ -204,7 +204,7 @@ def main():
     cond3 = dict(encoder_hidden_states=ehs, fps=fps3, image_latents=il_all, image_embeddings=ie)
     pnp_utils.clear_time(pipe)   # inversion steps run hook-free (stage 1 of the reference has no hooks registered)
     e_inv = _StepEngine(pipe, s_inv, cond1, b_unc=-1, b_cond=0, guidance=1.0, dup_slots=[])
-    e_pnp = _StepEngine(pipe, s_pnp, cond3, b_unc=1, b_cond=2, guidance=9.0, dup_slots=[1])
+    e_pnp = _StepEngine(pipe, s_pnp, cond3, b_unc=1, b_cond=2, guidance=9.0, dup_slots=[1], shared_stem=True)
     tt_inv = torch.tensor(ts_inv, dtype=torch.float32, device=device)[:, None].contiguous()
     tt_pnp = torch.tensor(ts_pnp, dtype=torch.float32, device=device)[:, None].expand(-1, 3).contiguous()
     cf_inv, cf_pnp = inv.coefficient_table(ts_inv, device), fwd.coefficient_table(ts_pnp, device)

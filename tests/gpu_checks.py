@@ -605,6 +605,25 @@ def check_unet_vs_oracle(cfg_name="mini", B=3, Fr=4, hw=8, with_pnp=True, tol=3e
                 vo = oracle(inp16["sample"].float(), t, **kw_o)[0]
             vn = native(inp16["sample"].to(DEV), t, **kw_n)[0]
             out.append(_res(f"unet {cfg_name} B3 PnP step t={t} vs oracle", vn.cpu(), vo, tol))
+        # shared stem: with branches 1 and 2 fed the same latent / image latents (as the edit loop does), the stem up to
+        # the first cross-attention may run on [source, shared]; same result as the full three-branch stem
+        smp = inp16["sample"].clone()
+        smp[2] = smp[1]
+        il = inp16["image_latents"].clone()
+        il[2] = il[1]
+        kw_s = dict(kw_n, image_latents=il.to(DEV))
+        for t in (981, 1):
+            pnp_utils.register_time(pipe, t)
+            outs = []
+            for shared in (False, True):
+                ctx = native._prepare_clip(3, Fr, hw, hw, kw_s["encoder_hidden_states"], kw_s["fps"], kw_s["image_latents"],
+                                           kw_s["image_embeddings"])
+                ctx.t_buf.fill_(float(t))
+                ctx.shared_stem = shared
+                outs.append(native._forward_core(ctx, smp.to(DEV).contiguous()).clone())
+            out.append(_res(f"unet {cfg_name} shared stem == full stem (t={t}, inject={t == 981})", outs[1][:, :4], outs[0][:, :4].float(),
+                            0.0 if DEV != "cpu" else 2e-2))
+        pnp_utils.clear_time(pipe)
     return out
 
 
