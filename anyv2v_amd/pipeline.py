@@ -67,11 +67,11 @@ class _StepEngine:
             unet.pack()
         self.ctx = unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
                                       cond["image_embeddings"])
-        # PnP edit batch [source, negative, editing]: slots 1 and 2 hold the same latent (dup_slots) and -- checked here,
+        # CFG batches [.., negative, positive]: the last two slots hold the same latent (dup_slots) and -- checked here,
         # once -- the same image latents and fps, so the UNet may share their stem (exact; unet._forward_core)
-        self.ctx.shared_stem = bool(shared_stem and B == 3 and os.environ.get("ANYV2V_SHARED_STEM", "1") == "1"
-                                    and torch.equal(cond["image_latents"][1], cond["image_latents"][2])
-                                    and torch.equal(cond["fps"][1], cond["fps"][2]))
+        self.ctx.shared_stem = bool(shared_stem and B >= 2 and os.environ.get("ANYV2V_SHARED_STEM", "1") == "1"
+                                    and torch.equal(cond["image_latents"][B - 2], cond["image_latents"][B - 1])
+                                    and torch.equal(cond["fps"][B - 2], cond["fps"][B - 1]))
 
     def _body(self):
         vtok = self.unet._forward_core(self.ctx, self.sample)
@@ -352,7 +352,7 @@ class I2VGenXLPipeline:
         cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
                     image_embeddings=ie_all.contiguous())
         eng = _StepEngine(self, sample, cond, b_unc=0 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
-                          dup_slots=range(nb - 1))
+                          dup_slots=range(nb - 1), shared_stem=cfg_on)
         t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, nb).contiguous()
         coef_table = self.scheduler.coefficient_table(ts, device)
         for i, t in enumerate(ts):
@@ -430,7 +430,8 @@ class I2VGenXLPipeline:
             if skip_src and not any(state):
                 if eng_nosrc is None:
                     cond2 = {k: v[1:].contiguous() for k, v in cond.items()}
-                    eng_nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale, dup_slots=[0])
+                    eng_nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale, dup_slots=[0],
+                                            shared_stem=True)
                 eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-nosrc",))
                 continue
             sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)

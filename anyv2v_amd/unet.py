@@ -158,11 +158,13 @@ class Identity(nn.Module):
 
 
 def expand_shared(x, full_ctx):
-    """Shared-stem batch [source, shared] -> full batch [source, negative, editing]: the last batch element is repeated."""
-    n = x.shape[0] // 2
-    out = torch.empty((3 * n, x.shape[1]), dtype=x.dtype, device=x.device)
-    out[:2 * n].copy_(x)
-    out[2 * n:].copy_(x[n:])
+    """Shared-stem batch -> full batch: the last batch element is repeated ([source, shared] -> [source, negative,
+    editing] for the PnP edit; [shared] -> [negative, positive] for plain CFG sampling)."""
+    Bs = full_ctx.B - 1
+    n = x.shape[0] // Bs
+    out = torch.empty(((Bs + 1) * n, x.shape[1]), dtype=x.dtype, device=x.device)
+    out[:Bs * n].copy_(x)
+    out[Bs * n:].copy_(x[(Bs - 1) * n:])
     return out
 
 
@@ -736,8 +738,8 @@ class I2VGenXLUNet(nn.Module):
         ctx.key = key
         ctx._keepalive = (ehs, image_latents, image_embeddings, fps)  # pin the tensors the key points at
         ctx.shared_stem = False   # set by the pipeline for the PnP edit batch (see _forward_core)
-        ctx.stem_ctx = copy.copy(ctx)  # same buffers, batch 2: geometry of the shared stem
-        ctx.stem_ctx.B = 2
+        ctx.stem_ctx = copy.copy(ctx)  # same buffers, one batch element fewer: geometry of the shared stem
+        ctx.stem_ctx.B = max(B - 1, 1)
         self._ctx = ctx
         return ctx
 
@@ -766,14 +768,14 @@ class I2VGenXLUNet(nn.Module):
                        residual=ctx.fps_emb)
         ctx.temb_all = ops.gemm(ops.silu(emb), self._w_temb_all, bias=self._b_temb_all)
         ctx.stem_ctx.temb_all = ctx.temb_all
-        # stem.  With ``ctx.shared_stem`` (PnP edit batch [source, negative, editing]: the last two share latent, image
-        # latents, fps and timestep and differ only in the cross-attention context) everything up to the first
-        # cross-attention -- conv_in, transformer_in, the first ResNet / temporal-conv / self-attention of
-        # down_blocks[0] -- runs on [source, shared] and is expanded where the branches start to differ (exact).
-        stem = ctx.stem_ctx if (getattr(ctx, "shared_stem", False) and B == 3 and self.down_blocks[0].has_cross_attention) else None
+        # stem.  With ``ctx.shared_stem`` (CFG batches [.., negative, positive]: the last two share latent, image latents,
+        # fps and timestep and differ only in the cross-attention context) everything up to the first cross-attention
+        # -- conv_in, transformer_in, the first ResNet / temporal-conv / self-attention of down_blocks[0] -- runs
+        # once for the pair and is expanded where the branches start to differ (exact).
+        stem = ctx.stem_ctx if (getattr(ctx, "shared_stem", False) and B >= 2 and self.down_blocks[0].has_cross_attention) else None
         if stem is not None:
-            T2 = 2 * F * H * W
-            ops.ncfhw_to_tokens(sample[:2], ctx.xin[:T2], col0=0)
+            T2 = (B - 1) * F * H * W
+            ops.ncfhw_to_tokens(sample[:B - 1], ctx.xin[:T2], col0=0)
             x = self.conv_in.tokens(ctx.xin[:T2], H, W)
             x = self.transformer_in.run(stem, x, H, W)
             skips = [expand_shared(x, ctx)]

@@ -701,6 +701,24 @@ def check_loops_mini():
             out.append(_res(f"sample_with_pnp early-ending schedules [{tag}] vs oracle", r_skip.cpu(), edited_o2, 8e-2))
             out.append(_res(f"source-branch skip on schedule-free steps == full B=3 steps [{tag}]", r_skip.cpu(), r_full.cpu(), 2e-2))  # not bitwise: GEMM tiling (and the CPU BLAS in the emulation) depends on M
     os.environ["ANYV2V_NO_GRAPH"] = "0"
+    # A3: plain CFG sampling (DDIM reconstruction), B = 2 [negative, positive]; shared stem on / off
+    cond2 = dict(fps=torch.tensor([8] * 2), image_latents=torch.cat([il[2:3], il[2:3]]).float(),
+                 image_embeddings=torch.cat([torch.zeros_like(ie[2:3]), ie[2:3]]).float(),
+                 encoder_hidden_states=torch.cat([ehs[1:2], ehs[2:3]]).float())
+    _, oracle_plain, _ = build_pair("mini", 1234)  # same weights, no hooks registered
+    rec_o = pnp_oracle.sample_loop(oracle_plain, traj_o[T].clone(), cond2, n_steps, 9.0, t_idx=0)
+    recs = []
+    for shared in ("1", "0"):
+        os.environ["ANYV2V_SHARED_STEM"] = shared
+        pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMScheduler())
+        pipe._device = torch.device(DEV)
+        recs.append(pipe(prompt_embeds=ehs[2:3].to(DEV), negative_prompt_embeds=ehs[1:2].to(DEV), image_embeddings=ie[2:3].to(DEV),
+                         image_latents=il[2:3].to(DEV), height=hw * 8, width=hw * 8, num_frames=Fr, num_inference_steps=n_steps,
+                         guidance_scale=9.0, target_fps=8, latents=traj_o[T].clone().half().to(DEV), output_type="latent",
+                         ddim_init_latents_t_idx=0).frames)
+    os.environ["ANYV2V_SHARED_STEM"] = "1"
+    out.append(_res(f"pipeline.__call__ (CFG sampling) {n_steps} steps vs oracle", recs[0].cpu(), rec_o, 8e-2))
+    out.append(_res("CFG sampling: shared stem == separate stems", recs[0].cpu(), recs[1].cpu().float(), 0.0 if DEV != "cpu" else 2e-2))
     return out
 
 
