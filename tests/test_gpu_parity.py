@@ -66,3 +66,10 @@ def test_pipeline_loops_vs_oracle_and_graph_equals_eager():
 def test_unet_full_config1_vs_oracle():
     """BASELINE config 1 (1 clip x 8f x 256x256), full 1.42 B-parameter model, HIP fp16 vs CPU fp32 oracle."""
     _assert_all(gc.check_unet_vs_oracle("full", 1, 8, 32, with_pnp=False, tol=5e-2))
+
+
+def test_unet_mini_long_clips():
+    """BASELINE config 5 geometry in miniature: 128 frames (temporal attention through the flash kernel with a frame
+    stride, S = 128 > 16) with PnP hooks, and a 40-frame clip."""
+    _assert_all(gc.check_unet_vs_oracle("mini", 3, 128, 8))
+    _assert_all(gc.check_unet_vs_oracle("mini", 1, 40, 16, with_pnp=False))
