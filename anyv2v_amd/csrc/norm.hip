@@ -4,8 +4,10 @@
 // i2vgen-xl/pnp_utils.py:48,104), Transformer2DModel.norm, TemporalConvLayer / TransformerTemporalModel.norm
 // (5-D: statistics over all frames of a clip) and conv_norm_out.  The input may be the channel concat [X0 | X1]
 // (skip connection of the up blocks, consisti2v/.../videoldm_unet_blocks.py:721-745) without materialising it.
-// Three kernels, no atomics (bit-reproducible): (1) partial sums per (stat group, row chunk, channel group) reduced
-// through LDS, (2) chunk reduction -> (mean, rstd), (3) normalise + affine (+ SiLU) -> fp16.
+// Two kernels, no atomics (bit-reproducible): (1) partial sums per (stat group, row chunk, channel group) reduced
+// through LDS; (2) normalise + affine (+ SiLU) -> fp16, each block first folding the chunk sums of its stat group into
+// (mean, rstd) in a fixed order (a separate 7-us finalize launch per GroupNorm used to cost 2 % of the step; a
+// last-arriver finalize would need device-scope fences, which flush the per-XCD L2 on gfx950).
 // Algorithmic traffic: 2 reads + 1 write of X.
 #include "common.h"
 
@@ -76,49 +78,47 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ X0, const half_t* _
     }
 }
 
-// (2) reduce the chunks -> (mean, rstd) per (stat group, channel group)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mr, int nchunks, int G,
-                                   float inv_cnt, float eps) {
-    __shared__ float rs[256], rq[256];
-    const int sg = blockIdx.x, tid = threadIdx.x;
-    const int parts = 256 / G;  // G <= 64
-    const int g = tid % G, part = tid / G;
-    float as = 0.f, aq = 0.f;
-    if (part < parts)
-        for (int c = part; c < nchunks; c += parts) {
-            const float* src = partial + (((size_t)sg * nchunks + c) * G + g) * 2;
-            as += src[0];
-            aq += src[1];
-        }
-    rs[tid] = as;
-    rq[tid] = aq;
-    __syncthreads();
-    if (tid < G) {
-        float s = 0.f, q = 0.f;
-        for (int p2 = 0; p2 < parts; ++p2) {
-            s += rs[p2 * G + tid];
-            q += rq[p2 * G + tid];
-        }
-        const float mean = s * inv_cnt;
-        const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
-        mr[((size_t)sg * G + tid) * 2 + 0] = mean;
-        mr[((size_t)sg * G + tid) * 2 + 1] = rsqrtf(var + eps);
-    }
-}
-
-// (3) normalise + affine (+ SiLU)
-__global__ void gn_apply_kernel(const half_t* __restrict__ X0, const half_t* __restrict__ X1, int C0, int C1,
-                                half_t* __restrict__ Y, const half_t* __restrict__ gamma,
-                                const half_t* __restrict__ beta, const float* __restrict__ mr, long long M,
-                                int rows_per_group, int G, int silu) {
+// (2) normalise + affine (+ SiLU); grid = (blocks per stat group, stat groups)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ X0, const half_t* __restrict__ X1, int C0,
+                                                       int C1, half_t* __restrict__ Y, const half_t* __restrict__ gamma,
+                                                       const half_t* __restrict__ beta, const float* __restrict__ partial,
+                                                       int nchunks, float inv_cnt, float eps, int rows_per_group, int G,
+                                                       int silu) {
+    __shared__ float rs[256], rq[256], smean[64], srstd[64];
     const int C = C0 + C1, V = C >> 3, cpg = C / G;
-    const long long total = M * V;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const long long row = idx / V;
-        const int v = (int)(idx - row * V);
+    const int sg = blockIdx.y, tid = threadIdx.x;
+    {   // statistics of this stat group: same order of additions in every block -> identical in all of them
+        const int parts = 256 / G;  // G <= 64
+        const int g = tid % G, part = tid / G;
+        float as = 0.f, aq = 0.f;
+        if (part < parts)
+            for (int c = part; c < nchunks; c += parts) {
+                const float* src = partial + (((size_t)sg * nchunks + c) * G + g) * 2;
+                as += src[0];
+                aq += src[1];
+            }
+        rs[tid] = as;
+        rq[tid] = aq;
+        __syncthreads();
+        if (tid < G) {
+            float s = 0.f, q = 0.f;
+            for (int p2 = 0; p2 < parts; ++p2) {
+                s += rs[p2 * G + tid];
+                q += rq[p2 * G + tid];
+            }
+            const float mean = s * inv_cnt;
+            const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
+            smean[tid] = mean;
+            srstd[tid] = rsqrtf(var + eps);
+        }
+        __syncthreads();
+    }
+    const long long total = (long long)rows_per_group * V;  // 16-byte vectors of this stat group
+    const long long row0 = (long long)sg * rows_per_group;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + tid; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = row0 + idx / V;
+        const int v = (int)(idx % V);
         const int c0 = v * 8;
-        const int sg = (int)(row / rows_per_group);
         h8 x;
         if (c0 < C0)
             x = *(const h8*)(X0 + row * C0 + c0);
@@ -127,17 +127,10 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ X0, const half_t* __r
         const h8 ga = *(const h8*)(gamma + c0);
         const h8 be = *(const h8*)(beta + c0);
         h8 y;
-        int g = -1;
-        float mean = 0.f, rstd = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ge = (c0 + e) / cpg;
-            if (ge != g) {
-                g = ge;
-                mean = mr[((size_t)sg * G + g) * 2 + 0];
-                rstd = mr[((size_t)sg * G + g) * 2 + 1];
-            }
-            float f = ((float)x[e] - mean) * rstd * (float)ga[e] + (float)be[e];
+            float f = ((float)x[e] - smean[ge]) * srstd[ge] * (float)ga[e] + (float)be[e];
             if (silu) f = av_silu(f);
             y[e] = (half_t)f;
         }
@@ -177,20 +170,21 @@ extern "C" int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, 
     if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
     const int rows_chunk = (rows_per_group + nchunks - 1) / nchunks;
     nchunks = (rows_per_group + rows_chunk - 1) / rows_chunk;
-    float* mr = stats;                              // [nsg][G][2] (mean, rstd)
-    float* partial = stats + (size_t)nsg * G * 2;   // [nsg][nchunks][G][2]
+    float* partial = stats;   // [nsg][nchunks][G][2]
     const size_t lds = (size_t)rpb * C * 2 * sizeof(float);
     AV_CHECK(lds <= 64 * 1024, "groupnorm: LDS reduction buffer too large");
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nsg, nchunks), dim3(threads), lds, s, (const half_t*)X0,
                        (const half_t*)X1, C0, C1, partial, rows_per_group, G, rows_chunk, rpb, nchunks);
     const float inv_cnt = 1.0f / ((float)rows_per_group * (float)(C / G));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nsg), dim3(256), 0, s, (const float*)partial, mr, nchunks, G, inv_cnt, eps);
-    const long long total = (long long)M * V;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const half_t*)X0, (const half_t*)X1,
-                       C0, C1, (half_t*)Y, (const half_t*)gamma, (const half_t*)beta, (const float*)mr,
-                       (long long)M, rows_per_group, G, silu);
+    // ~2048 blocks in total, each at least 8 vectors per thread where the stat group is large enough
+    const long long vec_sg = (long long)rows_per_group * V;
+    long long bps = (2048 + nsg - 1) / nsg;
+    const long long max_bps = (vec_sg + 256 * 8 - 1) / (256 * 8);
+    if (bps > max_bps) bps = max_bps;
+    if (bps < 1) bps = 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)bps, (unsigned)nsg), dim3(256), 0, s, (const half_t*)X0,
+                       (const half_t*)X1, C0, C1, (half_t*)Y, (const half_t*)gamma, (const half_t*)beta,
+                       (const float*)partial, nchunks, inv_cnt, eps, rows_per_group, G, silu);
     return av_launch_status("groupnorm");
 }
 
