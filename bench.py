@@ -97,7 +97,7 @@ def roofline_conv(device):
     ms = measure_kernel(fn)
     flops = 2.0 * N * H * H * 9 * C * C
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_mfma_kernel (conv3x3 320->320 @64x64, N=48)", "achieved": round(ach, 2),
+    return {"bound": "mfma", "kernel": "gemm_big_kernel<3,false,conv2d> (conv3x3 320->320 @64x64, N=48; persistent 192x320 tiles)", "achieved": round(ach, 2),
             "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
             "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
 
