@@ -20,6 +20,7 @@ The attribute paths the reference hooks rely on (``pnp_utils.py:20-27,130,239,34
 from __future__ import annotations
 
 import copy
+import os
 
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -197,8 +198,17 @@ class HipAttnProcessor:
         T = h.shape[0]
         o = torch.empty((T, Cq), dtype=torch.float16, device=h.device)
         if kv is None:  # self-attention
-            qkv = ops.gemm(h, attn._w_qkv)
             inject = pnp_on(self.t, self.injection_schedule)
+            if inject and T % 3 == 0 and _V_ONLY:
+                # Q and K of the negative / editing branches are never read on an injection step (they alias the source
+                # branch's): project Q,K,V for the source third and only V for the other two thirds (exact, 44 % fewer
+                # FLOPs and stores in this projection)
+                Ts = T // 3
+                qkv = torch.empty((T, 3 * Cq), dtype=torch.float16, device=h.device)
+                ops.gemm(h[:Ts], attn._w_qkv, out=qkv[:Ts])
+                ops.gemm(h[Ts:], attn._w_qkv[2 * Cq:], out=qkv[Ts:, 2 * Cq:])
+            else:
+                qkv = ops.gemm(h, attn._w_qkv)
             qk_mod = geom.batch // 3 if inject else 0
             ops.attention(qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], o, batch=geom.batch, heads=attn.heads,
                           Sq=geom.S, Sk=geom.S, inner=geom.inner, q_strides=geom.strides, kv_strides=geom.strides,
@@ -580,6 +590,7 @@ class _ConfigView:
         self.cross_attention_dim = cfg.cross_attention_dim
 
 
+_V_ONLY = os.environ.get("ANYV2V_VONLY", "1") == "1"
 PAD_CIN = 64  # conv_in input channels (8) are zero-padded to one MFMA K-tile
 
 
