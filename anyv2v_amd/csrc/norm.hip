@@ -113,11 +113,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
         }
         __syncthreads();
     }
-    const long long total = (long long)rows_per_group * V;  // 16-byte vectors of this stat group
+    const unsigned total = (unsigned)rows_per_group * (unsigned)V;  // 16-byte vectors of this stat group (< 2^31, checked on the host)
     const long long row0 = (long long)sg * rows_per_group;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + tid; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const long long row = row0 + idx / V;
-        const int v = (int)(idx % V);
+    for (unsigned idx = blockIdx.x * blockDim.x + tid; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned r = idx / (unsigned)V;  // 32-bit: the 64-bit division used here before cost more than the loads
+        const long long row = row0 + r;
+        const int v = (int)(idx - r * (unsigned)V);
         const int c0 = v * 8;
         h8 x;
         if (c0 < C0)
@@ -127,10 +128,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
         const h8 ga = *(const h8*)(gamma + c0);
         const h8 be = *(const h8*)(beta + c0);
         h8 y;
+        int ge = c0 / cpg, rem = c0 - ge * cpg;  // one division per vector; the group index then only steps forward
+        float mean = smean[ge], rstd = srstd[ge];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int ge = (c0 + e) / cpg;
-            float f = ((float)x[e] - smean[ge]) * srstd[ge] * (float)ga[e] + (float)be[e];
+            if (rem == cpg) {
+                rem = 0;
+                ++ge;
+                mean = smean[ge];
+                rstd = srstd[ge];
+            }
+            ++rem;
+            float f = ((float)x[e] - mean) * rstd * (float)ga[e] + (float)be[e];
             if (silu) f = av_silu(f);
             y[e] = (half_t)f;
         }
@@ -178,6 +187,7 @@ extern "C" int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, 
     const float inv_cnt = 1.0f / ((float)rows_per_group * (float)(C / G));
     // ~2048 blocks in total, each at least 8 vectors per thread where the stat group is large enough
     const long long vec_sg = (long long)rows_per_group * V;
+    AV_CHECK(vec_sg < (1ll << 31), "groupnorm: stat group too large (%lld vectors)", vec_sg);
     long long bps = (2048 + nsg - 1) / nsg;
     const long long max_bps = (vec_sg + 256 * 8 - 1) / (256 * 8);
     if (bps > max_bps) bps = max_bps;
