@@ -722,4 +722,60 @@ def check_loops_mini():
     return out
 
 
-ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_splitk, check_conv, check_norms, check_attention, check_elementwise]
+def check_full_size_properties():
+    """BASELINE config 3 sizes (T = 196608 tokens, N = 48 images, S = 4096), where the CPU oracle is far too slow:
+    size-independent identities of each kernel family."""
+    out = []
+    T, C = 196608, 320
+    g = torch.Generator(device="cpu").manual_seed(7)
+    r = lambda *sh, scale=1.0: (torch.randn(*sh, generator=g) * scale).to(torch.float16).to(DEV)
+    # attention: softmax rows sum to one -> with V == 1 every output is exactly 1; key order does not matter
+    N, h, S = 48, 5, 4096
+    qk = r(N * S, 2 * C)
+    ones = torch.ones(N * S, C, dtype=torch.float16, device=DEV)
+    o = torch.empty(N * S, C, dtype=torch.float16, device=DEV)
+    kw = dict(batch=N, heads=h, Sq=S, Sk=S, inner=1, q_strides=(S, 0, 1), kv_strides=(S, 0, 1))
+    ops.attention(qk[:, :C], qk[:, C:], ones, o, **kw)
+    out.append(_res("attention full size: V == 1 -> O == 1 (plain kernel)", o, ones.float(), 2e-3))
+    ops.attention(qk[:, :C], qk[:, C:], ones, o, qk_mod=N // 3, **kw)
+    out.append(_res("attention full size: V == 1 -> O == 1 (shared-softmax PnP kernel)", o, ones.float(), 2e-3))
+    v = r(N * S, C)
+    o1 = torch.empty_like(o)
+    ops.attention(qk[:, :C], qk[:, C:], v, o1, **kw)
+    perm = torch.randperm(S, generator=g).to(DEV)
+    idx = (torch.arange(N, device=DEV)[:, None] * S + perm[None, :]).reshape(-1)
+    o2 = torch.empty_like(o)
+    ops.attention(qk[:, :C], qk[idx, C:].contiguous(), v[idx].contiguous(), o2, **kw)
+    out.append(_res("attention full size: invariant under a permutation of the keys", o2, o1.float(), 4e-3))
+    # GEMM / conv linearity in the activations (fp32 accumulate, one rounding): f(a) + f(b) ~= f(a + b) with exact inputs
+    a = (torch.randint(-8, 9, (T, C), generator=g).float() / 8).to(torch.float16).to(DEV)   # sums exact in fp16
+    b = (torch.randint(-8, 9, (T, C), generator=g).float() / 8).to(torch.float16).to(DEV)
+    w = (torch.randint(-4, 5, (C, C), generator=g).float() / 64).to(torch.float16).to(DEV)
+    ya, yb, yab = ops.gemm(a, w), ops.gemm(b, w), ops.gemm((a + b), w)
+    out.append(_res("linear 320->320 full size: f(a) + f(b) == f(a + b) on exactly representable data", yab, ya.float() + yb.float(), 1e-3))
+    w9 = (torch.randint(-2, 3, (C, 9 * C), generator=g).float() / 64).to(torch.float16).to(DEV)
+    cv = dict(mode=ops.MODE_CONV2D, conv=(64, 64, 64, 64, 1, 0))
+    ca, cb, cab = ops.gemm(a, w9, **cv), ops.gemm(b, w9, **cv), ops.gemm((a + b), w9, **cv)
+    out.append(_res("conv3x3 320->320 @64x64 full size: additive in the input", cab, ca.float() + cb.float(), 2e-3))
+    # conv: shifting every image by one pixel row shifts the output (interior rows), i.e. the gather indexes correctly
+    x4 = a.view(48, 64, 64, C)
+    xs = torch.zeros_like(x4)
+    xs[:, 1:] = x4[:, :-1]
+    cs = ops.gemm(xs.reshape(T, C).contiguous(), w9, **cv).view(48, 64, 64, C)
+    out.append(_res("conv3x3 full size: translation equivariance (rows 2..62)", cs[:, 3:62], ca.view(48, 64, 64, C)[:, 2:61].float(), 1e-3))
+    # GroupNorm: per (frame, group) the normalised output has mean 0 / variance 1; LayerNorm likewise per row
+    x = r(T, C) * 3 + 1
+    stats = torch.empty(ops.gn_scratch_floats(48, 1), dtype=torch.float32, device=DEV)
+    one, zero = torch.ones(C, dtype=torch.float16, device=DEV), torch.zeros(C, dtype=torch.float16, device=DEV)
+    y = ops.groupnorm(x, one, zero, stats, 4096, groups=32, eps=1e-5).float().view(48, 4096, 32, 10)
+    m, v_ = y.mean((1, 3)), y.var((1, 3), unbiased=False)
+    out.append(_res("groupnorm full size: group means == 0", m + 1, torch.ones_like(m), 2e-3))
+    out.append(_res("groupnorm full size: group variances == 1", v_, torch.ones_like(v_), 4e-3))
+    yl = ops.layernorm(x, one, zero, 1e-5).float()
+    out.append(_res("layernorm full size: row means == 0", yl.mean(1) + 1, torch.ones(T, device=DEV), 2e-3))
+    out.append(_res("layernorm full size: row variances == 1", yl.var(1, unbiased=False), torch.ones(T, device=DEV), 4e-3))
+    return out
+
+
+ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_splitk, check_conv, check_norms, check_attention, check_elementwise,
+                     check_full_size_properties]

@@ -73,3 +73,8 @@ def test_unet_mini_long_clips():
     stride, S = 128 > 16) with PnP hooks, and a 40-frame clip."""
     _assert_all(gc.check_unet_vs_oracle("mini", 3, 128, 8))
     _assert_all(gc.check_unet_vs_oracle("mini", 1, 40, 16, with_pnp=False))
+
+
+def test_full_size_properties():
+    """Size-independent identities at the BASELINE config 3 sizes (the oracle cannot run there in test time)."""
+    _assert_all(gc.check_full_size_properties())
