@@ -872,7 +872,10 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     // split-K for launches that cannot fill the chip (512 block slots) and have a long K loop (the 8x8 / 16x16-level
     // convs: 64..256 tiles x 180..360 K-tiles); needs the caller's fp32 workspace
     const int nk = k.taps * (k.nt0 + k.nt1);
-    if (glds && !geglu && !(d->flags & 16) && d->workspace != nullptr && tiles < 384 && nk >= 16 && d->N % 8 == 0) {
+    // (measured, tools history in DESIGN.md: with 20 K-tiles the second pass costs more than the idle CUs; with 60 it
+    //  pays only when fewer than a quarter of the block slots would be busy; from ~72 K-tiles on it always pays)
+    const bool split_pays = (tiles <= 128 && nk >= 32) || nk >= 72;
+    if (glds && !geglu && !(d->flags & 16) && d->workspace != nullptr && tiles < 384 && split_pays && d->N % 8 == 0) {
         int splits = (512 + tiles - 1) / tiles;
         if (splits > 8) splits = 8;
         if (splits > nk / 8) splits = nk / 8;
