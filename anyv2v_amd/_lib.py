@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("lda0", C.c_int32), ("lda1", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
         ("ldrv", C.c_int32), ("rowvec_div", C.c_int32), ("mode", C.c_int32),
         ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
-        ("stride", C.c_int32), ("up", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32),
+        ("stride", C.c_int32), ("up", C.c_int32), ("asym", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32),
         ("act", C.c_int32), ("flags", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
@@ -55,6 +55,7 @@ SYMBOLS = {
     "anyv2v_layernorm_f16": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _VP]),
     "anyv2v_attention_f16": (C.c_int, [C.POINTER(AttnDesc), _VP]),
     "anyv2v_attention_small_f16": (C.c_int, [C.POINTER(AttnDesc), _I32, _VP]),
+    "anyv2v_softmax_rows_f32_f16": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _F32, _VP]),
     "anyv2v_silu_f16": (C.c_int, [_VP, _VP, _I64, _VP]),
     "anyv2v_add_f16": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
     "anyv2v_timestep_embedding_f16": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),

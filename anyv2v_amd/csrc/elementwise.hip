@@ -126,6 +126,45 @@ static inline unsigned nblk(long long n, int t, long long cap = 65535) {
     return (unsigned)b;
 }
 
+// Row softmax of fp32 logits -> fp16 probabilities: P[r, :] = softmax(scale * S[r, :]).  One block per row, the row
+// lives in registers (cols <= 256 * 32).  Used by the single 512-wide attention head of the AutoencoderKL mid block
+// (logits come from anyv2v_gemm_f16 with act = 4).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int lds_, half_t* __restrict__ P,
+                                                           int ldp, int cols, float scale_log2) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* src = S + (size_t)row * lds_;
+    float v[32];
+    float mx = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = i * 256 + tid;
+        v[i] = c < cols ? src[c] * scale_log2 : -1e30f;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        v[i] = i * 256 + tid < cols ? __builtin_amdgcn_exp2f(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[w] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    half_t* dst = P + (size_t)row * ldp;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = i * 256 + tid;
+        if (c < cols) dst[c] = (half_t)(v[i] * inv);
+    }
+}
+
 extern "C" int anyv2v_silu_f16(const void* X, void* Y, int64_t n, void* stream) {
     AV_CHECK(X && Y && n > 0, "silu: bad arguments");
     hipLaunchKernelGGL(silu_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const half_t*)X,
@@ -179,6 +218,14 @@ extern "C" int anyv2v_copy_cols_f16(const void* X, int32_t ldx, int32_t xcol0, v
     hipLaunchKernelGGL(copy_cols_kernel, dim3(nblk(M * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)X, ldx, xcol0, (half_t*)Y, ldy, ycol0, (long long)M, C);
     return av_launch_status("copy_cols");
+}
+
+extern "C" int anyv2v_softmax_rows_f32_f16(const float* S, int32_t lds_, void* P, int32_t ldp, int32_t rows, int32_t cols,
+                                           float scale, void* stream) {
+    AV_CHECK(S && P && rows > 0 && cols > 0 && cols <= 8192 && lds_ >= cols && ldp >= cols, "softmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, lds_, (half_t*)P, ldp,
+                       cols, scale * 1.4426950408889634f);
+    return av_launch_status("softmax_rows");
 }
 
 extern "C" int anyv2v_cfg_ddim_step_f16(const void* Vtok, int32_t ldv, int32_t b_unc, int32_t b_cond, float guidance,

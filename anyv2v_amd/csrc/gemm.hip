@@ -19,7 +19,7 @@
 #include "common.h"
 
 enum { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_TEMPORAL = 2 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3, ACT_F32OUT = 4 };
 
 __device__ __attribute__((aligned(256))) half_t g_zero_line[128];  // 256 B of zeros: source for padded taps
 
@@ -34,6 +34,7 @@ struct GemmK {
     const half_t* zeros;
     int M, N, C0, C1, lda0, lda1, ldc, ldr, ldrv, rowvec_div;
     int mode, Hi, Wi, Ho, Wo, stride, up, F, HW, act;
+    int pad_lo;  // conv2d: zero rows / columns before the first pixel (1 = "same" 3x3; 0 = pad only right / bottom)
     int taps, Ktot, nt0, nt1, tilesN;
     int vec_epi;  // bias / rowvec may be read as 8-byte vectors
     int splits;   // split-K factor (128-row kernel only): each split writes an fp32 partial tile, reduced afterwards
@@ -55,8 +56,8 @@ __device__ __forceinline__ RowInfo make_row(const GemmK& p, int m) {
         const int img = m / hw, rem = m - img * hw;
         const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
         r.base = img * p.Hi * p.Wi;
-        r.y = ok ? yo * p.stride - 1 : -(1 << 28);
-        r.x = xo * p.stride - 1;
+        r.y = ok ? yo * p.stride - p.pad_lo : -(1 << 28);
+        r.x = xo * p.stride - p.pad_lo;
     } else if constexpr (MODE == MODE_TEMPORAL) {
         r.base = m;
         r.y = ok ? (m / p.HW) % p.F : -(1 << 28);
@@ -130,6 +131,27 @@ __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char*
             for (int nf = 0; nf < NF; ++nf) {
                 const int n = n_blk + wc * NF * 16 + nf * 16 + 4 * lq;
                 if (m < p.M && n + 4 <= p.N) *(f4*)(dst + (size_t)m * p.N + n) = acc[mf][nf];
+            }
+        }
+        return;
+    }
+    if (p.act == ACT_F32OUT) {  // raw fp32 result (+bias): attention logits of the VAE's 512-wide single head
+        float* dst = (float*)p.C;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int m = m_blk + wr * 64 + mf * 16 + l15;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int n = n_blk + wc * NF * 16 + nf * 16 + 4 * lq;
+                if (m < p.M && n + 4 <= p.N) {
+                    f4 v = acc[mf][nf];
+                    if (p.bias != nullptr) {
+                        const h4 b = *(const h4*)(p.bias + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+                    }
+                    *(f4*)(dst + (size_t)m * p.ldc + n) = v;
+                }
             }
         }
         return;
@@ -769,6 +791,10 @@ __global__ void gemm_naive_kernel(const GemmK p) {
         else if (p.act == ACT_GELU)
             v = av_gelu(v);
     }
+    if (p.act == ACT_F32OUT) {
+        ((float*)p.C)[(size_t)m * p.ldc + j] = v;
+        return;
+    }
     if (p.R != nullptr) v = (float)(half_t)v + (float)p.R[(size_t)m * p.ldr + j];
     p.C[(size_t)m * p.ldc + j] = (half_t)v;
 }
@@ -875,7 +901,8 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     // (measured, tools history in DESIGN.md: with 20 K-tiles the second pass costs more than the idle CUs; with 60 it
     //  pays only when fewer than a quarter of the block slots would be busy; from ~72 K-tiles on it always pays)
     const bool split_pays = (tiles <= 128 && nk >= 32) || nk >= 72;
-    if (glds && !geglu && !(d->flags & 16) && d->workspace != nullptr && tiles < 384 && split_pays && d->N % 8 == 0) {
+    if (glds && !geglu && d->act != ACT_F32OUT && !(d->flags & 16) && d->workspace != nullptr && tiles < 384 && split_pays &&
+        d->N % 8 == 0) {
         int splits = (512 + tiles - 1) / tiles;
         if (splits > 8) splits = 8;
         if (splits > nk / 8) splits = nk / 8;
@@ -932,7 +959,10 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     AV_CHECK(d->A0 && d->W && d->C, "gemm: null A0/W/C");
     AV_CHECK(d->M > 0 && d->N > 0 && d->C0 > 0 && d->C1 >= 0, "gemm: bad M/N/C0/C1 (%d %d %d %d)", d->M, d->N, d->C0, d->C1);
     AV_CHECK(d->mode >= 0 && d->mode <= 2, "gemm: bad mode %d", d->mode);
-    AV_CHECK(d->act >= 0 && d->act <= 3, "gemm: bad act %d", d->act);
+    AV_CHECK(d->act >= 0 && d->act <= 4, "gemm: bad act %d", d->act);
+    AV_CHECK(d->act != ACT_F32OUT || (d->rowvec == nullptr && d->R == nullptr && d->N % 4 == 0 && d->ldc % 4 == 0),
+             "gemm: fp32 output supports bias only and needs N, ldc multiples of 4");
+    AV_CHECK(d->asym == 0 || d->asym == 1, "gemm: asym must be 0 or 1");
     AV_CHECK(d->C1 == 0 || d->A1 != nullptr, "gemm: C1 > 0 but A1 is null");
     AV_CHECK(d->rowvec == nullptr || d->rowvec_div > 0, "gemm: rowvec needs rowvec_div > 0");
     if (d->mode == MODE_CONV2D) {
@@ -963,6 +993,7 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     k.rowvec_div = d->rowvec_div > 0 ? d->rowvec_div : 1;
     k.mode = d->mode; k.Hi = d->Hi; k.Wi = d->Wi; k.Ho = d->Ho; k.Wo = d->Wo; k.stride = d->stride; k.up = d->up;
     k.F = d->F; k.HW = d->HW; k.act = d->act;
+    k.pad_lo = d->asym ? 0 : 1;
     k.taps = d->mode == MODE_LINEAR ? 1 : (d->mode == MODE_CONV2D ? 9 : 3);
     k.Ktot = k.taps * (d->C0 + d->C1);
     k.nt0 = d->C0 / 64;

@@ -2,9 +2,11 @@
 
 The reference wires ``AutoencoderKL`` / ``CLIPTextModel`` / ``CLIPVisionModelWithProjection`` from the hub repo
 ``ali-vilab/i2vgen-xl`` (``pipeline_i2vgen_xl.py:155-178``).  Neither the weights nor ``diffusers`` exist offline, and
-these once-per-clip stages are outside the HIP hot path of this round.  The pipeline only needs four small
-interfaces, defined here, and ships *synthetic* implementations (deterministic, weight-free, NOT the real models) so
-that the CLIs, file formats and multi-GPU sharding can be exercised end to end:
+these once-per-clip stages are outside the HIP hot path.  The pipeline only needs four small interfaces, defined here.
+``NativeVAE`` is the real AutoencoderKL architecture on the HIP kernels (``anyv2v_amd/vae.py``, diffusers state-dict
+keys, random weights offline).  The text / image encoders and ``SyntheticVAE`` are *synthetic* implementations
+(deterministic, weight-free, NOT the real models) so that the CLIs, file formats and multi-GPU sharding can be
+exercised end to end without any checkpoint:
 
   vae.encode_image(pil, device, height, width) -> [1,4,h,w]      (posterior mean x scaling_factor)
   vae.encode_video(list[pil], device, height, width) -> [1,4,F,h,w]
@@ -77,6 +79,52 @@ class SyntheticVAE:
         return [Image.fromarray(fr) for fr in x]
 
 
+class NativeVAE:
+    """The real AutoencoderKL architecture on the HIP kernels (``anyv2v_amd/vae.py``) behind the pipeline's VAE
+    interface: ``encode_vae_video`` / ``prepare_image_latents`` sample the posterior with the global RNG and scale by
+    ``scaling_factor`` (``pipeline_i2vgen_xl.py:540,582``); ``decode_latents`` divides by it and decodes
+    ``decode_chunk_size`` frames at a time (``:598-620``).  Weights: ``vae.load_state_dict(diffusers_state_dict)``;
+    offline only seeded random weights are available (``random_init_seed``)."""
+
+    def __init__(self, state_dict=None, random_init_seed=None, cfg=None, sample_posterior=True):
+        from .vae import AutoencoderKL, init_random_weights_
+        self.model = AutoencoderKL(cfg)
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        else:
+            init_random_weights_(self.model, 0 if random_init_seed is None else random_init_seed)
+        self.config = SimpleNamespace(scaling_factor=self.model.cfg.scaling_factor,
+                                      block_out_channels=self.model.cfg.block_out_channels)
+        self.sample_posterior = sample_posterior
+
+    def to(self, device):
+        self.model.to(device)
+        return self
+
+    def _encode(self, x, device):
+        self.model.to(device)
+        mean, logvar = self.model.encode_moments(x)
+        z = mean + torch.exp(0.5 * logvar) * torch.randn_like(mean) if self.sample_posterior else mean
+        return z * self.config.scaling_factor
+
+    def encode_image(self, image, device, height, width):
+        x = _pil_to_tensor(_center_crop_wide(image, (width, height)))
+        return self._encode(x, device).to(torch.float16)
+
+    def encode_video(self, video: List[Image.Image], device, height, width):
+        x = torch.cat([_pil_to_tensor(_center_crop_wide(f, (width, height))) for f in video])  # [F,3,H,W]
+        return self._encode(x, device).permute(1, 0, 2, 3)[None].to(torch.float16)
+
+    def decode_video(self, latents, decode_chunk_size=None):
+        z = latents[0].permute(1, 0, 2, 3).float() / self.config.scaling_factor  # [F,4,h,w]
+        n = z.shape[0]
+        chunk = n if not decode_chunk_size else int(decode_chunk_size)
+        frames = [self.model.decode(z[i:i + chunk]) for i in range(0, n, chunk)]
+        return torch.cat(frames).permute(1, 0, 2, 3)[None].float().cpu().clamp(-1, 1)  # [1,3,F,H,W]
+
+    to_pil = SyntheticVAE.to_pil
+
+
 def _seeded(text: str, shape):
     seed = int.from_bytes(hashlib.sha256(text.encode()).digest()[:8], "little") % (2 ** 63)
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
@@ -112,6 +160,12 @@ class SyntheticImageEncoder:
         img = _center_crop_wide(image, (width, width)).resize((224, 224), resample=Image.BILINEAR)
         x = F.avg_pool2d(_pil_to_tensor(img), 16).reshape(-1)
         return (self.proj @ x)[None, None].to(device=device, dtype=torch.float16)
+
+
+def attach_native_vae(pipe, state_dict=None, random_init_seed=0, cfg=None):
+    """Swap the VAE stand-in for the native AutoencoderKL (real architecture; real weights if a state dict is given)."""
+    pipe.vae = NativeVAE(state_dict, random_init_seed, cfg)
+    return pipe
 
 
 def attach_synthetic_encoders(pipe):

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import AttnDesc, GemmDesc
 
 MODE_LINEAR, MODE_CONV2D, MODE_TEMPORAL = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU, ACT_F32OUT = 0, 1, 2, 3, 4
 
 # global knobs (tests flip them to cross-check kernel variants)
 FORCE_NAIVE = False   # route GEMM / attention through the reference-grade kernels
@@ -51,7 +51,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
          mode: int = MODE_LINEAR, conv=None, temporal=None, M: Optional[int] = None, naive: bool = False):
     """out[M, N'] = epilogue(gather(A) @ W^T).  ``w`` is [N, taps*K] packed (see anyv2v_hip.h).
 
-    conv = (Hi, Wi, Ho, Wo, stride, up) for MODE_CONV2D; temporal = (F, HW) for MODE_TEMPORAL.
+    conv = (Hi, Wi, Ho, Wo, stride, up[, asym]) for MODE_CONV2D; temporal = (F, HW) for MODE_TEMPORAL.
     ``M`` overrides the row count (output rows); A may have a different number of rows for convs.
     """
     lib = _lib.load()
@@ -69,9 +69,15 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     if M is None:
         M = a0.shape[0]
     n_out = N // 2 if act == ACT_GEGLU else N
-    if out is None:
-        out = torch.empty((M, n_out), dtype=torch.float16, device=a0.device)
-    _rowmajor(out, "C")
+    if act == ACT_F32OUT:  # raw fp32 accumulator (+bias) -> float32 matrix
+        if out is None:
+            out = torch.empty((M, n_out), dtype=torch.float32, device=a0.device)
+        assert out.dim() == 2 and out.stride(1) == 1 and out.dtype == torch.float32 and out.is_cuda
+        assert rowvec is None and residual is None
+    else:
+        if out is None:
+            out = torch.empty((M, n_out), dtype=torch.float16, device=a0.device)
+        _rowmajor(out, "C")
     assert out.shape[0] >= M and out.shape[1] >= n_out
     d = GemmDesc()
     d.A0, d.A1, d.W, d.C = _p(a0), _p(a1), _p(w), _p(out)
@@ -85,7 +91,8 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     d.rowvec_div = rowvec_div
     d.mode = mode
     if mode == MODE_CONV2D:
-        d.Hi, d.Wi, d.Ho, d.Wo, d.stride, d.up = conv
+        d.Hi, d.Wi, d.Ho, d.Wo, d.stride, d.up = conv[:6]
+        d.asym = conv[6] if len(conv) > 6 else 0  # 1: pad only right / bottom (AutoencoderKL Downsample2D)
     elif mode == MODE_TEMPORAL:
         d.F, d.HW = temporal
     d.act = act
@@ -129,6 +136,19 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5, out=None):
     if out is None:
         out = torch.empty_like(x)
     _lib.check(lib.anyv2v_layernorm_f16(_p(x), _p(out), _p(gamma), _p(beta), M, Cc, eps, _stream()), "anyv2v_layernorm_f16")
+    return out
+
+
+def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None):
+    """fp32 logits [rows, cols] -> fp16 softmax(scale * s) (row-wise)."""
+    lib = _lib.load()
+    assert s.dim() == 2 and s.stride(1) == 1 and s.dtype == torch.float32 and s.is_cuda
+    rows, cols = s.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float16, device=s.device)
+    _rowmajor(out, "P")
+    _lib.check(lib.anyv2v_softmax_rows_f32_f16(_p(s), s.stride(0), _p(out), out.stride(0), rows, cols, float(scale), _stream()),
+               "anyv2v_softmax_rows_f32_f16")
     return out
 
 

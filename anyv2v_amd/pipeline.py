@@ -114,7 +114,8 @@ class I2VGenXLPipeline:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.float16, variant="fp16",
                         unet_config: Optional[I2VGenXLUNetConfig] = None, random_init_seed: Optional[int] = None, **kw):
-        """Loads ``<path>/unet/diffusion_pytorch_model[.fp16].safetensors`` (diffusers key naming) when present.
+        """Loads ``<path>/unet/diffusion_pytorch_model[.fp16].safetensors`` and ``<path>/vae/...`` (diffusers key naming) when
+        present.
         There is no network here: for the hub id ``"ali-vilab/i2vgen-xl"`` without a local copy, random weights of
         the exact architecture are used when ``random_init_seed`` (or ANYV2V_RANDOM_INIT_SEED) is given."""
         if torch_dtype != torch.float16:
@@ -137,7 +138,17 @@ class I2VGenXLPipeline:
                     "network; pass random_init_seed= (or ANYV2V_RANDOM_INIT_SEED) to run with random weights")
             unet._random_seed = seed
         scheduler = DDIMScheduler.from_pretrained(root, subfolder="scheduler")
-        return cls(unet=unet, scheduler=scheduler)
+        pipe = cls(unet=unet, scheduler=scheduler)
+        # the VAE of the checkpoint, when a local copy exists: native AutoencoderKL on the HIP kernels (same key naming)
+        vcands = [os.path.join(root, "vae", f"diffusion_pytorch_model.{variant}.safetensors"),
+                  os.path.join(root, "vae", "diffusion_pytorch_model.safetensors")]
+        vpath = next((c for c in vcands if os.path.isfile(c)), None)
+        if vpath is not None:
+            from safetensors.torch import load_file
+
+            from .encoders import NativeVAE
+            pipe.vae = NativeVAE(state_dict=load_file(vpath))
+        return pipe
 
     def to(self, device):
         device = torch.device(device)

@@ -104,17 +104,21 @@ class Conv2d(nn.Module):
             w = wp
         self._w = w.permute(0, 2, 3, 1).reshape(self.cout, -1).contiguous()  # [Cout, (ky kx cin)]
 
-    def tokens(self, x, H, W, *, x1=None, up=False, act=ACT_NONE, rowvec=None, rowvec_div=0, residual=None, out=None):
-        """x: [N*H*W, Cin] tokens -> [N*Ho*Wo, Cout]."""
+    def tokens(self, x, H, W, *, x1=None, up=False, act=ACT_NONE, rowvec=None, rowvec_div=0, residual=None, out=None,
+               asym=False):
+        """x: [N*H*W, Cin] tokens -> [N*Ho*Wo, Cout].  ``asym``: zero padding only after the last row / column
+        (``F.pad(x, (0, 1, 0, 1))`` + padding-0 conv of the AutoencoderKL encoder's Downsample2D)."""
         if self.k == 1:
             return ops.gemm(x, self._w, a1=x1, bias=self.bias, act=act, residual=residual, out=out)
         if up:
             Ho, Wo = 2 * H, 2 * W
+        elif asym:
+            Ho, Wo = (H + 1 - 3) // self.stride + 1, (W + 1 - 3) // self.stride + 1
         else:
             Ho, Wo = (H + 2 - 3) // self.stride + 1, (W + 2 - 3) // self.stride + 1
         n_img = x.shape[0] // (H * W)
         return ops.gemm(x, self._w, a1=x1, bias=self.bias, act=act, rowvec=rowvec, rowvec_div=rowvec_div,
-                        residual=residual, mode=MODE_CONV2D, conv=(H, W, Ho, Wo, self.stride, int(up)),
+                        residual=residual, mode=MODE_CONV2D, conv=(H, W, Ho, Wo, self.stride, int(up), int(asym)),
                         M=n_img * Ho * Wo, out=out)
 
 

@@ -34,11 +34,15 @@ extern "C" {
  *                       (attn.to_q/to_k/to_v/to_out[0]  i2vgen-xl/pnp_utils.py:175,182-183,216;
  *                        conv_shortcut pnp_utils.py:117-122; time_emb_proj pnp_utils.py:81-88)
  *   mode 1  CONV2D3x3 : 9 taps, pad 1, stride 1|2, optional nearest x2 upsample folded into the gather
- *                       (conv1/conv2 pnp_utils.py:78,107; Upsample2D/Downsample2D pnp_utils.py:51-76)
+ *                       (conv1/conv2 pnp_utils.py:78,107; Upsample2D/Downsample2D pnp_utils.py:51-76);
+ *                       asym = 1: zero padding only after the last row / column (F.pad (0,1,0,1) + stride-2
+ *                       conv of the AutoencoderKL encoder's Downsample2D, pipeline_i2vgen_xl.py:565-592)
  *   mode 2  TEMPORAL3 : 3 taps along the frame axis, pad 1 (Conv3d (3,1,1) of TemporalConvLayer;
  *                       consisti2v/consisti2v/models/videoldm_unet_blocks.py:316-328)
  * epilogue: + bias[n]; + rowvec[(m / rowvec_div) * ldrv + n] (the temb broadcast pnp_utils.py:91-92);
- *           act: 0 none, 1 SiLU, 2 GELU(erf), 3 GEGLU (W packed [16 x h | 16 x gate] per 32 rows, out N/2);
+ *           act: 0 none, 1 SiLU, 2 GELU(erf), 3 GEGLU (W packed [16 x h | 16 x gate] per 32 rows, out N/2),
+ *                4 = store the fp32 accumulator (+bias) to C as float (ldc in floats; no rowvec / R): attention
+ *                logits of the VAE mid-block's single 512-wide head;
  *           + R[m, n] (residual, pnp_utils.py:124); store fp16.
  */
 typedef struct AnyV2VGemmDesc {
@@ -54,6 +58,7 @@ typedef struct AnyV2VGemmDesc {
     int32_t lda0, lda1, ldc, ldr, ldrv, rowvec_div;
     int32_t mode;
     int32_t Hi, Wi, Ho, Wo, stride, up; /* mode 1 */
+    int32_t asym;                       /* mode 1: 0 = pad 1 on every side, 1 = pad only right / bottom */
     int32_t F, HW;                      /* mode 2: frames per clip, pixels per frame */
     int32_t act;
     int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging; bit2: never use the
@@ -135,6 +140,12 @@ int anyv2v_adaptive_avgpool_f16(const void* X, void* Y, int32_t N, int32_t Hi, i
 /* rows copy with column window: Y[m, ycol0 : ycol0+C] = X[m, xcol0 : xcol0+C] */
 int anyv2v_copy_cols_f16(const void* X, int32_t ldx, int32_t xcol0, void* Y, int32_t ldy, int32_t ycol0, int64_t M,
                          int32_t C, void* stream);
+
+/* Row softmax of fp32 logits (from anyv2v_gemm_f16 with act = 4) into fp16 probabilities:
+ * P[r, c] = softmax_c(scale * S[r, c]), cols <= 8192.  AutoencoderKL mid-block attention (single head of width 512,
+ * encode_vae_video / decode_latents, pipeline_i2vgen_xl.py:565-592,598-620). */
+int anyv2v_softmax_rows_f32_f16(const float* S, int32_t lds, void* P, int32_t ldp, int32_t rows, int32_t cols, float scale,
+                                void* stream);
 
 /* Fused classifier-free-guidance combine + DDIM step (eta = 0, v-prediction), reading the UNet's
  * channels-last v-prediction tokens directly and updating NCFHW latents in place:

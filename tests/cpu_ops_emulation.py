@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 MODE_LINEAR, MODE_CONV2D, MODE_TEMPORAL = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU, ACT_F32OUT = 0, 1, 2, 3, 4
 
 
 def _h(x):
@@ -30,13 +30,17 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rowvec_div=0, residual=None,
     if mode == MODE_LINEAR:
         y = a @ wf.t()
     elif mode == MODE_CONV2D:
-        Hi, Wi, Ho, Wo, stride, up = conv
+        Hi, Wi, Ho, Wo, stride, up = conv[:6]
+        asym = conv[6] if len(conv) > 6 else 0
         n = a.shape[0] // (Hi * Wi)
         x = a.view(n, Hi, Wi, K).permute(0, 3, 1, 2)
         if up:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         w4 = wf.view(N, 3, 3, K).permute(0, 3, 1, 2)
-        y = F.conv2d(x, w4, None, stride=stride, padding=1)
+        if asym:
+            y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w4, None, stride=stride, padding=0)
+        else:
+            y = F.conv2d(x, w4, None, stride=stride, padding=1)
         assert y.shape[2] == Ho and y.shape[3] == Wo
         y = y.permute(0, 2, 3, 1).reshape(n * Ho * Wo, N)
     else:
@@ -47,6 +51,13 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rowvec_div=0, residual=None,
         y = F.conv3d(x, w5, None, padding=(1, 0, 0)).squeeze(-1).permute(0, 2, 3, 1).reshape(B * Fr * HW, N)
     if M is not None:
         assert y.shape[0] == M, (y.shape, M)
+    if act == ACT_F32OUT:
+        if bias is not None:
+            y = y + bias.float()
+        if out is None:
+            return y
+        out[: y.shape[0], : y.shape[1]] = y
+        return out
     if act == ACT_GEGLU:
         if bias is not None:
             y = y + bias.float()
@@ -87,6 +98,14 @@ def groupnorm(x0, gamma, beta, stats, rows_per_group, *, x1=None, groups=32, eps
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
     y = _h(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def softmax_rows(s, scale, out=None):
+    y = _h(torch.softmax(s.float() * scale, dim=-1))
     if out is not None:
         out.copy_(y)
         return out
@@ -192,7 +211,7 @@ def ddim_step(v, x, sa_t, sb_t, sa_p, sb_p, out=None):
 def install(monkeypatch=None):
     """Replace every function of ``anyv2v_amd.ops`` with the emulation (tests only)."""
     from anyv2v_amd import ops
-    names = ["gemm", "groupnorm", "layernorm", "attention", "silu", "add", "timestep_embedding", "ncfhw_to_tokens",
+    names = ["gemm", "groupnorm", "layernorm", "softmax_rows", "attention", "silu", "add", "timestep_embedding", "ncfhw_to_tokens",
              "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "cfg_ddim_step", "ddim_step"]
     g = globals()
     for n in names:

@@ -777,5 +777,65 @@ def check_full_size_properties():
     return out
 
 
+def check_vae_kernels():
+    """The kernel modes added for the AutoencoderKL: one-sided-pad stride-2 conv, fp32-output GEMM, row softmax, and the
+    logits -> softmax -> value chain as one 512-wide attention head."""
+    out = []
+    for naive in (False, True):
+        tag = "naive" if naive else "mfma"
+        n, ci, co, H, W = 4, 64, 128, 16, 12
+        x, w, b = rnd(n, ci, H, W), rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
+        y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, H // 2, W // 2, 2, 0, 1),
+                     M=n * (H // 2) * (W // 2), naive=naive)
+        ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+        out.append(_res(f"conv3x3[{tag}] stride 2, pad (0,1,0,1) (VAE Downsample2D)", y, _to_tokens(ref), 4e-3))
+        a, wk = rnd(300, 128), rnd(256, 128, scale=1 / math.sqrt(128))
+        bias = rnd(256)
+        s32 = ops.gemm(a, wk, bias=bias, act=ops.ACT_F32OUT, naive=naive)
+        ref32 = a.float() @ wk.float().t() + bias.float()
+        out.append(_res(f"gemm[{tag}] fp32 output", s32, ref32, 2e-5))
+    s32 = torch.randn(500, 1000, device=DEV) * 30
+    p = ops.softmax_rows(s32, 0.0442)
+    out.append(_res("softmax rows fp32 -> fp16", p, torch.softmax(s32 * 0.0442, -1), 2e-3))
+    out.append(_res("softmax rows sum to 1", p.float().sum(-1), torch.ones(500, device=DEV), 2e-3))
+    # single head, d = 512, S = 1024: logits GEMM (fp32) -> softmax -> value GEMM
+    S, C = 1024, 512
+    q, k, v = rnd(S, C), rnd(S, C), rnd(S, C)
+    logits = ops.gemm(q, k, act=ops.ACT_F32OUT)
+    o = ops.gemm(ops.softmax_rows(logits, C ** -0.5), v.t().contiguous())
+    ref = F.scaled_dot_product_attention(q.float()[None, None], k.float()[None, None], v.float()[None, None])[0, 0]
+    out.append(_res("single 512-wide attention head via GEMM / softmax / GEMM", o, ref, 6e-3))
+    return out
+
+
+def check_vae(full: bool = True):
+    """Native AutoencoderKL vs the CPU oracle on identical fp16-rounded random weights: mini config, and the full SD-VAE
+    architecture (83.65 M parameters) on 2 x 64x64 images / 2 x 8x8 latents."""
+    from anyv2v_amd.vae import AutoencoderKL, VAEConfig
+    from oracle import vae_oracle as vo
+    out = []
+    cases = [("mini", VAEConfig.mini(), vo.VAEConfig.mini(), (2, 3, 32, 48), (2, 4, 8, 12))]
+    if full:
+        cases.append(("full", VAEConfig(), vo.VAEConfig(), (2, 3, 64, 64), (2, 4, 8, 8)))
+    for name, ncfg, ocfg, xs, zs in cases:
+        oracle = vo.AutoencoderKLOracle(ocfg)
+        sd = vo.random_state_dict(ocfg, 11)
+        oracle.load_state_dict(sd)
+        native = AutoencoderKL(ncfg)
+        native.load_state_dict(sd)
+        native.to(DEV)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(*xs, generator=g).clamp(-1, 1).half().float()
+        z = torch.randn(*zs, generator=g).half().float()
+        m0, l0 = oracle.encode_moments(x)
+        m1, l1 = native.encode_moments(x.to(DEV))
+        out.append(_res(f"vae[{name}] encode: posterior mean vs oracle", m1.cpu(), m0, 2e-2))
+        out.append(_res(f"vae[{name}] encode: posterior logvar vs oracle", l1.cpu(), l0, 2e-2))
+        d0 = oracle.decode(z)
+        d1 = native.decode(z.to(DEV))
+        out.append(_res(f"vae[{name}] decode vs oracle", d1.cpu(), d0, 2e-2))
+    return out
+
+
 ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_splitk, check_conv, check_norms, check_attention, check_elementwise,
-                     check_full_size_properties]
+                     check_full_size_properties, check_vae_kernels]

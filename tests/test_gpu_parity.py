@@ -78,3 +78,12 @@ def test_unet_mini_long_clips():
 def test_full_size_properties():
     """Size-independent identities at the BASELINE config 3 sizes (the oracle cannot run there in test time)."""
     _assert_all(gc.check_full_size_properties())
+
+
+def test_vae_kernel_modes():
+    _assert_all(gc.check_vae_kernels())
+
+
+def test_native_vae_vs_oracle():
+    """AutoencoderKL encode / decode on the HIP kernels vs the CPU restatement (mini + full architecture)."""
+    _assert_all(gc.check_vae())

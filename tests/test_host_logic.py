@@ -165,3 +165,26 @@ def test_pipeline_input_checks():
         p.check_inputs(None, None, 512, 512)
     with pytest.raises(FileNotFoundError):
         I2VGenXLPipeline.from_pretrained("ali-vilab/i2vgen-xl")  # no weights, no seed -> loud
+
+
+def test_native_vae_host_logic_and_state_dict(cpu_ops):
+    """AutoencoderKL wiring over the token layout (CPU emulation of the ops): diffusers state-dict keys / shapes of the
+    full SD-VAE, mini-config encode / decode vs the oracle, and the pipeline-facing adapter."""
+    import numpy as np
+    from PIL import Image
+
+    from anyv2v_amd.encoders import NativeVAE
+    from anyv2v_amd.vae import AutoencoderKL, VAEConfig
+    from oracle import vae_oracle as vo
+    full, full_o = AutoencoderKL(), vo.AutoencoderKLOracle()
+    assert list(full.state_dict()) == list(full_o.state_dict()) and len(full.state_dict()) == 248
+    assert all(full.state_dict()[k].shape == v.shape for k, v in full_o.state_dict().items())
+    assert sum(p.numel() for p in full_o.parameters()) == 83_653_863  # the SD-VAE's parameter count
+    _ok(gc.check_vae(full=False))
+    v = NativeVAE(random_init_seed=1, cfg=VAEConfig.mini())
+    imgs = [Image.fromarray((np.random.RandomState(i).rand(40, 60, 3) * 255).astype("uint8")) for i in range(3)]
+    lat = v.encode_video(imgs, torch.device("cpu"), 32, 48)
+    assert lat.shape == (1, 4, 3, 16, 24) and lat.dtype == torch.float16
+    vid = v.decode_video(lat, decode_chunk_size=2)
+    assert vid.shape == (1, 3, 3, 32, 48) and float(vid.abs().max()) <= 1.0
+    assert len(v.to_pil(vid)) == 3
