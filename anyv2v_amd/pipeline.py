@@ -148,6 +148,9 @@ class I2VGenXLPipeline:
 
             from .encoders import NativeVAE
             pipe.vae = NativeVAE(state_dict=load_file(vpath))
+        if os.path.isdir(os.path.join(root, "text_encoder")):
+            from .encoders import attach_hf_clip_encoders
+            attach_hf_clip_encoders(pipe, root)  # CLIP towers of a local checkpoint (plain PyTorch-ROCm modules)
         return pipe
 
     def to(self, device):

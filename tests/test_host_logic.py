@@ -188,3 +188,40 @@ def test_native_vae_host_logic_and_state_dict(cpu_ops):
     vid = v.decode_video(lat, decode_chunk_size=2)
     assert vid.shape == (1, 3, 3, 32, 48) and float(vid.abs().max()) <= 1.0
     assert len(v.to_pil(vid)) == 3
+
+
+def test_hf_clip_adapters_follow_the_reference_encode_paths():
+    """``HFTextEncoder`` / ``HFImageEncoder`` on tiny randomly initialised CLIP towers: clip_skip semantics
+    (hidden state -(clip_skip+1) + final LayerNorm, pipeline_i2vgen_xl.py:312-324) and the image-embedding shape."""
+    transformers = pytest.importorskip("transformers")
+    from PIL import Image
+
+    from anyv2v_amd.encoders import HFImageEncoder, HFTextEncoder
+    tm = transformers.CLIPTextModel(transformers.CLIPTextConfig(vocab_size=100, hidden_size=32, intermediate_size=64,
+                                                                num_hidden_layers=3, num_attention_heads=4,
+                                                                max_position_embeddings=16, bos_token_id=1, eos_token_id=2))
+
+    class Tok:
+        model_max_length = 16
+
+        def __call__(self, prompts, padding, max_length, truncation, return_tensors):
+            ids = torch.zeros(len(prompts), max_length, dtype=torch.long)
+            for i, p in enumerate(prompts):
+                t = [(ord(c) % 90) + 3 for c in p][: max_length - 1]
+                ids[i, : len(t)] = torch.tensor(t, dtype=torch.long)
+                ids[i, len(t)] = 2
+            return type("O", (), {"input_ids": ids})
+
+    enc = HFTextEncoder(tm, Tok())
+    e = enc.encode(["a robot", ""], torch.device("cpu"), clip_skip=1)
+    assert e.shape == (2, 16, 32) and e.dtype == torch.float16
+    ids = Tok()(["a robot", ""], "max_length", 16, True, "pt").input_ids
+    hs = tm(ids, output_hidden_states=True).hidden_states
+    ln = getattr(tm, "text_model", tm).final_layer_norm
+    assert torch.allclose(e.float(), ln(hs[-2]).detach(), atol=2e-3)
+    assert torch.allclose(enc.encode("a robot", torch.device("cpu"), None).float(), tm(ids[:1])[0].detach(), atol=2e-3)
+    vm = transformers.CLIPVisionModelWithProjection(transformers.CLIPVisionConfig(
+        hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, image_size=224, patch_size=32,
+        projection_dim=24))
+    img = Image.fromarray((np.random.RandomState(0).rand(300, 500, 3) * 255).astype("uint8"))
+    assert HFImageEncoder(vm).encode(img, 512, torch.device("cpu")).shape == (1, 1, 24)
