@@ -441,6 +441,11 @@ class I2VGenXLPipeline:
         for i, t in enumerate(ts):
             pnp_utils.register_time(self, t)  # host-side only: python int, no device sync (:1143)
             state = pnp_utils.injection_state(self)
+            if any(state) and nb != 3:
+                # the hooks slice the batch in thirds (pnp_utils.py:111,166,272); with guidance_scale <= 1 the reference
+                # builds a 2-way batch and silently injects the wrong rows -- refuse instead
+                raise ValueError("PnP feature injection needs classifier-free guidance (guidance_scale > 1): the hooks "
+                                 "assume the 3-way batch [source, negative, editing]")
             if skip_src and not any(state):
                 if eng_nosrc is None:
                     cond2 = {k: v[1:].contiguous() for k, v in cond.items()}

@@ -225,3 +225,33 @@ def test_hf_clip_adapters_follow_the_reference_encode_paths():
         projection_dim=24))
     img = Image.fromarray((np.random.RandomState(0).rand(300, 500, 3) * 255).astype("uint8"))
     assert HFImageEncoder(vm).encode(img, 512, torch.device("cpu")).shape == (1, 1, 24)
+
+
+def test_pnp_without_cfg_is_refused(cpu_ops):
+    """Reference quirk B.1: with guidance_scale <= 1 the hooks would slice a 2-way batch in thirds; we raise instead."""
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMScheduler
+    from anyv2v_amd.utils import LatentTrajectory
+    native, _, ocfg = gc.build_pair("mini", 7)
+    pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMScheduler())
+    pipe._device = torch.device("cpu")
+    inp = gc.config1_inputs(ocfg, 3, 4, 8)
+    sched = DDIMScheduler()
+    sched.set_timesteps(4)
+    pnp_utils.register_conv_injection(pipe, sched.timesteps)
+    pnp_utils.register_spatial_attention_pnp(pipe, sched.timesteps)
+    pnp_utils.register_temp_attention_pnp(pipe, sched.timesteps)
+    traj = LatentTrajectory()
+    for t in sched.timesteps.tolist():
+        traj[int(t)] = inp["sample"][:1].half()
+    h = lambda x: x.half()
+    with pytest.raises(ValueError, match="classifier-free guidance"):
+        pipe.sample_with_pnp(prompt_embeds=h(inp["encoder_hidden_states"][2:3]), image_embeddings=h(inp["image_embeddings"][2:3]),
+                             image_latents=h(inp["image_latents"][2:3]), height=64, width=64, num_frames=4,
+                             num_inference_steps=4, guidance_scale=1.0, target_fps=8, latents=h(inp["sample"][:1]),
+                             output_type="latent", ddim_init_latents_t_idx=0, ddim_inv_latents_path=traj,
+                             ddim_inv_prompt_embeds=h(inp["encoder_hidden_states"][:1]),
+                             ddim_inv_image_embeddings=h(inp["image_embeddings"][:1]),
+                             ddim_inv_image_latents=h(inp["image_latents"][:1]))
+    pnp_utils.clear_time(pipe)
