@@ -557,7 +557,7 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
 #undef AV_RB
 }
 
-template <int MF, bool GEGLU, int MODE, bool TRACE = false>
+template <int MF, bool GEGLU, int MODE, bool TRACE = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     constexpr int BM = 64 * MF, BN = 320;  // four wave rows of MF 16-row fragments
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -570,23 +570,33 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     const int G = gridDim.x;
     const int b0 = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous
     const int tilesM = (p.M + BM - 1) / BM;
-    const int ntiles = tilesM * p.tilesN;
+    const int ntiles_out = tilesM * p.tilesN;
+    // SPLIT: work items are (split, output tile) -- split-K for launches whose tiles alone cannot fill the CUs (a separate
+    // instantiation: the extra per-item state costs registers the plain kernel does not have)
+    const int ntiles = SPLIT ? ntiles_out * p.splits : ntiles_out;
 
     const int srow0 = tid >> 3, pc = tid & 7, kc = pc ^ (srow0 & 7);
     const int ntap = p.nt0 + p.nt1;
-    const int nk = p.taps * ntap;
+    const int nk_all = p.taps * ntap;
+    auto k_begin = [&](int item) { return SPLIT ? (nk_all * (item / ntiles_out)) / p.splits : 0; };
+    auto k_end = [&](int item) { return SPLIT ? (nk_all * (item / ntiles_out + 1)) / p.splits : nk_all; };
 
     // ---- producer state (the tile whose K-tiles are being requested; runs ahead of the consumer by one K-tile) ----
     RowInfo ri[4];  // (entries >= MF unused)
     const half_t* bptr;               // W row (n_blk + srow0); the other four rows sit 64 * Ktot halves apart
     const size_t brow = (size_t)64 * p.Ktot;
     AGen<MODE> gen;
-    auto producer_start = [&](int tile) {
-        const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+    auto producer_start = [&](int item) {
+        const int tile_o = SPLIT ? item % ntiles_out : item;
+        const int mt = tile_o / p.tilesN, nt = tile_o - mt * p.tilesN;
+        const int kb = k_begin(item);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ri[i] = make_row<MODE>(p, i < MF ? mt * BM + srow0 + 64 * i : p.M);
-        bptr = p.W + (size_t)(nt * BN + srow0) * p.Ktot + kc * 8;
-        gen.start(p, ri, kc);
+        bptr = p.W + (size_t)(nt * BN + srow0) * p.Ktot + kc * 8 + (size_t)kb * 64;
+        if constexpr (SPLIT)
+            gen.start(p, ri, kc, kb, ntap);
+        else
+            gen.start(p, ri, kc);
     };
     auto advance = [&]() {
         bptr += 64;
@@ -610,7 +620,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     bool landed = false;
     bool rederive = false;  // producer state is not carried across an epilogue (register pressure): re-derive it  // the current tile's first K-tile was already waited for (before the previous epilogue)
     while (true) {
-        const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+        const int tile_o = SPLIT ? tile % ntiles_out : tile;
+        const int mt = tile_o / p.tilesN, nt = tile_o - mt * p.tilesN;
+        const int nk = k_end(tile) - k_begin(tile);
         const int m_wave = mt * BM + wr * MF * 16;
         const int n_wave = nt * BN + wc * 160;
         const int next_tile = tile + G;
@@ -658,6 +670,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int l15 = lane_e & 15, lq = lane_e >> 4;
+        if constexpr (SPLIT) {  // raw fp32 partial tile; gemm_splitk_reduce_kernel sums the splits in order and finishes
+            float* dst = p.partial + (size_t)(tile / ntiles_out) * p.M * p.N;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int m = m_wave + mf * 16 + l15;
+#pragma unroll
+                for (int nf = 0; nf < 10; ++nf)
+                    if (m < p.M) *(f4*)(dst + (size_t)m * p.N + n_wave + nf * 16 + 4 * lq) = acc[mf][nf];
+            }
+            if (!has_next) break;
+            tile = next_tile;
+            continue;
+        }
+        if constexpr (SPLIT) __builtin_unreachable();
         half_t* const slab = (half_t*)(smem + (stage ^ 1) * STAGE_BYTES + w * SLAB_BYTES);
         constexpr int OUT_W = GEGLU ? 80 : 160;       // output columns of this wave
         constexpr int CPRW = OUT_W / 8;               // 16-byte chunks per slab row
@@ -868,6 +894,35 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         const int tiles_big = ((d->M + BMB - 1) / BMB) * (d->N / 320);
         const int rounds = (tiles_big + 255) / 256;
         const bool fills = tiles_big >= 224 && tiles_big * 4 >= rounds * 256 * 3;
+        // launches that cannot fill the CUs but have a long K loop (8x8-level convs / FF-down of the 3-clip batch, M = 3072):
+        // split K so that (tiles x splits) is one nearly full round of 256 work items; the ordered reduce pass finishes them.
+        // Measured (profiles/r01_gemm_split_ab.txt): 1.2-1.4x over the 128-row kernel's split path from 80 K-tiles on with
+        // >= 224 work items; slower below 72 K-tiles or with a 3/4-full round (M = 1024), which stay on the 128-row kernel.
+        int big_splits = 1;
+        {
+            const int nk_all = k.taps * (k.nt0 + k.nt1);
+            if (!fills && !geglu && !(d->flags & (16 | 8)) && d->workspace != nullptr && tiles_big <= 128 && nk_all >= 72 &&
+                d->N % 8 == 0) {
+                int sp = 256 / tiles_big;
+                if (sp > 8) sp = 8;
+                if (sp > nk_all / 12) sp = nk_all / 12;
+                if (sp >= 2 && tiles_big * sp >= 224 &&
+                    (size_t)sp * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes)
+                    big_splits = sp;
+            }
+        }
+        if (big_splits > 1) {
+            k.tilesN = d->N / 320;
+            k.splits = big_splits;
+            k.partial = (float*)d->workspace;
+            const dim3 grid(tiles_big * big_splits < 256 ? tiles_big * big_splits : 256);
+            hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, false, true>), grid, dim3(512), 0, s, k);
+            const long long total = (long long)d->M * (d->N / 8);
+            long long blocks = (total + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k);
+            return av_launch_status("gemm_big<split-K>");
+        }
         if (fills || (d->flags & 8)) {
             k.tilesN = d->N / 320;
             const dim3 grid(tiles_big < 256 ? tiles_big : 256);

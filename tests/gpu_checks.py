@@ -246,6 +246,24 @@ def check_gemm_splitk():
         y_one = ops.gemm(xt, wp, **kw)
         out.append(_res("conv3x3[split-K] vs unsplit kernel", ys[0], y_one.float(), 2e-3))
         ops.GEMM_FLAGS = saved
+        # same level, N = 1280: split-K work items of the persistent 192x320 kernel (16 x 4 tiles x 4 splits = one round);
+        # M = 3000 is not a multiple of 192 (row guards), compared with the 128-row kernel's split path (flag bit2) too
+        n, ci, co = 48, 640, 1280
+        x, w, b = rnd(n, ci, H, W), rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
+        temb, res = rnd(3, co), rnd(n * H * W, co)
+        kw = dict(bias=b, rowvec=temb, rowvec_div=16 * H * W, residual=res, mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0))
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + temb.float().repeat_interleave(16, 0)[:, :, None, None]
+        ref = _to_tokens(ref) + res.float()
+        xt, wp = _to_tokens(x), _pack_conv(w)
+        ys = [ops.gemm(xt, wp, **kw) for _ in range(3)]
+        out.append(_res("conv3x3[persistent split-K] vs torch", ys[0], ref, 4e-3))
+        out.append(_res("conv3x3[persistent split-K] bit-reproducible", ys[0], ys[2].float(), 0.0))
+        ops.GEMM_FLAGS = saved | 4
+        out.append(_res("conv3x3[persistent split-K] vs 128-row split-K", ys[0], ops.gemm(xt, wp, **kw).float(), 2e-3))
+        ops.GEMM_FLAGS = saved
+        a, wl, rl = rnd(3000, 5120), rnd(1280, 5120, scale=1 / math.sqrt(5120)), rnd(3000, 1280)
+        y = ops.gemm(a, wl, bias=rnd(1280) * 0, residual=rl)
+        out.append(_res("gemm[persistent split-K] M3000 N1280 K5120 +res", y, _gemm_ref(a, wl) + rl.float(), 4e-3))
         # linear, long K, small M
         a, wl = rnd(1024, 5120), rnd(1280, 5120, scale=1 / math.sqrt(5120))
         y = ops.gemm(a, wl, bias=rnd(1280) * 0)
