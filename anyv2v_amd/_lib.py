@@ -52,6 +52,9 @@ SYMBOLS = {
     "anyv2v_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _VP]),
     "anyv2v_groupnorm_f16": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _F32, _I32, _VP]),
     "anyv2v_groupnorm_scratch_floats": (C.c_int64, [_I32, _I32, _I32]),
+    "anyv2v_groupnorm_partial_floats": (C.c_int64, [_I32, _I32, _I32, _I32]),
+    "anyv2v_groupnorm_partial_f16": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _I32, _I32, _I32, _VP]),
+    "anyv2v_groupnorm_apply_f16": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _F32, _I32, _I32, _VP]),
     "anyv2v_layernorm_f16": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _VP]),
     "anyv2v_attention_f16": (C.c_int, [C.POINTER(AttnDesc), _VP]),
     "anyv2v_attention_small_f16": (C.c_int, [C.POINTER(AttnDesc), _I32, _VP]),

@@ -152,50 +152,104 @@ extern "C" int64_t anyv2v_groupnorm_scratch_floats(int32_t M, int32_t rows_per_g
     return nsg * G * 2 * (int64_t)(1 + GN_MAX_CHUNKS);
 }
 
-extern "C" int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y,
-                                    const void* gamma, const void* beta, float* stats, int32_t M,
-                                    int32_t rows_per_group, int32_t G, float eps, int32_t silu, void* stream) {
-    AV_CHECK(X0 && Y && gamma && beta && stats, "groupnorm: null pointer");
+// launch plan shared by the one-call and the two-phase (sharded) entry points
+struct GnPlan {
+    int nsg, V, rpb, threads, nchunks, rows_chunk;
+    size_t lds;
+    long long bps;
+};
+
+static int gn_plan(GnPlan& pl, const void* X0, const void* X1, int32_t C0, int32_t C1, int32_t M, int32_t rows_per_group,
+                   int32_t G) {
     AV_CHECK(C0 > 0 && C1 >= 0 && (C1 == 0 || X1), "groupnorm: bad C0/C1");
     const int C = C0 + C1;
     AV_CHECK(C0 % 8 == 0 && C1 % 8 == 0, "groupnorm: C0/C1 must be multiples of 8 (%d,%d)", C0, C1);
     AV_CHECK(G > 0 && G <= 64 && C % G == 0, "groupnorm: bad group count %d for C=%d", G, C);
     AV_CHECK(rows_per_group > 0 && M % rows_per_group == 0, "groupnorm: M %% rows_per_group != 0");
-    AV_CHECK(av_aligned16(X0) && av_aligned16(X1) && av_aligned16(Y) && av_aligned16(gamma) && av_aligned16(beta),
-             "groupnorm: pointers must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    const int nsg = M / rows_per_group;
-    const int V = C / 8;
-    AV_CHECK(V <= 1024, "groupnorm: C too large (%d)", C);
-    int rpb = 256 / V;
-    if (rpb < 1) rpb = 1;
-    int threads = V * rpb;
-    if (threads < 64) threads = 64;
-    if (threads < G) threads = G;
-    int nchunks = (1536 + nsg - 1) / nsg;
-    int max_chunks = (rows_per_group + rpb * 8 - 1) / (rpb * 8);  // >= 8 row-iterations per thread
+    AV_CHECK(av_aligned16(X0) && av_aligned16(X1), "groupnorm: pointers must be 16-byte aligned");
+    pl.nsg = M / rows_per_group;
+    pl.V = C / 8;
+    AV_CHECK(pl.V <= 1024, "groupnorm: C too large (%d)", C);
+    pl.rpb = 256 / pl.V;
+    if (pl.rpb < 1) pl.rpb = 1;
+    pl.threads = pl.V * pl.rpb;
+    if (pl.threads < 64) pl.threads = 64;
+    if (pl.threads < G) pl.threads = G;
+    int nchunks = (1536 + pl.nsg - 1) / pl.nsg;
+    int max_chunks = (rows_per_group + pl.rpb * 8 - 1) / (pl.rpb * 8);  // >= 8 row-iterations per thread
     if (max_chunks < 1) max_chunks = 1;
     if (nchunks > max_chunks) nchunks = max_chunks;
     if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
-    const int rows_chunk = (rows_per_group + nchunks - 1) / nchunks;
-    nchunks = (rows_per_group + rows_chunk - 1) / rows_chunk;
-    float* partial = stats;   // [nsg][nchunks][G][2]
-    const size_t lds = (size_t)rpb * C * 2 * sizeof(float);
-    AV_CHECK(lds <= 64 * 1024, "groupnorm: LDS reduction buffer too large");
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nsg, nchunks), dim3(threads), lds, s, (const half_t*)X0,
-                       (const half_t*)X1, C0, C1, partial, rows_per_group, G, rows_chunk, rpb, nchunks);
-    const float inv_cnt = 1.0f / ((float)rows_per_group * (float)(C / G));
-    // ~2048 blocks in total, each at least 8 vectors per thread where the stat group is large enough
-    const long long vec_sg = (long long)rows_per_group * V;
+    pl.rows_chunk = (rows_per_group + nchunks - 1) / nchunks;
+    pl.nchunks = (rows_per_group + pl.rows_chunk - 1) / pl.rows_chunk;
+    pl.lds = (size_t)pl.rpb * C * 2 * sizeof(float);
+    AV_CHECK(pl.lds <= 64 * 1024, "groupnorm: LDS reduction buffer too large");
+    // ~2048 apply blocks in total, each at least 8 vectors per thread where the stat group is large enough
+    const long long vec_sg = (long long)rows_per_group * pl.V;
     AV_CHECK(vec_sg < (1ll << 31), "groupnorm: stat group too large (%lld vectors)", vec_sg);
-    long long bps = (2048 + nsg - 1) / nsg;
+    pl.bps = (2048 + pl.nsg - 1) / pl.nsg;
     const long long max_bps = (vec_sg + 256 * 8 - 1) / (256 * 8);
-    if (bps > max_bps) bps = max_bps;
-    if (bps < 1) bps = 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)bps, (unsigned)nsg), dim3(256), 0, s, (const half_t*)X0,
-                       (const half_t*)X1, C0, C1, (half_t*)Y, (const half_t*)gamma, (const half_t*)beta,
-                       (const float*)partial, nchunks, inv_cnt, eps, rows_per_group, G, silu);
+    if (pl.bps > max_bps) pl.bps = max_bps;
+    if (pl.bps < 1) pl.bps = 1;
+    return ANYV2V_OK;
+}
+
+static int gn_partial(const GnPlan& pl, const void* X0, const void* X1, int32_t C0, int32_t C1, float* stats,
+                      int32_t rows_per_group, int32_t G, hipStream_t s) {
+    // stats: [nsg][nchunks][G][2]
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(pl.nsg, pl.nchunks), dim3(pl.threads), pl.lds, s, (const half_t*)X0,
+                       (const half_t*)X1, C0, C1, stats, rows_per_group, G, pl.rows_chunk, pl.rpb, pl.nchunks);
+    return av_launch_status("groupnorm<partial>");
+}
+
+static int gn_apply(const GnPlan& pl, const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y, const void* gamma,
+                    const void* beta, const float* stats, int32_t rows_per_group, int32_t G, float eps, int32_t silu,
+                    int32_t shards, hipStream_t s) {
+    AV_CHECK(av_aligned16(Y) && av_aligned16(gamma) && av_aligned16(beta), "groupnorm: pointers must be 16-byte aligned");
+    const float inv_cnt = 1.0f / ((float)rows_per_group * (float)((C0 + C1) / G) * (float)shards);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)pl.bps, (unsigned)pl.nsg), dim3(256), 0, s, (const half_t*)X0,
+                       (const half_t*)X1, C0, C1, (half_t*)Y, (const half_t*)gamma, (const half_t*)beta, stats, pl.nchunks,
+                       inv_cnt, eps, rows_per_group, G, silu);
     return av_launch_status("groupnorm");
+}
+
+extern "C" int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y,
+                                    const void* gamma, const void* beta, float* stats, int32_t M,
+                                    int32_t rows_per_group, int32_t G, float eps, int32_t silu, void* stream) {
+    AV_CHECK(X0 && Y && gamma && beta && stats, "groupnorm: null pointer");
+    GnPlan pl;
+    if (int rc = gn_plan(pl, X0, X1, C0, C1, M, rows_per_group, G)) return rc;
+    if (int rc = gn_partial(pl, X0, X1, C0, C1, stats, rows_per_group, G, (hipStream_t)stream)) return rc;
+    return gn_apply(pl, X0, X1, C0, C1, Y, gamma, beta, stats, rows_per_group, G, eps, silu, 1, (hipStream_t)stream);
+}
+
+// Sharded GroupNorm (a clip whose frames or pixels are split over `shards` ranks, every rank holding the same local
+// shape): phase 1 writes this rank's partial sums; the caller adds the first anyv2v_groupnorm_partial_floats() floats
+// of `stats` over the ranks (all-reduce SUM, RCCL); phase 2 normalises with shards x the local element count.
+extern "C" int64_t anyv2v_groupnorm_partial_floats(int32_t M, int32_t rows_per_group, int32_t G, int32_t C) {
+    GnPlan pl;
+    static const int dummy __attribute__((aligned(16))) = 0;
+    if (gn_plan(pl, &dummy, nullptr, C, 0, M, rows_per_group, G) != ANYV2V_OK) return -1;
+    return (int64_t)pl.nsg * pl.nchunks * G * 2;
+}
+
+extern "C" int anyv2v_groupnorm_partial_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, float* stats, int32_t M,
+                                            int32_t rows_per_group, int32_t G, void* stream) {
+    AV_CHECK(X0 && stats, "groupnorm_partial: null pointer");
+    GnPlan pl;
+    if (int rc = gn_plan(pl, X0, X1, C0, C1, M, rows_per_group, G)) return rc;
+    return gn_partial(pl, X0, X1, C0, C1, stats, rows_per_group, G, (hipStream_t)stream);
+}
+
+extern "C" int anyv2v_groupnorm_apply_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y,
+                                          const void* gamma, const void* beta, const float* stats, int32_t M,
+                                          int32_t rows_per_group, int32_t G, float eps, int32_t silu, int32_t shards,
+                                          void* stream) {
+    AV_CHECK(X0 && Y && gamma && beta && stats, "groupnorm_apply: null pointer");
+    AV_CHECK(shards >= 1, "groupnorm_apply: shards must be >= 1");
+    GnPlan pl;
+    if (int rc = gn_plan(pl, X0, X1, C0, C1, M, rows_per_group, G)) return rc;
+    return gn_apply(pl, X0, X1, C0, C1, Y, gamma, beta, stats, rows_per_group, G, eps, silu, shards, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -108,7 +108,11 @@ def gn_scratch_floats(M: int, rows_per_group: int, groups: int = 32) -> int:
 
 
 def groupnorm(x0: torch.Tensor, gamma, beta, stats: torch.Tensor, rows_per_group: int, *, x1=None, groups: int = 32,
-              eps: float = 1e-5, silu: bool = False, out=None):
+              eps: float = 1e-5, silu: bool = False, out=None, shard=None):
+    """``shard`` = (shards, all_reduce_sum): this rank holds 1/shards of every statistics group (frame- / pixel-parallel
+    clip, ``anyv2v_amd.parallel.FrameParallel``); the partial sums are added over the ranks between the two kernels."""
+    if shard is not None:
+        return _groupnorm_sharded(x0, gamma, beta, stats, rows_per_group, x1, groups, eps, silu, out, shard)
     lib = _lib.load()
     _rowmajor(x0, "X0")
     assert x0.is_contiguous()
@@ -125,6 +129,31 @@ def groupnorm(x0: torch.Tensor, gamma, beta, stats: torch.Tensor, rows_per_group
     assert stats.dtype == torch.float32 and stats.numel() >= need, "GroupNorm scratch too small"
     _lib.check(lib.anyv2v_groupnorm_f16(_p(x0), _p(x1), C0, C1, _p(out), _p(gamma), _p(beta), _p(stats), M,
                                         rows_per_group, groups, eps, int(silu), _stream()), "anyv2v_groupnorm_f16")
+    return out
+
+
+def _groupnorm_sharded(x0, gamma, beta, stats, rows_per_group, x1, groups, eps, silu, out, shard):
+    lib = _lib.load()
+    shards, all_reduce_sum = shard
+    _rowmajor(x0, "X0")
+    assert x0.is_contiguous()
+    M, C0 = x0.shape
+    C1 = 0
+    if x1 is not None:
+        _rowmajor(x1, "X1")
+        assert x1.is_contiguous() and x1.shape[0] == M
+        C1 = x1.shape[1]
+    if out is None:
+        out = torch.empty((M, C0 + C1), dtype=torch.float16, device=x0.device)
+    assert out.is_contiguous()
+    n = int(lib.anyv2v_groupnorm_partial_floats(M, rows_per_group, groups, C0 + C1))
+    assert n > 0 and stats.dtype == torch.float32 and stats.numel() >= n, "GroupNorm scratch too small"
+    _lib.check(lib.anyv2v_groupnorm_partial_f16(_p(x0), _p(x1), C0, C1, _p(stats), M, rows_per_group, groups, _stream()),
+               "anyv2v_groupnorm_partial_f16")
+    all_reduce_sum(stats[:n])
+    _lib.check(lib.anyv2v_groupnorm_apply_f16(_p(x0), _p(x1), C0, C1, _p(out), _p(gamma), _p(beta), _p(stats), M,
+                                              rows_per_group, groups, eps, int(silu), int(shards), _stream()),
+               "anyv2v_groupnorm_apply_f16")
     return out
 
 

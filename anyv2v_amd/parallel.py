@@ -53,3 +53,103 @@ def gather_latents(latents: Optional[torch.Tensor], like_shape, dtype, device) -
     out = [torch.empty_like(x) for _ in range(world)]
     dist.all_gather(out, x.contiguous())
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+class FrameParallel:
+    """One clip over ``world`` GPUs for the long-clip mode (128 frames, ``gradio_demo.py:129-131``).
+
+    Every rank holds ``F / world`` consecutive frames of every batch element, as token matrices ``[(b f_loc)(h w), C]``.
+    Spatial layers (ResNet convs, per-frame GroupNorm, spatial / cross attention, feed-forward) are independent per frame
+    and need no communication.  Around each temporal layer (``TemporalConvLayer``, ``TransformerTemporalModel``) the
+    tokens are re-sharded frames -> pixels with ONE all-to-all (rank r then holds pixels ``[r HW/world, (r+1) HW/world)``
+    of ALL frames: the temporal conv and the temporal attention are independent per pixel), and back with another; the
+    5-D GroupNorm statistics inside those layers are the only reduction (``ops.groupnorm(shard=...)``: one all-reduce
+    of a few KiB of fp32 partial sums).  The v-prediction (8 channels) is all-gathered at the end of the forward, so the
+    scheduler step, the PnP bookkeeping and the pipeline loops run unchanged -- and identically -- on every rank.
+
+    Per 64x64 layer at B=3, F=128 the re-shard moves 7/8 of a 1 GiB activation: 7 x 16 MiB per rank and direction,
+    one message per xGMI link -- the pattern the point-to-point fabric is built for (no ring, no NVSwitch assumed).
+    Transport: ``torch.distributed`` (backend "nccl" = RCCL); with the ``gloo`` backend device tensors are staged
+    through host memory (tests / bring-up only).
+    """
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("FrameParallel needs an initialised torch.distributed process group (init_distributed())")
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.host_staged = dist.get_backend(group) == "gloo"
+        self.bytes_moved = 0  # all-to-all payload sent by this rank (for the comm accounting in DESIGN.md / tests)
+
+    # ---- geometry
+    def check(self, F: int, H: int, W: int, levels: int):
+        hw_min = (H >> (levels - 1)) * (W >> (levels - 1))
+        if F % self.world or hw_min % self.world or hw_min == 0:
+            raise ValueError(f"frame-parallel clip: F={F} and the coarsest level's {hw_min} pixels must both be multiples "
+                             f"of the world size {self.world}")
+
+    def frames(self, F: int):
+        n = F // self.world
+        return self.rank * n, (self.rank + 1) * n
+
+    # ---- collectives
+    def _a2a(self, send: torch.Tensor) -> torch.Tensor:
+        self.bytes_moved += send.numel() * send.element_size() * (self.world - 1) // self.world
+        if self.host_staged and send.is_cuda:
+            s = send.cpu()
+            r = torch.empty_like(s)
+            self.dist.all_to_all_single(r, s, group=self.group)
+            return r.to(send.device)
+        recv = torch.empty_like(send)
+        self.dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        if self.host_staged and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
+    def frames_to_pixels(self, x: torch.Tensor, B: int, Fl: int, HW: int) -> torch.Tensor:
+        """[(B Fl)(HW), C] (my frames, all pixels) -> [(B F)(HW/world), C] (all frames, my pixels)."""
+        N, C = self.world, x.shape[1]
+        send = x.view(B, Fl, N, HW // N, C).permute(2, 0, 1, 3, 4).contiguous()      # [dst, B, Fl, HWl, C]
+        recv = self._a2a(send)                                                         # [src = frame block, ...]
+        return recv.permute(1, 0, 2, 3, 4).reshape(B * N * Fl * (HW // N), C)          # frames of rank s sit at s*Fl..
+
+    def pixels_to_frames(self, y: torch.Tensor, B: int, Fl: int, HW: int) -> torch.Tensor:
+        N, C = self.world, y.shape[1]
+        send = y.view(B, N, Fl, HW // N, C).permute(1, 0, 2, 3, 4).contiguous()       # [dst = frame block, B, Fl, HWl, C]
+        recv = self._a2a(send)                                                         # [src = pixel block, ...]
+        return recv.permute(1, 2, 0, 3, 4).reshape(B * Fl * HW, C)
+
+    def gather_frames(self, v: torch.Tensor, B: int, Fl: int, HW: int) -> torch.Tensor:
+        """[(B Fl)(HW), C] per rank -> the full [(B F)(HW), C] on every rank (the 8-channel v-prediction)."""
+        N, C = self.world, v.shape[1]
+        if self.host_staged and v.is_cuda:
+            parts = [torch.empty(v.shape, dtype=v.dtype) for _ in range(N)]
+            self.dist.all_gather(parts, v.cpu(), group=self.group)
+            parts = [p.to(v.device) for p in parts]
+        else:
+            parts = [torch.empty_like(v) for _ in range(N)]
+            self.dist.all_gather(parts, v.contiguous(), group=self.group)
+        full = torch.stack([p.view(B, Fl, HW, C) for p in parts], 1)                  # [B, N, Fl, HW, C]
+        return full.reshape(B * N * Fl * HW, C)
+
+    # ---- the wrapper the temporal layers call
+    def temporal(self, ctx, x: torch.Tensor, HW: int, body):
+        """``body(ctx_t, x_pixels, HW_local, shard)`` runs the layer on the pixel-sharded tokens of ALL frames."""
+        tctx = ctx.__dict__.get("_temporal_view")
+        if tctx is None:
+            import copy
+            tctx = copy.copy(ctx)
+            tctx.F = ctx.F * self.world
+            ctx._temporal_view = tctx
+        xp = self.frames_to_pixels(x, ctx.B, ctx.F, HW)
+        y = body(tctx, xp, HW // self.world, (self.world, self.all_reduce_sum))
+        return self.pixels_to_frames(y, ctx.B, ctx.F, HW)

@@ -60,7 +60,8 @@ class _StepEngine:
         self.dup_slots = list(dup_slots)
         self.coef = torch.zeros(4, dtype=torch.float32, device=sample.device)
         self.graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
-        self.use_graphs = _use_graphs() and sample.is_cuda
+        # (a frame-parallel forward contains collectives: run eagerly -- at 128 frames launch overhead is irrelevant)
+        self.use_graphs = _use_graphs() and sample.is_cuda and getattr(pipe.unet, "frame_parallel", None) is None
         B, _, F, H, W = sample.shape
         unet = self.unet
         if not unet._packed:
@@ -120,8 +121,11 @@ class I2VGenXLPipeline:
         the exact architecture are used when ``random_init_seed`` (or ANYV2V_RANDOM_INIT_SEED) is given."""
         if torch_dtype != torch.float16:
             raise ValueError("the HIP kernels compute in fp16 (fp32 accumulate); torch_dtype must be torch.float16")
-        unet = I2VGenXLUNet(unet_config)
         root = str(pretrained_model_name_or_path)
+        cfg_json = os.path.join(root, "unet", "config.json")
+        if unet_config is None and os.path.isfile(cfg_json):
+            unet_config = I2VGenXLUNetConfig.from_json(cfg_json)
+        unet = I2VGenXLUNet(unet_config)
         cands = [os.path.join(root, "unet", f"diffusion_pytorch_model.{variant}.safetensors"),
                  os.path.join(root, "unet", "diffusion_pytorch_model.safetensors")]
         path = next((c for c in cands if os.path.isfile(c)), None)
@@ -461,7 +465,9 @@ class I2VGenXLPipeline:
         if output_type == "latent":
             return I2VGenXLPipelineOutput(frames=latents)
         video = self.decode_latents(latents, decode_chunk_size=decode_chunk_size)
-        frames = self._need("vae").to_pil(video) if output_type == "pil" else video
+        # "pil": one list of PIL frames per video, as ``tensor2vid`` returns (``pipeline_i2vgen_xl.py:79-97``; the runners
+        # index ``.frames[0]``, ``run_group_ddim_inversion.py:77``)
+        frames = [self._need("vae").to_pil(video)] if output_type == "pil" else video
         if not return_dict:
             return (frames,)
         return I2VGenXLPipelineOutput(frames=frames)

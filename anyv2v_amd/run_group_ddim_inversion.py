@@ -20,7 +20,7 @@ from PIL import Image
 
 from .config import OmegaConf
 from .encoders import attach_synthetic_encoders
-from .parallel import init_distributed, seed_for_entry, shard_entries
+from .parallel import FrameParallel, init_distributed, seed_for_entry, shard_entries
 from .pipeline import I2VGenXLPipeline
 from .schedulers import DDIMInverseScheduler, DDIMScheduler
 from .utils import convert_video_to_frames, export_to_gif, load_ddim_latents_at_t, load_video_frames, seed_everything
@@ -28,7 +28,7 @@ from .utils import convert_video_to_frames, export_to_gif, load_ddim_latents_at_
 MODEL_ID = "ali-vilab/i2vgen-xl"
 
 
-def ddim_inversion(config, first_frame, frame_list, pipe: I2VGenXLPipeline, inverse_scheduler, g):
+def ddim_inversion(config, first_frame, frame_list, pipe: I2VGenXLPipeline, inverse_scheduler, g, write=True):
     """``run_group_ddim_inversion.py:29-55``."""
     pipe.scheduler = inverse_scheduler
     video_latents_at_0 = pipe.encode_vae_video(frame_list, device=pipe._execution_device, height=config.image_size[1],
@@ -37,7 +37,8 @@ def ddim_inversion(config, first_frame, frame_list, pipe: I2VGenXLPipeline, inve
                                width=config.image_size[0], num_frames=config.n_frames,
                                num_inference_steps=config.n_steps, guidance_scale=config.cfg,
                                negative_prompt=config.negative_prompt, target_fps=config.target_fps,
-                               latents=video_latents_at_0, generator=g, return_dict=False, output_dir=config.output_dir)
+                               latents=video_latents_at_0, generator=g, return_dict=False,
+                               output_dir=config.output_dir if write else None)
     logging.getLogger(__name__).debug(f"ddim_latents.shape: {ddim_latents.shape}")
     return ddim_latents[0]  # [num_inference_steps, c, num_frames, h, w]
 
@@ -51,13 +52,20 @@ def ddim_sampling(config, first_frame, ddim_latents_at_T, pipe: I2VGenXLPipeline
                 generator=g, return_dict=True, ddim_init_latents_t_idx=ddim_init_latents_t_idx).frames[0]
 
 
-def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None):
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False):
     rank, local_rank, world = init_distributed()
+    # --frame_parallel (long clips): every rank works on EVERY entry, the clip's frames sharded over
+    # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
+    fp_mode = bool(frame_parallel) and world > 1
+    writer = rank == 0 or not fp_mode
+    e_rank, e_world = (0, 1) if fp_mode else (rank, world)
     pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
                                             variant="fp16", random_init_seed=random_init_seed)
     pipe.to(device)
     if synthetic_encoders:
         attach_synthetic_encoders(pipe)
+    if fp_mode:
+        pipe.unet.set_frame_parallel(FrameParallel())
     inverse_scheduler = DDIMInverseScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
     ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
     video_dir = template_config.video_dir
@@ -66,13 +74,19 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
     for config_entry in configs_list:
         if config_entry["active"] is False:
             logger.info(f"Skipping config_entry: {config_entry}")
-    for config_entry in shard_entries(configs_list, rank, world):
+    for config_entry in shard_entries(configs_list, e_rank, e_world):
         entry_idx = all_active.index(config_entry)
         logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
         config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
         config.video_path = os.path.join(config.video_dir, config.video_name + ".mp4")
         config.video_frames_path = os.path.join(config.video_dir, config.video_name)
-        if os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False):
+        skip = os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False)
+        if fp_mode:  # all ranks must take the same decision, before rank 0 starts writing into that directory
+            import torch.distributed as dist
+            flag = [skip]
+            dist.broadcast_object_list(flag, src=0)
+            skip = flag[0]
+        if skip:
             logger.info(f"### Skipping !!! {config.output_dir} already exists. ")
             continue
         logger.info(f"config: {OmegaConf.to_yaml(config)}")
@@ -92,9 +106,9 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         if config.inverse_config.null_image_inversion:
             logger.info("### Inverse a null image!")
             first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
-        seed_everything(seed_for_entry(template_config.seed, entry_idx) if world > 1 else template_config.seed)
+        seed_everything(seed_for_entry(template_config.seed, entry_idx) if e_world > 1 else template_config.seed)
         g = torch.Generator().manual_seed(template_config.seed)
-        ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, inverse_scheduler, g)
+        ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, inverse_scheduler, g, write=writer)
         recon_config = config.recon_config
         if recon_config.enable_recon:
             t_idx = recon_config.ddim_init_latents_t_idx
@@ -104,10 +118,11 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             traj = pipe._last_trajectory
             ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
             reconstructed_video = ddim_sampling(recon_config, first_frame, ddim_latents_at_t, pipe, ddim_scheduler, t_idx, g)
-            os.makedirs(config.output_dir, exist_ok=True)
-            reconstructed_video = [f.resize((512, 512), resample=Image.LANCZOS) for f in reconstructed_video]
-            export_to_gif(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.gif"), fps=10)
-            logger.info(f"Saved reconstructed video to {config.output_dir}")
+            if writer:
+                os.makedirs(config.output_dir, exist_ok=True)
+                reconstructed_video = [f.resize((512, 512), resample=Image.LANCZOS) for f in reconstructed_video]
+                export_to_gif(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.gif"), fps=10)
+                logger.info(f"Saved reconstructed video to {config.output_dir}")
         pipe._last_trajectory.wait()
 
 
@@ -117,6 +132,8 @@ def cli(argv=None):
     parser.add_argument("--configs_json", type=str, default="./configs/group_config.json")
     parser.add_argument("--synthetic_encoders", action="store_true",
                         help="use the weight-free stand-ins for VAE/CLIP (no pretrained weights offline)")
+    parser.add_argument("--frame_parallel", action="store_true",
+                        help="under torchrun: shard every clip's frames over the ranks instead of dealing clips to ranks")
     parser.add_argument("--random_init_seed", type=int, default=None, help="random UNet weights (no checkpoint offline)")
     args = parser.parse_args(argv)
     template_config = OmegaConf.load(args.template_config)
@@ -135,7 +152,7 @@ def cli(argv=None):
         torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
     seed_everything(template_config.seed)
-    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed)
+    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed, args.frame_parallel)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ from PIL import Image
 
 from .config import OmegaConf
 from .encoders import attach_synthetic_encoders
-from .parallel import gather_latents, init_distributed, seed_for_entry, shard_entries
+from .parallel import FrameParallel, gather_latents, init_distributed, seed_for_entry, shard_entries
 from .pipeline import I2VGenXLPipeline
 from .pnp_utils import register_conv_injection, register_spatial_attention_pnp, register_temp_attention_pnp
 from .schedulers import DDIMScheduler
@@ -53,20 +53,27 @@ def output_suffix(config, ddim_init_latents_t_idx) -> str:
             + str(config.pnp_temp_attn_t))
 
 
-def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None):
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False):
     rank, local_rank, world = init_distributed()
+    # --frame_parallel (long clips): every rank works on EVERY entry, the clip's frames sharded over
+    # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
+    fp_mode = bool(frame_parallel) and world > 1
+    writer = rank == 0 or not fp_mode
+    e_rank, e_world = (0, 1) if fp_mode else (rank, world)
     pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
                                             variant="fp16", random_init_seed=random_init_seed)
     pipe.to(device)
     if synthetic_encoders:
         attach_synthetic_encoders(pipe)
+    if fp_mode:
+        pipe.unet.set_frame_parallel(FrameParallel())
     ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
     all_active = [e for e in configs_list if e["active"] is not False]
     for config_entry in configs_list:
         if config_entry["active"] is False:
             logger.info(f"Skipping config_entry: {config_entry}")
     last_latents, lat_shape = None, None
-    for config_entry in shard_entries(configs_list, rank, world):
+    for config_entry in shard_entries(configs_list, e_rank, e_world):
         entry_idx = all_active.index(config_entry)
         logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
         config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
@@ -95,7 +102,7 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         traj = LatentTrajectory.load(config.ddim_latents_path, device=device,
                                      timesteps=[int(t) for t in ddim_scheduler.timesteps[t_idx:]])
         ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
-        seed_everything(seed_for_entry(template_config.seed, entry_idx) if world > 1 else template_config.seed)
+        seed_everything(seed_for_entry(template_config.seed, entry_idx) if e_world > 1 else template_config.seed)
         random_latents = torch.randn(ddim_latents_at_t.shape, dtype=torch.float32).to(ddim_latents_at_t)  # drawn even if unused (:124)
         logger.info(f"Blending random_ratio (1 means random latent): {config.random_ratio}")
         mixed_latents = random_latents * config.random_ratio + ddim_latents_at_t * (1 - config.random_ratio)
@@ -110,6 +117,8 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             ddim_inv_latents_path=traj, ddim_inv_prompt=config.ddim_inv_prompt, ddim_inv_1st_frame=src_1st_frame,
             output_type="latent").frames
         last_latents, lat_shape = edited_latents, tuple(edited_latents.shape)
+        if not writer:
+            continue
         video = pipe.decode_latents(edited_latents, decode_chunk_size=1)
         edited_video = pipe.vae.to_pil(video)
 
@@ -123,7 +132,10 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             frame.save(os.path.join(output_dir, f"{name}_{i:05d}.png"))
         torch.save(edited_latents.cpu(), os.path.join(output_dir, "edited_latents.pt"))
 
-    if world > 1:
+    if fp_mode:
+        import torch.distributed as dist
+        dist.barrier()
+    elif world > 1:
         import torch.distributed as dist
         shape = lat_shape or (1, 4, template_config.n_frames, template_config.image_size[1] // 8, template_config.image_size[0] // 8)
         gathered = gather_latents(last_latents, shape, torch.float16, device)
@@ -140,6 +152,8 @@ def cli(argv=None):
     parser.add_argument("--configs_json", type=str, default="./configs/group_config.json")
     parser.add_argument("--synthetic_encoders", action="store_true")
     parser.add_argument("--random_init_seed", type=int, default=None)
+    parser.add_argument("--frame_parallel", action="store_true",
+                        help="under torchrun: shard every clip's frames over the ranks instead of dealing entries to ranks")
     args = parser.parse_args(argv)
     template_config = OmegaConf.load(args.template_config)
     logging_level = logging.DEBUG if template_config.debug else logging.INFO
@@ -157,7 +171,7 @@ def cli(argv=None):
         torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
     seed_everything(template_config.seed)
-    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed)
+    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed, args.frame_parallel)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,27 @@ class I2VGenXLUNetConfig:
         return self.block_out_channels[0] * 4
 
     @staticmethod
+    def from_json(path: str) -> "I2VGenXLUNetConfig":
+        """``<checkpoint>/unet/config.json`` as diffusers writes it (``I2VGenXLUNet.register_to_config``); unknown keys
+        (``_class_name``, ``num_attention_heads`` -- which diffusers itself overrides with attention_head_dim) are ignored."""
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        kw = {}
+        for k in ("in_channels", "out_channels", "layers_per_block", "norm_num_groups", "cross_attention_dim", "sample_size"):
+            if d.get(k) is not None:
+                kw[k] = int(d[k])
+        for k in ("block_out_channels", "down_block_types", "up_block_types"):
+            if d.get(k) is not None:
+                kw[k] = tuple(d[k])
+        if d.get("attention_head_dim") is not None:
+            ahd = d["attention_head_dim"]
+            kw["attention_head_dim"] = int(ahd[0] if isinstance(ahd, (list, tuple)) else ahd)
+        if d.get("transformer_in_heads") is not None:  # (not a diffusers key: diffusers hard-codes 8; mini checkpoints set it)
+            kw["transformer_in_heads"] = int(d["transformer_in_heads"])
+        return I2VGenXLUNetConfig(**kw)
+
+    @staticmethod
     def mini() -> "I2VGenXLUNetConfig":
         return I2VGenXLUNetConfig(block_out_channels=(64, 128, 256, 256), cross_attention_dim=128,
                                   transformer_in_heads=2, sample_size=8)
@@ -384,10 +405,13 @@ class TransformerTemporalModel(nn.Module):
         self.proj_out = Linear(inner, in_channels)
 
     def run(self, ctx, x, H, W):
-        HW = H * W
+        fp = getattr(ctx, "fp", None)   # frame-parallel clip: re-shard frames -> pixels around the layer (parallel.py)
+        return self._run(ctx, x, H * W, None) if fp is None else fp.temporal(ctx, x, H * W, self._run)
+
+    def _run(self, ctx, x, HW, shard):
         # 5-D GroupNorm: statistics over all frames of a clip
         h = ops.groupnorm(x, self.norm.weight, self.norm.bias, ctx.stats, ctx.F * HW, groups=self.norm.num_groups,
-                          eps=self.norm.eps)
+                          eps=self.norm.eps, shard=shard)
         h = ops.gemm(h, self.proj_in.weight, bias=self.proj_in.bias)
         geom = Geom("temporal", ctx.B, ctx.F, HW)
         for blk in self.transformer_blocks:
@@ -466,12 +490,16 @@ class TemporalConvLayer(nn.Module):
         self.conv4 = nn.Sequential(GroupNorm(groups, dim), SiLU(), Identity(), Conv3dTemporal(dim, dim))
 
     def run(self, ctx, x, H, W):
-        HW = H * W
+        fp = getattr(ctx, "fp", None)
+        return self._run(ctx, x, H * W, None) if fp is None else fp.temporal(ctx, x, H * W, self._run)
+
+    def _run(self, ctx, x, HW, shard):
         h = x
         seqs = (self.conv1, self.conv2, self.conv3, self.conv4)
         for i, seq in enumerate(seqs):
             gn, conv = seq[0], seq[-1]
-            h = ops.groupnorm(h, gn.weight, gn.bias, ctx.stats, ctx.F * HW, groups=gn.num_groups, eps=gn.eps, silu=True)
+            h = ops.groupnorm(h, gn.weight, gn.bias, ctx.stats, ctx.F * HW, groups=gn.num_groups, eps=gn.eps, silu=True,
+                              shard=shard)
             h = ops.gemm(h, conv._w, bias=conv.bias, mode=MODE_TEMPORAL, temporal=(ctx.F, HW),
                          residual=x if i == 3 else None)
         return h
@@ -638,6 +666,13 @@ class I2VGenXLUNet(nn.Module):
         self.conv_out = Conv2d(boc[0], cfg.out_channels, 3, padding=1)
         self._packed = False
         self._ctx = _Ctx()
+        self.frame_parallel = None
+
+    def set_frame_parallel(self, fp):
+        """Shard ONE clip's frames over the ranks of ``fp`` (``anyv2v_amd.parallel.FrameParallel``; None = off).  Inputs
+        and outputs of ``forward`` stay full-size and replicated; only the activations are sharded."""
+        self.frame_parallel = fp
+        self._ctx = _Ctx()
 
     # ----------------------------------------------------------------------------------- weights
     @property
@@ -692,6 +727,9 @@ class I2VGenXLUNet(nn.Module):
             return ctx
         ctx = _Ctx()
         ctx.B, ctx.F, ctx.H, ctx.W = B, F, H, W
+        ctx.fp = fp = self.frame_parallel
+        if fp is not None:
+            fp.check(F, H, W, len(cfg.block_out_channels))
         HW = H * W
         T = B * F * HW
         ctx.stats = torch.empty(ops.gn_scratch_floats(B * F, 1, cfg.norm_num_groups), dtype=torch.float32, device=dev)
@@ -748,6 +786,12 @@ class I2VGenXLUNet(nn.Module):
                       head_dim=a.dim_head)
         h = ops.gemm(o, a.to_out[0].weight, bias=a.to_out[0].bias, residual=h)
         h = enc.ff.run(h, residual=h)
+        if fp is not None:
+            # frame-parallel clip: the (cheap, <= 16-channel) image-latents branch above ran replicated on all frames
+            # because its temporal encoder attends over them; from here on this rank owns frames [f0, f1)
+            f0, f1 = fp.frames(F)
+            h = h.view(B, F, HW, -1)[:, f0:f1].reshape(B * (f1 - f0) * HW, -1).contiguous()
+            ctx.F, T = f1 - f0, B * (f1 - f0) * HW
         ctx.xin = torch.zeros((T, PAD_CIN), dtype=torch.float16, device=dev)
         ops.copy_cols(h, 0, ctx.xin, cfg.in_channels, cfg.in_channels)
         ctx.key = key
@@ -776,6 +820,10 @@ class I2VGenXLUNet(nn.Module):
         (sample, t) -- this is what the pipeline captures into a HIP graph."""
         cfg = self.cfg
         B, C, F, H, W = sample.shape
+        fp = ctx.fp
+        if fp is not None:  # frame-parallel clip: this rank's frames of the (replicated, 4-channel) latents
+            f0, f1 = fp.frames(F)
+            sample, F = sample[:, :, f0:f1].contiguous(), f1 - f0
         # time embedding (+ fps) -> SiLU -> all 22 time_emb_proj at once
         te = ops.timestep_embedding(ctx.t_buf, cfg.block_out_channels[0])
         te = ops.gemm(te, self.time_embedding["linear_1"].weight, bias=self.time_embedding["linear_1"].bias, act=ACT_SILU)
@@ -810,6 +858,8 @@ class I2VGenXLUNet(nn.Module):
                           groups=self.conv_norm_out.num_groups, eps=self.conv_norm_out.eps, silu=True)
         vtok = torch.empty((x.shape[0], 8), dtype=torch.float16, device=x.device)
         self.conv_out.tokens(x, H, W, out=vtok)
+        if fp is not None:
+            vtok = fp.gather_frames(vtok, B, F, H * W)  # every rank steps the full latents (identically)
         return vtok
 
     def forward(self, sample, timestep, fps=None, image_latents=None, image_embeddings=None,

@@ -84,6 +84,18 @@ int anyv2v_groupnorm_f16(const void* X0, const void* X1, int32_t C0, int32_t C1,
                          const void* beta, float* stats, int32_t M, int32_t rows_per_group, int32_t G, float eps,
                          int32_t silu, void* stream);
 
+/* Sharded 5-D GroupNorm, for a clip whose frames / pixels are split over `shards` ranks (the 128-frame mode,
+ * gradio_demo.py:129-131; every rank holds the same local shape).  Phase 1 writes this rank's partial sums into
+ * `stats`; the caller adds the first anyv2v_groupnorm_partial_floats(M, rows_per_group, G, C0 + C1) floats over the
+ * ranks (one all-reduce SUM: RCCL on the node); phase 2 normalises with shards x the local element count.
+ * partial + apply(shards = 1) on one rank is exactly anyv2v_groupnorm_f16. */
+int64_t anyv2v_groupnorm_partial_floats(int32_t M, int32_t rows_per_group, int32_t G, int32_t C);
+int anyv2v_groupnorm_partial_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, float* stats, int32_t M,
+                                 int32_t rows_per_group, int32_t G, void* stream);
+int anyv2v_groupnorm_apply_f16(const void* X0, const void* X1, int32_t C0, int32_t C1, void* Y, const void* gamma,
+                               const void* beta, const float* stats, int32_t M, int32_t rows_per_group, int32_t G,
+                               float eps, int32_t silu, int32_t shards, void* stream);
+
 /* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3). */
 int anyv2v_layernorm_f16(const void* X, void* Y, const void* gamma, const void* beta, int32_t M, int32_t C,
                          float eps, void* stream);

@@ -82,11 +82,25 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rowvec_div=0, residual=None,
     return out
 
 
-def groupnorm(x0, gamma, beta, stats, rows_per_group, *, x1=None, groups=32, eps=1e-5, silu=False, out=None):
+def groupnorm(x0, gamma, beta, stats, rows_per_group, *, x1=None, groups=32, eps=1e-5, silu=False, out=None, shard=None):
     x = x0.float() if x1 is None else torch.cat([x0.float(), x1.float()], 1)
     M, C = x.shape
     n = M // rows_per_group
-    y = F.group_norm(x.view(n, rows_per_group, C).permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)
+    if shard is not None:  # two-phase contract of anyv2v_groupnorm_partial_f16 / _apply_f16: sums -> all-reduce -> apply
+        shards, all_reduce_sum = shard
+        xg = x.view(n, rows_per_group, groups, C // groups)
+        sums = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1).contiguous()  # [n, G, 2]
+        buf = stats[: sums.numel()]
+        buf.copy_(sums.reshape(-1))
+        all_reduce_sum(buf)
+        sums = buf.view(n, groups, 2)
+        cnt = rows_per_group * (C // groups) * shards
+        mean = sums[..., 0] / cnt
+        rstd = torch.rsqrt((sums[..., 1] / cnt - mean * mean).clamp_min(0) + eps)
+        y = ((xg - mean[:, None, :, None]) * rstd[:, None, :, None]).reshape(n, rows_per_group, C)
+        y = (y * gamma.float() + beta.float()).permute(0, 2, 1)
+    else:
+        y = F.group_norm(x.view(n, rows_per_group, C).permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)
     if silu:
         y = F.silu(y)
     y = _h(y.permute(0, 2, 1).reshape(M, C))

@@ -857,3 +857,80 @@ def check_vae(full: bool = True):
 
 ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_splitk, check_conv, check_norms, check_attention, check_elementwise,
                      check_full_size_properties, check_vae_kernels]
+
+
+def check_frame_parallel(Fr=4, hw=16, tol=4e-3):
+    """Frame-parallel clip (``anyv2v_amd.parallel.FrameParallel``): called on every rank of an
+    initialised process group; the sharded forward must reproduce this rank's own unsharded forward (same kernels, same
+    weights; only the order of the fp32 additions inside the 5-D GroupNorm statistics differs), with and without the
+    PnP hooks and the shared stem, and leave the pipeline untouched."""
+    import types
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.parallel import FrameParallel
+    out = []
+    fp = FrameParallel()
+    native, _, ocfg = build_pair("mini", 1234)
+    for B in (1, 3):
+        inp = config1_inputs(ocfg, B, Fr, hw)
+        if B == 3:  # the edit loop's batch: slots 1 and 2 share latent and image latents (shared stem allowed)
+            inp["sample"][2] = inp["sample"][1]
+            inp["image_latents"][2] = inp["image_latents"][1]
+        smp = inp["sample"].half().to(DEV)
+        kw = dict(fps=inp["fps"].to(DEV), image_latents=inp["image_latents"].half().to(DEV),
+                  image_embeddings=inp["image_embeddings"].half().to(DEV),
+                  encoder_hidden_states=inp["encoder_hidden_states"].half().to(DEV))
+        cases = [("no hooks", 981, False)]
+        if B == 3:
+            ts = [981 - 20 * i for i in range(50)]
+            pipe = types.SimpleNamespace(unet=native)
+            pnp_utils.register_conv_injection(pipe, ts[:10])
+            pnp_utils.register_spatial_attention_pnp(pipe, ts[:25])
+            pnp_utils.register_temp_attention_pnp(pipe, ts[:40])
+            cases = [("PnP all sites", 981, False), ("PnP temporal only + shared stem", 301, True), ("PnP off", 1, True)]
+        for name, t, shared in cases:
+            if B == 3:
+                pnp_utils.register_time(pipe, t)
+            res = []
+            for use_fp in (None, fp):
+                native.set_frame_parallel(use_fp)
+                native.forward_tokens(smp, t, kw["fps"], kw["image_latents"], kw["image_embeddings"], kw["encoder_hidden_states"])
+                native._ctx.shared_stem = shared
+                res.append(native(smp, t, **kw)[0].float().cpu())
+            out.append(_res(f"frame-parallel x{fp.world} rank {fp.rank}: B{B} {name} vs unsharded", res[1], res[0], tol))
+    # the pipeline loops on top (unchanged code: every rank steps the full, replicated latents): 4-step inversion, then
+    # a 4-step PnP edit with schedules that end early (so the 2-branch steps are covered too)
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    inp = config1_inputs(ocfg, 3, Fr, hw)
+    h = lambda x: x.half().to(DEV)
+    lat0, ehs, ie, il = h(inp["sample"][:1]), h(inp["encoder_hidden_states"]), h(inp["image_embeddings"]), h(inp["image_latents"])
+    n_steps, finals = 4, []
+    for use_fp in (None, fp):
+        native.set_frame_parallel(use_fp)
+        pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+        pipe._device = torch.device(DEV)
+        traj = pipe.invert(prompt_embeds=ehs[:1], image_embeddings=ie[:1], image_latents=il[:1], height=hw * 8, width=hw * 8,
+                           num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0, target_fps=8, latents=lat0,
+                           return_trajectory=True)
+        T = max(traj.keys())
+        sched = DDIMScheduler()
+        sched.set_timesteps(n_steps)
+        pnp_utils.register_conv_injection(pipe, sched.timesteps[:1])
+        pnp_utils.register_spatial_attention_pnp(pipe, sched.timesteps[:2])
+        pnp_utils.register_temp_attention_pnp(pipe, sched.timesteps[:3])
+        pipe.register_modules(scheduler=sched)
+        res = pipe.sample_with_pnp(prompt_embeds=ehs[2:3], negative_prompt_embeds=ehs[1:2], image_embeddings=ie[2:3],
+                                   image_latents=il[2:3], height=hw * 8, width=hw * 8, num_frames=Fr,
+                                   num_inference_steps=n_steps, guidance_scale=9.0, target_fps=8, latents=traj[T].clone(),
+                                   output_type="latent", ddim_init_latents_t_idx=0, ddim_inv_latents_path=traj,
+                                   ddim_inv_prompt_embeds=ehs[:1], ddim_inv_image_embeddings=ie[:1],
+                                   ddim_inv_image_latents=il[:1]).frames
+        finals.append((traj[T].float().cpu(), res.float().cpu()))
+        pnp_utils.clear_time(pipe)
+    out.append(_res(f"frame-parallel rank {fp.rank}: pipeline.invert {n_steps} steps vs unsharded", finals[1][0], finals[0][0], 2e-2))
+    out.append(_res(f"frame-parallel rank {fp.rank}: pipeline.sample_with_pnp {n_steps} steps vs unsharded", finals[1][1],
+                    finals[0][1], 4e-2))
+    native.set_frame_parallel(None)
+    out.append({"name": f"frame-parallel rank {fp.rank}: all-to-all payload > 0", "err": 0.0 if fp.bytes_moved > 0 else 1.0,
+                "tol": 0.5, "ok": fp.bytes_moved > 0})
+    return out

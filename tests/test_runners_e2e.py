@@ -1,0 +1,139 @@
+"""End-to-end CLI runners on CPU (TEST-ONLY op emulation): stage 1 ``run_group_ddim_inversion`` -> stage 2
+``run_group_pnp_edit`` on a tiny synthetic clip with a mini UNet checkpoint (``unet/config.json`` + safetensors in diffusers
+key naming) and the weight-free stand-in encoders.  Checks the on-disk formats the reference uses on either side of the hot
+path (``ddim_latents_{t}.pt``, PNG frame dirs, GIF) and that ``--frame_parallel`` under a world_size-2
+gloo group (F3) reproduces the single-process outputs with rank 0 as the only writer."""
+import json
+import logging
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_FRAMES, SIZE, N_STEPS = 4, 128, 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_workspace(base):
+    """<base>/model (mini checkpoint), <base>/demo/<clip> (PNG frames + edited first frame), configs."""
+    sys.path.insert(0, ROOT)
+    from safetensors.torch import save_file
+    from oracle.unet_oracle import UNetConfig, random_state_dict
+    base = str(base)
+    os.makedirs(os.path.join(base, "model", "unet"), exist_ok=True)
+    sd = {k: v.half().contiguous() for k, v in random_state_dict(UNetConfig.mini(), 1234).items()}
+    save_file(sd, os.path.join(base, "model", "unet", "diffusion_pytorch_model.fp16.safetensors"))
+    json.dump({"_class_name": "I2VGenXLUNet", "block_out_channels": [64, 128, 256, 256], "cross_attention_dim": 128,
+               "attention_head_dim": 64, "in_channels": 4, "out_channels": 4, "layers_per_block": 2, "norm_num_groups": 32,
+               "sample_size": 8, "transformer_in_heads": 2}, open(os.path.join(base, "model", "unet", "config.json"), "w"))
+    clip = os.path.join(base, "demo", "clip")
+    os.makedirs(os.path.join(clip, "edited_first_frame"), exist_ok=True)
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:SIZE, 0:SIZE]
+    for i in range(N_FRAMES):
+        img = np.stack([(xx * 2 + 10 * i) % 256, (yy * 2) % 256, ((xx + yy) + 30 * i) % 256], -1).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(clip, f"{i:05d}.png"))
+    Image.fromarray(rng.integers(0, 255, (SIZE, SIZE, 3), dtype=np.uint8)).save(os.path.join(clip, "edited_first_frame", "e.png"))
+    return base
+
+
+def _configs(base, tag):
+    from anyv2v_amd.config import OmegaConf
+    inv = OmegaConf.load(os.path.join(ROOT, "configs", "group_ddim_inversion", "template.yaml"))
+    ed = OmegaConf.load(os.path.join(ROOT, "configs", "group_pnp_edit", "template.yaml"))
+    for c in (inv, ed):
+        c.device, c.data_dir, c.model_path = "cpu", base, os.path.join(base, "model")
+        c.image_size, c.n_frames, c.model_name = [SIZE, SIZE], N_FRAMES, f"mini-{tag}"
+    inv.inverse_config.n_steps = N_STEPS
+    inv.recon_config.n_steps = N_STEPS
+    inv.recon_config.ddim_init_latents_t_idx = 0
+    ed.n_steps, ed.ddim_init_latents_t_idx = N_STEPS, 0
+    inv_list = [{"active": True, "force_recompute_latents": False, "video_name": "clip", "recon_config": {"enable_recon": True}},
+                {"active": False, "video_name": "unused"}]
+    ed_list = [{"active": True, "task_name": "Prompt-Based-Editing", "video_name": "clip",
+                "edited_first_frame_path": "demo/clip/edited_first_frame/e.png", "editing_prompt": "a robot",
+                "edited_video_name": "robot", "ddim_init_latents_t_idx": 0, "pnp_f_t": 0.25, "pnp_spatial_attn_t": 0.5,
+                "pnp_temp_attn_t": 0.75}]
+    return inv, inv_list, ed, ed_list
+
+
+def _run_both_stages(base, tag, frame_parallel=False):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_emulation as emu
+    emu.install()
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    from anyv2v_amd import run_group_ddim_inversion as s1, run_group_pnp_edit as s2
+    from anyv2v_amd.utils import seed_everything
+    inv, inv_list, ed, ed_list = _configs(base, tag)
+    log = logging.getLogger("e2e")
+    dev = torch.device("cpu")
+    seed_everything(inv.seed)
+    s1.main(inv, inv_list, dev, log, synthetic_encoders=True, frame_parallel=frame_parallel)
+    seed_everything(ed.seed)
+    s2.main(ed, ed_list, dev, log, synthetic_encoders=True, frame_parallel=frame_parallel)
+
+
+def _outputs(base, tag):
+    inv_dir = os.path.join(base, "inversions", f"mini-{tag}", "clip")
+    res_root = os.path.join(base, "Results", "Prompt-Based-Editing", f"mini-{tag}", "clip", "robot")
+    sub = os.listdir(res_root)
+    assert len(sub) == 1
+    return inv_dir, os.path.join(res_root, sub[0])
+
+
+def test_stage1_stage2_file_formats(tmp_path):
+    base = _make_workspace(tmp_path)
+    _run_both_stages(base, "single")
+    inv_dir, out_dir = _outputs(base, "single")
+    lat_files = sorted(os.listdir(os.path.join(inv_dir, "ddim_latents")))
+    assert len(lat_files) == N_STEPS and all(f.startswith("ddim_latents_") and f.endswith(".pt") for f in lat_files)
+    x = torch.load(os.path.join(inv_dir, "ddim_latents", lat_files[0]))
+    assert tuple(x.shape) == (1, 4, N_FRAMES, SIZE // 8, SIZE // 8) and torch.isfinite(x.float()).all()
+    assert os.path.isfile(os.path.join(inv_dir, "ddim_reconstruction.gif"))
+    assert "ddim_init_latents_t_idx_0_nsteps_4_cfg_9.0_pnpf0.25_pnps0.5_pnpt0.75" == os.path.basename(out_dir)
+    names = sorted(os.listdir(out_dir))
+    assert "video.gif" in names and "edited_latents.pt" in names
+    assert [n for n in names if n.endswith(".png")] == [f"video_{i:05d}.png" for i in range(N_FRAMES)]
+    lat = torch.load(os.path.join(out_dir, "edited_latents.pt"))
+    assert tuple(lat.shape) == (1, 4, N_FRAMES, SIZE // 8, SIZE // 8) and torch.isfinite(lat.float()).all()
+    with Image.open(os.path.join(out_dir, "video.gif")) as g:
+        assert g.n_frames == N_FRAMES and g.size == (SIZE, SIZE)
+    # stage 1 is skipped when its output exists (reference behaviour, run_group_ddim_inversion.py:118-120)
+    mtime = os.path.getmtime(os.path.join(inv_dir, "ddim_latents", lat_files[0]))
+    _run_both_stages(base, "single")
+    assert os.path.getmtime(os.path.join(inv_dir, "ddim_latents", lat_files[0])) == mtime
+
+
+def _fp_worker(rank, world, port, base):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    _run_both_stages(base, "fp", frame_parallel=True)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_frame_parallel_runners_world2_match_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    base = _make_workspace(tmp_path)
+    _run_both_stages(base, "single")
+    mp.spawn(_fp_worker, args=(2, _free_port(), base), nprocs=2, join=True)
+    (inv_a, out_a), (inv_b, out_b) = _outputs(base, "single"), _outputs(base, "fp")
+    fa, fb = sorted(os.listdir(os.path.join(inv_a, "ddim_latents"))), sorted(os.listdir(os.path.join(inv_b, "ddim_latents")))
+    assert fa == fb and len(fa) == N_STEPS
+    for f in fa:
+        a, b = torch.load(os.path.join(inv_a, "ddim_latents", f)).float(), torch.load(os.path.join(inv_b, "ddim_latents", f)).float()
+        assert (a - b).abs().max() <= 2e-2 * a.abs().max(), f
+    a, b = torch.load(os.path.join(out_a, "edited_latents.pt")).float(), torch.load(os.path.join(out_b, "edited_latents.pt")).float()
+    assert (a - b).abs().max() <= 5e-2 * a.abs().max()
+    assert sorted(os.listdir(out_a)) == sorted(os.listdir(out_b))
