@@ -375,6 +375,21 @@ def check_norms():
     xc = torch.cat([x0, x1], 1).float().view(B, Fr * hw, c0 + c1).permute(0, 2, 1)
     ref = F.silu(F.group_norm(xc, 32, ga.float(), be.float(), 1e-5)).permute(0, 2, 1).reshape(B * Fr * hw, c0 + c1)
     out.append(_res("groupnorm 5-D two-source silu", y, ref, 4e-3))
+    # sharded statistics (frame-parallel clips): partial + apply(shards=1) IS the one-call kernel pair (bit-identical);
+    # a clip split into two pixel halves, partial sums added as the all-reduce would, equals the unsharded result
+    y1 = ops.groupnorm(x0, ga, be, stats, Fr * hw, x1=x1, groups=32, eps=1e-5, silu=True, shard=(1, lambda t: t))
+    out.append(_res("groupnorm two-phase (shards=1) == one call", y1, y.float(), 0.0 if DEV != "cpu" else 2e-3))
+    xs = x0.view(B, Fr, hw, c0)
+    halves = [xs[:, :, i * hw // 2:(i + 1) * hw // 2].reshape(-1, c0).contiguous() for i in range(2)]
+    ga0, be0 = ga[:c0].contiguous(), be[:c0].contiguous()
+    full = ops.groupnorm(x0, ga0, be0, stats, Fr * hw, groups=32, eps=1e-5, silu=True).view(B, Fr, hw, c0)
+    st = [torch.zeros_like(stats) for _ in range(2)]
+    ops.groupnorm(halves[1], ga0, be0, st[1], Fr * hw // 2, groups=32, silu=True, shard=(1, lambda t: t))  # rank 1's sums
+    other = st[1].clone()
+    got = ops.groupnorm(halves[0], ga0, be0, st[0], Fr * hw // 2, groups=32, eps=1e-5, silu=True,
+                        shard=(2, lambda t: t.add_(other[:t.numel()])))
+    out.append(_res("groupnorm sharded over 2 pixel halves vs unsharded", got,
+                    full[:, :, :hw // 2].reshape(-1, c0).float(), 2e-3))
     for (m, c) in [(1000, 320), (77, 1280), (333, 512), (50, 4), (64, 64)]:
         x = rnd(m, c) * 2 + 0.3
         ga, be = rnd(c) + 1.0, rnd(c)
