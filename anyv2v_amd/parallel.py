@@ -141,6 +141,21 @@ class FrameParallel:
         full = torch.stack([p.view(B, Fl, HW, C) for p in parts], 1)                  # [B, N, Fl, HW, C]
         return full.reshape(B * N * Fl * HW, C)
 
+    def gather_video(self, video: torch.Tensor) -> torch.Tensor:
+        """Decoded frames [1,3,F/world,H,W] (host fp32, as ``decode_video`` returns them) -> the whole clip on every rank."""
+        parts = [torch.empty_like(video) for _ in range(self.world)]
+        if self.host_staged or not video.is_cuda:
+            if self.host_staged:
+                self.dist.all_gather(parts, video.contiguous(), group=self.group)
+            else:  # RCCL moves device buffers: stage the (host) frames through HBM
+                dev = torch.device("cuda", torch.cuda.current_device())
+                dparts = [torch.empty(video.shape, dtype=video.dtype, device=dev) for _ in range(self.world)]
+                self.dist.all_gather(dparts, video.to(dev).contiguous(), group=self.group)
+                parts = [p.cpu() for p in dparts]
+        else:
+            self.dist.all_gather(parts, video.contiguous(), group=self.group)
+        return torch.cat(parts, 2)
+
     # ---- the wrapper the temporal layers call
     def temporal(self, ctx, x: torch.Tensor, HW: int, body):
         """``body(ctx_t, x_pixels, HW_local, shard)`` runs the layer on the pixel-sharded tokens of ALL frames."""

@@ -254,6 +254,13 @@ class I2VGenXLPipeline:
 
     def decode_latents(self, latents, decode_chunk_size=None):
         vae = self._need("vae")
+        fp = getattr(self.unet, "frame_parallel", None)
+        if fp is not None and latents.shape[2] % fp.world == 0:
+            # frame-parallel clip: frames decode independently (``decode_chunk_size=1`` in the reference) -- every rank
+            # decodes its own frames, one all_gather of the decoded frames (12 MiB per 16 frames at 512^2)
+            f0, f1 = fp.frames(latents.shape[2])
+            mine = vae.decode_video(latents[:, :, f0:f1].contiguous(), decode_chunk_size)
+            return fp.gather_video(mine)
         return vae.decode_video(latents, decode_chunk_size)
 
     def prepare_latents(self, batch_size, num_channels_latents, num_frames, height, width, dtype, device, generator,

@@ -117,9 +117,9 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             ddim_inv_latents_path=traj, ddim_inv_prompt=config.ddim_inv_prompt, ddim_inv_1st_frame=src_1st_frame,
             output_type="latent").frames
         last_latents, lat_shape = edited_latents, tuple(edited_latents.shape)
+        video = pipe.decode_latents(edited_latents, decode_chunk_size=1)  # (frame-parallel: every rank decodes its frames)
         if not writer:
             continue
-        video = pipe.decode_latents(edited_latents, decode_chunk_size=1)
         edited_video = pipe.vae.to_pil(video)
 
         output_dir = os.path.join(config.output_dir, output_suffix(config, t_idx))

@@ -44,6 +44,15 @@ def test_abi_argument_validation_without_gpu():
     assert lib.anyv2v_gemm_f16(ctypes.byref(d), None) == -1
     assert b"bad mode" in lib.anyv2v_last_error()
     assert lib.anyv2v_layernorm_f16(None, None, None, None, 1, 1, 1e-5, None) == -1
+    # sharded GroupNorm pair (frame-parallel clips): same validation as the one-call entry point, plus `shards`
+    assert lib.anyv2v_groupnorm_partial_f16(None, None, 64, 0, None, 8, 8, 32, None) == -1
+    assert b"null pointer" in lib.anyv2v_last_error()
+    assert lib.anyv2v_groupnorm_partial_f16(16, None, 60, 0, 16, 8, 8, 32, None) == -1      # C0 % 8
+    assert lib.anyv2v_groupnorm_partial_f16(16, None, 64, 0, 16, 9, 8, 32, None) == -1      # M % rows_per_group
+    assert lib.anyv2v_groupnorm_apply_f16(16, None, 64, 0, 16, 16, 16, 16, 8, 8, 32, 1e-5, 0, 0, None) == -1
+    assert b"shards" in lib.anyv2v_last_error()
+    assert lib.anyv2v_groupnorm_partial_floats(8, 9, 32, 64) == -1 and lib.anyv2v_groupnorm_partial_floats(64, 8, 32, 64) == 8 * 32 * 2
+    assert lib.anyv2v_groupnorm_partial_floats(64, 8, 32, 64) <= lib.anyv2v_groupnorm_scratch_floats(64, 8, 32)
     with pytest.raises(_lib.HipKernelError):
         _lib.check(-1, "x")
 

@@ -52,6 +52,7 @@ def _run(tmp_path, device):
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.timeout(900)
 def test_frame_parallel_unet_world2_gloo_cpu(tmp_path):
     _run(tmp_path, "cpu")
 

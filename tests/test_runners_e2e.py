@@ -10,6 +10,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 from PIL import Image
 
@@ -123,6 +124,7 @@ def _fp_worker(rank, world, port, base):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(900)
 def test_frame_parallel_runners_world2_match_single_process(tmp_path):
     import torch.multiprocessing as mp
     base = _make_workspace(tmp_path)
