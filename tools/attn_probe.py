@@ -39,24 +39,25 @@ def attn_case(tag, N, h, S, iters, Sk=None, kv_div=1, qk_mod=0):
         kv = torch.randn((N // kv_div) * Sk, 2 * C, device=dev).half()
         fn = lambda: ops.attention(q[:, :C], kv[:, :C], kv[:, C:], o, batch=N, heads=h, Sq=S, Sk=Sk, inner=1,
                                    q_strides=(S, 0, 1), kv_strides=(Sk, 0, 1), kv_div=kv_div)
-    ms = timeit(fn, 2 if quick else iters, warm=1 if quick else 2)
+    ms = timeit(fn, iters, warm=2)
     tf = 4.0 * N * h * S * Sk * 64 / (ms * 1e-3) / 1e12
     lines.append(f"{tag:<40s} N={N:3d} h={h:2d} S={S:5d} Sk={Sk:5d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s")
     print(lines[-1], flush=True)
 
 
-for flags, name in ((0, "v2"), (8, "v2 pnp as aliasing"), (4, "v1 reg-staged")):
+for flags, name in ((0, "v3 pipelined"), (16, "v2"), (4, "v1 reg-staged")):
+    if quick and flags == 4:
+        continue
     ops.ATTN_FLAGS = flags
     attn_case(f"[{name}] spatial 64x64 B=3", 48, 5, 4096, 10)
-    if flags != 4:
-        attn_case(f"[{name}] spatial 64x64 B=3 PnP inject", 48, 5, 4096, 10, qk_mod=16)
-        attn_case(f"[{name}] spatial 32x32 B=3 PnP inject", 48, 10, 1024, 20, qk_mod=16)
-    if quick:
-        continue
     attn_case(f"[{name}] spatial 64x64 B=1", 16, 5, 4096, 10)
     attn_case(f"[{name}] spatial 32x32 B=3", 48, 10, 1024, 20)
     attn_case(f"[{name}] spatial 16x16 B=3", 48, 20, 256, 20)
     attn_case(f"[{name}] cross 64x64 Sk=145 B=3", 48, 5, 4096, 20, Sk=145, kv_div=16)
+for flags, name in ((0, "shared softmax"), (8, "v2 per-branch aliasing")):
+    ops.ATTN_FLAGS = flags
+    attn_case(f"[{name}] spatial 64x64 B=3 PnP inject", 48, 5, 4096, 10, qk_mod=16)
+    attn_case(f"[{name}] spatial 32x32 B=3 PnP inject", 48, 10, 1024, 20, qk_mod=16)
 ops.ATTN_FLAGS = 0
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
