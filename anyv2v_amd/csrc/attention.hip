@@ -285,34 +285,48 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     }
 
     // DMA assignment: instruction t (0,1), chunk slot = t*256 + tid -> row = slot >> 3, physical chunk = tid & 7.
-    // Source pointers advance by 64 keys per tile (incremental: no 64-bit multiplies in the loop).
+    // Wave-uniform tile pointers (SGPRs, advanced by scalar adds) + constant 32-bit per-lane byte offsets; only the
+    // ragged last tile needs the per-row test (wave-uniform branch), every other issue is bare DMA instructions.
     const int drow = tid >> 3, dpc = tid & 7;
     const int ntiles = (p.Sk + 63) / 64;
-    const half_t* kcur[2];
-    const half_t* vcur[NV][2];
+    const char* kptr = (const char*)(p.K + kbase * p.ldk + h * 64);
+    const char* vptr[NV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b) vptr[b] = (const char*)(p.V + vbase[b] * p.ldv + h * 64);
+    unsigned koff[2], voff_g[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int row = drow + 32 * t;
-        kcur[t] = p.K + (kbase + (long long)row * p.kv_seq) * p.ldk + h * 64 + ((dpc ^ ((row >> 1) & 7)) << 3);
-#pragma unroll
-        for (int b = 0; b < NV; ++b)
-            vcur[b][t] = p.V + (vbase[b] + (long long)row * p.kv_seq) * p.ldv + h * 64 + ((dpc ^ (row & 7)) << 3);
+        koff[t] = (unsigned)(((long long)row * p.kv_seq * p.ldk + ((dpc ^ ((row >> 1) & 7)) << 3)) * 2);
+        voff_g[t] = (unsigned)(((long long)row * p.kv_seq * p.ldv + ((dpc ^ (row & 7)) << 3)) * 2);
     }
-    const long long kstep = 64ll * p.kv_seq * p.ldk, vstep = 64ll * p.kv_seq * p.ldv;
+    const long long kstep = 128ll * p.kv_seq * p.ldk, vstep = 128ll * p.kv_seq * p.ldv;  // bytes per 64-key tile
+    const int w_s = __builtin_amdgcn_readfirstlane(w);  // wave index in an SGPR: the DMA's LDS base (m0) stays scalar
     int issue_key0 = 0;
     auto issue = [&](int stage) {
         char* st = smem + stage * STAGE_BYTES;
+        if (issue_key0 + 64 <= p.Sk) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bool ok = issue_key0 + drow + 32 * t < p.Sk;  // only the last tile can be ragged
-            glds16_attn(ok ? kcur[t] : zeros, st + (t * 256 + w * 64) * 16);
-            kcur[t] += kstep;
+            for (int t = 0; t < 2; ++t) {
+                glds16_attn((const half_t*)(kptr + koff[t]), st + (t * 256 + w_s * 64) * 16);
 #pragma unroll
-            for (int b = 0; b < NV; ++b) {
-                glds16_attn(ok ? vcur[b][t] : zeros, st + (1 + b) * TILE_BYTES + (t * 256 + w * 64) * 16);
-                vcur[b][t] += vstep;
+                for (int b = 0; b < NV; ++b)
+                    glds16_attn((const half_t*)(vptr[b] + voff_g[t]), st + (1 + b) * TILE_BYTES + (t * 256 + w_s * 64) * 16);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool ok = issue_key0 + drow + 32 * t < p.Sk;  // only the last tile can be ragged
+                glds16_attn(ok ? (const half_t*)(kptr + koff[t]) : zeros, st + (t * 256 + w_s * 64) * 16);
+#pragma unroll
+                for (int b = 0; b < NV; ++b)
+                    glds16_attn(ok ? (const half_t*)(vptr[b] + voff_g[t]) : zeros,
+                                st + (1 + b) * TILE_BYTES + (t * 256 + w_s * 64) * 16);
             }
         }
+        kptr += kstep;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) vptr[b] += vstep;
         issue_key0 += 64;
     };
 
@@ -334,6 +348,9 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     for (int db = 0; db < 2; ++db) voff[db] = vrow * 128 + (((4 * db + vc0) ^ vfl) << 4) + (i16 & 1) * 8;
 
     for (int t = 0; t < PRE && t < ntiles; ++t) issue(t);
+    // Q fragments must be complete BEFORE the loop: otherwise hipcc places their vmcnt wait at the first MFMA inside
+    // the loop, where it has to be vmcnt(0) and drains the DMA ring on every tile (seen in the .s)
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
     int stage = 0;
     for (int j = 0; j < ntiles; ++j) {
         const int ahead = ntiles - 1 - j;  // tiles issued after tile j that may still be in flight (<= PRE - 1)
@@ -383,21 +400,18 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            {  // cross-half maximum by v_permlane32_swap: VALU, no LDS-queue round trip (ds_bpermute) in the softmax
+                const unsigned mu = __float_as_uint(mx);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             const float m_new = fmaxf(m_run, mx);
-            const float mc = m_new * c;
-            float psum = 0.f;
-            h8 pf[4];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mc));  // raw v_exp_f32 (args <= 0)
-                    psum += pv;
-                    pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
-                }
-            // rescale only when some row's running max actually moved (exact; after the first few tiles it rarely does)
-            if (__any(m_new != m_run)) {
+            // Deferred rescale: the running maximum is only advanced (and O, l rescaled) when some row of the wave
+            // would otherwise see a probability above 2^8; until then P = exp2((s - m_run) c) is taken against the
+            // OLD maximum.  Softmax is shift-invariant, fp16 / fp32 are floating point, so the result only differs in
+            // the last bit of P's rounding -- but on random data the maximum moves in ~85 % of the 64 tiles and after
+            // the first tile almost never by 2^8, so 16 v_pk_mul + 1 v_exp per tile and wave disappear.
+            if (__any((m_new - m_run) * c > 8.0f)) {
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
                 l_run *= alpha;
 #pragma unroll
@@ -409,6 +423,17 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                     }
                 m_run = m_new;
             }
+            const float mc = m_run * c;
+            float psum = 0.f;
+            h8 pf[4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mc));  // raw v_exp_f32 (args <= 8)
+                    psum += pv;
+                    pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
+                }
             l_run += psum;
             // O^T += V^T P^T, one (branch, d-half) unit at a time; the next unit's transpose reads are in flight
             // while the current unit's 4 MFMAs run (two register sets, counted lgkmcnt)
@@ -455,21 +480,25 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// v3: the v2 data path (LDS-DMA rings, swapped MFMAs, hardware-transposed V^T fragments) with the KV loop software-
-// pipelined INSIDE each wave.  In v2 a wave runs QK^T (8 MFMAs) -> softmax (~150 VALU) -> PV (8 MFMAs) strictly in
-// sequence and relies on the other waves of its SIMD to fill the matrix pipe while it is on the VALU; measured, the two
-// phases add up instead of overlapping (~1280 cycles per wave and tile = 512 MFMA + ~770 VALU).  Here iteration j
-// carries three independent streams in one straight-line body:
+// v3 (EXPERIMENTAL, opt-in through flag bit5; kept as a measured negative result): the v2 data path (LDS-DMA rings,
+// swapped MFMAs, hardware-transposed V^T fragments) with the KV loop software-pipelined INSIDE each wave.  In v2 a wave
+// runs QK^T (8 MFMAs) -> softmax (~150 VALU) -> PV (8 MFMAs) strictly in sequence and relies on the other waves of its
+// SIMD to fill the matrix pipe while it is on the VALU.  Here iteration j carries three independent streams in one
+// straight-line body:
 //     VALU : softmax of tile j          (scores produced by the previous iteration)
 //     MFMA : O^T += V^T P^T of tile j-1 (probabilities produced by the previous iteration)
 //     MFMA : S^T  = K Q^T   of tile j+1
 // so every MFMA is issued with independent VALU work behind it in the same wave (sched_group_barrier interleave).
-// Costs: scores and probabilities are double-buffered in registers (2 x 32 + 2 x 16 VGPRs -> two waves per SIMD
-// instead of three), K needs tiles j+1..j+3 and V tiles j-1..j+2 resident, i.e. separate rings of 3 and 4 stages
+// Costs: scores and probabilities are double-buffered in registers (2 x 32 + 2 x 16 VGPRs -> 250 VGPRs, two waves per
+// SIMD instead of three), K needs tiles j+1..j+3 and V tiles j-1..j+2 resident, i.e. separate rings of 3 and 4 stages
 // (56 KiB per block, two blocks per CU).  All LDS reads are inline asm behind explicit lgkmcnt waits (V^T fragments
-// first, then K), the softmax uses packed fp32 math (v_pk_fma / v_pk_add / v_pk_mul) and v_permlane32_swap instead of
-// an LDS shuffle (no compiler-inserted lgkmcnt(0) in the body), and the O rescale is unconditional -- on random data
-// some row of the wave moves its maximum in ~85 % of the 64 tiles, the branch did not pay for itself.
+// first, then K), the cross-half maximum is v_permlane32_swap instead of an LDS shuffle (no compiler-inserted
+// lgkmcnt(0) in the body), and the O rescale is unconditional.
+// Measured (profiles/r01_attn_probe.txt, r01_issue_probe.txt): bit-compatible with v2 up to the row-sum order, but
+// 1.55 ms against v2's 1.30 ms at (48, 5, 4096, 64).  The microbenchmark explains it: on this part 16 MFMAs + the
+// softmax's ~160 VALU instructions cost ~470 ns per SIMD whether they are interleaved inside one wave or issued as
+// separate phases by three co-resident waves (MFMA alone 345 ns, VALU alone 290-315 ns; packed fp32 and dot
+// instructions do not overlap with MFMA at all), so the in-wave pipeline buys nothing and pays for its third wave.
 // Same products and accumulation order per output as v2; only the row sum is accumulated as two interleaved partials.
 // Requires Sq % 128 == 0 (every wave active); Sk arbitrary.
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -998,9 +1027,9 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
         hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<pnp3>");
     }
-    if (k.Sq % 128 == 0 && !(d->flags & (8 | 16))) {
-        // v3: in-wave software pipeline (flag bit4 forces v2; bit3's aliasing form stays on v2 so that it remains the
-        // bit-exact cross-check of the shared-softmax kernel)
+    if ((d->flags & 32) && k.Sq % 128 == 0 && !(d->flags & 8)) {
+        // experimental v3 (in-wave software pipeline): correct, but measured 15-20 % slower than v2 on MI355X -- see the
+        // kernel's header and profiles/r01_issue_probe.txt.  Opt-in through flag bit5.
         hipLaunchKernelGGL(flash_attn_d64_v3_kernel, dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v3");
     }

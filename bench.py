@@ -42,7 +42,7 @@ def synthetic_clip(device, seed):
     return lat, ehs, ie, il_all
 
 
-def measure_kernel(fn, iters=20, warm=3):
+def measure_kernel(fn, iters=20, warm=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

@@ -127,8 +127,8 @@ typedef struct AnyV2VAttnDesc {
     float scale;
     int32_t flags;      /* bit0: force the naive reference kernel; bit1: no short-sequence kernel; bit2: register-staged
                            v1 kernel; bit3: PnP launches (batch == 3 qk_mod) as per-branch aliasing on the v2 kernel instead
-                           of the shared-softmax kernel; bit4: plain launches on the v2 kernel instead of the in-wave
-                           pipelined v3 kernel (A/B measurements and cross-checks) */
+                           of the shared-softmax kernel; bit5: plain launches with Sq % 128 == 0 on the experimental
+                           in-wave pipelined v3 kernel (measured slower than v2; kept for A/B measurements) */
 } AnyV2VAttnDesc;
 
 int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);

@@ -480,8 +480,8 @@ def check_attention(naive_too=True):
                     q[c3:2 * c3], k[c3:2 * c3], q[2 * c3:], k[2 * c3:] = q[:c3], k[:c3], q[:c3], k[:c3]
                 ref = _sdpa(q, k, v).reshape(B_, HW, h, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B_ * Fr * HW, C)
                 out.append(_res(f"attn[{tag}] temporal F{Fr} inject={inj}", o, ref, 6e-3))
-    # in-wave pipelined kernel (v3; taken when Sq % 128 == 0): every peeling path of its KV loop (1 .. 7 tiles, ragged last
-    # tile), shared K/V (kv_div), Q/K aliasing, strided (temporal) sequences -- against fp32 SDPA and against v2 (flag 16)
+    # experimental in-wave pipelined kernel (v3, flag 32, Sq % 128 == 0): every peeling path of its KV loop (1 .. 7 tiles,
+    # ragged last tile), shared K/V (kv_div), Q/K aliasing, strided (temporal) sequences -- against fp32 SDPA and against v2
     for (b, h, S, Sk, kv_div, qk_mod) in [(2, 1, 128, 64, 1, 0), (2, 2, 128, 128, 1, 0), (4, 1, 256, 145, 2, 0),
                                            (1, 2, 128, 200, 1, 0), (2, 1, 128, 320, 1, 0), (1, 1, 256, 384, 1, 0),
                                            (4, 2, 128, 448, 1, 2), (1, 5, 4096, 4096, 1, 0)]:
@@ -491,11 +491,11 @@ def check_attention(naive_too=True):
         kw = dict(batch=b, heads=h, Sq=S, Sk=Sk, inner=1, q_strides=(S, 0, 1), kv_strides=(Sk, 0, 1), kv_div=kv_div,
                   qk_mod=qk_mod)
         o = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
-        ops.attention(q2, kv[:, :C], kv[:, C:], o, **kw)
         o2 = torch.zeros_like(o)
-        saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | 16
+        ops.attention(q2, kv[:, :C], kv[:, C:], o2, **kw)  # v2 (default)
+        saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | 32
         try:
-            ops.attention(q2, kv[:, :C], kv[:, C:], o2, **kw)
+            ops.attention(q2, kv[:, :C], kv[:, C:], o, **kw)  # v3
         finally:
             ops.ATTN_FLAGS = saved
         q = q2.view(b, S, h, 64).transpose(1, 2).clone()
@@ -512,12 +512,20 @@ def check_attention(naive_too=True):
     qkv = rnd(B_ * Fr * HW, 3 * C)
     st = (Fr * HW, 1, HW)
     kw = dict(batch=B_ * HW, heads=h, Sq=Fr, Sk=Fr, inner=HW, q_strides=st, kv_strides=st)
-    o = torch.zeros(B_ * Fr * HW, C, dtype=torch.float16, device=DEV)
-    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, **kw)
+    for flag, tag in ((0, "v2"), (32, "v3")):
+        o = torch.zeros(B_ * Fr * HW, C, dtype=torch.float16, device=DEV)
+        saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | flag
+        try:
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, **kw)
+        finally:
+            ops.ATTN_FLAGS = saved
+        if flag == 0:
+            o_v2 = o
     def seq128(x):
         return x.reshape(B_, Fr, HW, h, 64).permute(0, 2, 3, 1, 4).reshape(B_ * HW, h, Fr, 64)
     q, k, v = (seq128(qkv[:, i * C:(i + 1) * C]) for i in range(3))
     ref = _sdpa(q, k, v).reshape(B_, HW, h, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B_ * Fr * HW, C)
+    out.append(_res("attn[v2] temporal F128 (frame stride)", o_v2, ref, 6e-3))
     out.append(_res("attn[v3] temporal F128 (frame stride)", o, ref, 6e-3))
     # small-head generic kernel (image_latents_temporal_encoder: 2 heads x dim 4)
     B_, Fr, HW, h, d = 2, 6, 10, 2, 4
