@@ -60,7 +60,8 @@ def roofline_spatial_attention(device, pnp=False):
 
     pnp=False: the plain launch (every branch its own Q, K, V) -- flash_attn_d64_v2_kernel<3,1>; algorithmic FLOP ==
     executed FLOP.  `traffic` is the HBM byte count per launch from the PMC passes recorded in
-    profiles/r01_attention_pmc.md (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not re-measured here.
+    profiles/r01_attention_pmc.md (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE: 377.63 MB + 125.83 MB for the plain
+    launch, 212.92 MB + 125.84 MB for the shared-softmax launch), not re-measured here.
     pnp=True: the launch the edit loop actually issues on injection steps (Q/K of all three branches alias the source
     branch) -- flash_attn_d64_v2_kernel<2,3> shares one S/softmax over three V streams, so it executes 2/3 of the
     reference op's MFMA FLOP; `achieved` prices the reference op's algorithmic FLOP (as the contract defines it) and
@@ -79,7 +80,7 @@ def roofline_spatial_attention(device, pnp=False):
                                      if pnp else "flash_attn_d64_v2_kernel<3,1> (spatial self-attn, ") + "N=48 h=5 S=4096 d=64)",
          "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
          "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
-         "traffic": None if pnp else 503459840}
+         "traffic": 338810675 if pnp else 503455949}
     if pnp:
         r["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
     return r
