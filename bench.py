@@ -80,7 +80,7 @@ def roofline_spatial_attention(device, pnp=False):
                                      if pnp else "flash_attn_d64_v2_kernel<3,1> (spatial self-attn, ") + "N=48 h=5 S=4096 d=64)",
          "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
          "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
-         "traffic": 338810675 if pnp else 503455949}
+         "traffic": 338765414 if pnp else 503455949}
     if pnp:
         r["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
     return r
