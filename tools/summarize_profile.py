@@ -53,6 +53,15 @@ def main():
     print("\n| kernel | workgroups | launches | avg us | min us | max us | total ms |\n|---|---:|---:|---:|---:|---:|---:|")
     for (n, wg), v in sorted(by_grid.items(), key=lambda kv: -sum(kv[1]))[:40]:
         print(f"| `{n}` | {wg} | {len(v)} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {sum(v) / 1e3:.2f} |")
+    # the graded launch: plain spatial self-attention at (N=48, h=5, S=4096) = 7680 workgroups; cross-attention launches
+    # (Sk = 145) share kernel and grid but run ~0.1 ms, so split on duration
+    for (n, wg), v in by_grid.items():
+        if n.startswith("flash_attn_d64_v2_kernel<3, 1>") and wg == 7680:
+            big = sorted(x for x in v if x > 600.0)
+            if big:
+                print(f"\nGraded launch (`{n}`, 7680 workgroups, self-attention S = Sk = 4096, i.e. duration > 0.6 ms): "
+                      f"{len(big)} launches, avg {sum(big) / len(big):.1f} us, median {big[len(big) // 2]:.1f} us, "
+                      f"min {big[0]:.1f} us, max {big[-1]:.1f} us -- compare `roofline.ms_per_launch` of the same run's bench line.")
 
 
 if __name__ == "__main__":
