@@ -480,6 +480,32 @@ def check_attention(naive_too=True):
                     q[c3:2 * c3], k[c3:2 * c3], q[2 * c3:], k[2 * c3:] = q[:c3], k[:c3], q[:c3], k[:c3]
                 ref = _sdpa(q, k, v).reshape(B_, HW, h, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B_ * Fr * HW, C)
                 out.append(_res(f"attn[{tag}] temporal F{Fr} inject={inj}", o, ref, 6e-3))
+    # deferred rescale (the running maximum only advances when a probability would exceed 2^8): wide score ranges, and
+    # keys whose scores grow along the sequence so that the maximum keeps jumping by more than the threshold
+    for name, qs, ramp in (("wide scores (|s c| up to ~60)", 3.0, False), ("ramped keys (max jumps every tile)", 1.0, True)):
+        b, h, S = 2, 2, 1024
+        C = 64 * h
+        qkv = rnd(b * S, 3 * C, scale=qs, seed=4242)
+        if ramp:
+            grow = torch.linspace(0.0, 12.0, S, device=DEV).repeat(b).unsqueeze(1).half()
+            qkv[:, C:2 * C] = (qkv[:, C:2 * C].float() * (1.0 + grow.float())).half()
+        o = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=b, heads=h, Sq=S, Sk=S, inner=1,
+                      q_strides=(S, 0, 1), kv_strides=(S, 0, 1))
+        q, k, v = (qkv[:, i * C:(i + 1) * C].view(b, S, h, 64).transpose(1, 2) for i in range(3))
+        out.append(_res(f"attn[flash] {name}", o, _sdpa(q, k, v).transpose(1, 2).reshape(b * S, C), 6e-3))
+        # the shared-softmax kernel on the same data (three V streams, branch 0's Q / K)
+        b3 = 3
+        qkv3 = rnd(b3 * S, 3 * C, scale=qs, seed=777)
+        if ramp:
+            grow3 = torch.linspace(0.0, 12.0, S, device=DEV).repeat(b3).unsqueeze(1)
+            qkv3[:, C:2 * C] = (qkv3[:, C:2 * C].float() * (1.0 + grow3)).half()
+        o3 = torch.zeros(b3 * S, C, dtype=torch.float16, device=DEV)
+        ops.attention(qkv3[:, :C], qkv3[:, C:2 * C], qkv3[:, 2 * C:], o3, batch=b3, heads=h, Sq=S, Sk=S, inner=1,
+                      q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=1)
+        q, k, v = (qkv3[:, i * C:(i + 1) * C].view(b3, S, h, 64).transpose(1, 2).clone() for i in range(3))
+        q[1], k[1], q[2], k[2] = q[0], k[0], q[0], k[0]
+        out.append(_res(f"attn[shared softmax] {name}", o3, _sdpa(q, k, v).transpose(1, 2).reshape(b3 * S, C), 6e-3))
     # experimental in-wave pipelined kernel (v3, flag 32, Sq % 128 == 0): every peeling path of its KV loop (1 .. 7 tiles,
     # ragged last tile), shared K/V (kv_div), Q/K aliasing, strided (temporal) sequences -- against fp32 SDPA and against v2
     for (b, h, S, Sk, kv_div, qk_mod) in [(2, 1, 128, 64, 1, 0), (2, 2, 128, 128, 1, 0), (4, 1, 256, 145, 2, 0),
