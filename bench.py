@@ -255,7 +255,7 @@ def main():
                        "hip_graphs": os.environ.get("ANYV2V_NO_GRAPH", "0") != "1", "finite": finite,
                        "excluded": "VAE encode/decode, CLIP encoders, file I/O (SURVEY 8(f) F1/F2)"},
         }
-        if world == 1 and not args.no_roofline:
+        if not args.no_roofline:  # rank 0, after the timed region (the other ranks wait at destroy_process_group)
             line["roofline"] = roofline_spatial_attention(device)
             line["roofline_pnp"] = roofline_spatial_attention(device, pnp=True)
             line["roofline_gemm"] = roofline_conv(device)
