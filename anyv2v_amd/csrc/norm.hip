@@ -285,47 +285,71 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int V = C >> 3;
-    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
+    const int stride = gridDim.x * wpb;
+    // gamma / beta of this lane's vectors: loaded once per wave, not once per row
+    h8 ga[NV], be[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+            ga[i] = *(const h8*)(gamma + v * 8);
+            be[i] = *(const h8*)(beta + v * 8);
+        }
+    }
+    auto load_row = [&](int row, h8 (&xv)[NV]) {
         const half_t* x = X + (size_t)row * C;
-        h8 xv[NV];
-        float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = lane + 64 * i;
-            if (v < V) {
-                xv[i] = *(const h8*)(x + v * 8);
+            if (v < V) xv[i] = *(const h8*)(x + v * 8);
+        }
+    };
+    auto norm_row = [&](int row, const h8 (&xv)[NV]) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < V) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += (float)xv[i][e];
             }
-        }
         const float mean = wave_sum(sum) / (float)C;
         float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = lane + 64 * i;
-            if (v < V) {
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < V) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float d = (float)xv[i][e] - mean;
                     sq += d * d;
                 }
             }
-        }
         const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
         half_t* y = Y + (size_t)row * C;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = lane + 64 * i;
             if (v < V) {
-                const h8 ga = *(const h8*)(gamma + v * 8);
-                const h8 be = *(const h8*)(beta + v * 8);
                 h8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    o[e] = (half_t)(((float)xv[i][e] - mean) * rstd * (float)ga[e] + (float)be[e]);
+                    o[e] = (half_t)(((float)xv[i][e] - mean) * rstd * (float)ga[i][e] + (float)be[i][e]);
                 *(h8*)(y + v * 8) = o;
             }
         }
+    };
+    // two rows in flight per wave (one row per wave and iteration left ~20 KiB in flight per CU at C = 320)
+    int row = blockIdx.x * wpb + (threadIdx.x >> 6);
+    for (; row + stride < M; row += 2 * stride) {
+        h8 xa[NV], xb[NV];
+        load_row(row, xa);
+        load_row(row + stride, xb);
+        norm_row(row, xa);
+        norm_row(row + stride, xb);
+    }
+    if (row < M) {
+        h8 xa[NV];
+        load_row(row, xa);
+        norm_row(row, xa);
     }
 }
 
@@ -360,7 +384,7 @@ extern "C" int anyv2v_layernorm_f16(const void* X, void* Y, const void* gamma, c
                            (const half_t*)gamma, (const half_t*)beta, M, C, eps);
         return av_launch_status("layernorm_naive");
     }
-    int blocks = (M + 3) / 4;
+    int blocks = (M + 7) / 8;  // 4 waves per block, two rows in flight per wave
     if (blocks > 8192) blocks = 8192;
     const int V = C / 8;
 #define LN_LAUNCH(NV)                                                                                             \
