@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(const AttnK p) {
 // raw s_barrier per tile -- the v1 kernel's single register-prefetched tile exposed the global latency on every tile
 // (~5000 cycles per 64-key tile for 512 cycles of MFMA).  Both tiles stay ROW-MAJOR in LDS ([64 key][64 d], 16-byte
 // chunks XOR-swizzled on the DMA *source* side): K fragments are ds_read_b128 as before (swizzle (key>>1)&7), and
-// the V^T fragments of O^T = V^T P^T come from ds_read_b64_tr_b16 (hardware 4x16 transpose, swizzle key&7) -- no
+// the V^T fragments of O^T = V^T P^T come from ds_read_b64_tr_b16 (hardware 4x16 transpose, swizzle av_vswz(key)) -- no
 // register transposition, no LDS stores at all in the main loop.
 typedef __fp16 fp16x4v_t __attribute__((__vector_size__(8)));
 
@@ -217,6 +217,13 @@ __device__ __forceinline__ void glds16_attn(const half_t* g, char* lds_wave_base
 }
 
 __device__ __attribute__((aligned(256))) half_t g_attn_zero_line[128];
+// 16-byte-chunk swizzle of the row-major V tile.  ds_read_b64_tr_b16 is serviced in two 32-lane groups, each reading
+// 4 consecutive keys x 64 bytes; keys r and r + 2 of such a block land on the same 32 banks (128-byte rows, 64 banks), so
+// their chunk sets must be disjoint: bit 2 of the XOR mask = bit 1 of the key.  (`key & 7`, used before, gave a 2-way
+// conflict on every transpose read: SQ_LDS_BANK_CONFLICT = 32 of 96 LDS cycles per KV tile, profiles/r01_attention_pmc.md.)
+// Depends on key & 3 only, so the +8 / +16 t row offsets of the fragment reads stay immediates.
+__device__ __forceinline__ int av_vswz(int key) { return (key & 3) | ((key & 2) << 1); }
+
 
 // ds_read_b64_tr_b16 through inline asm: with the builtin hipcc treats the read as possibly aliasing the LDS-DMA
 // writes still in flight and drains them with s_waitcnt vmcnt(0) every tile (seen in the .s), which defeats the
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     for (int t = 0; t < 2; ++t) {
         const int row = drow + 32 * t;
         koff[t] = (unsigned)(((long long)row * p.kv_seq * p.ldk + ((dpc ^ ((row >> 1) & 7)) << 3)) * 2);
-        voff_g[t] = (unsigned)(((long long)row * p.kv_seq * p.ldv + ((dpc ^ (row & 7)) << 3)) * 2);
+        voff_g[t] = (unsigned)(((long long)row * p.kv_seq * p.ldv + ((dpc ^ av_vswz(row)) << 3)) * 2);
     }
     const long long kstep = 128ll * p.kv_seq * p.ldk, vstep = 128ll * p.kv_seq * p.ldv;  // bytes per 64-key tile
     const int w_s = __builtin_amdgcn_readfirstlane(w);  // wave index in an SGPR: the DMA's LDS base (m0) stays scalar
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     // V^T fragment addressing (ds_read_b64_tr_b16): lane i16 of a 16-lane group supplies &V[kb + (i16>>2)][dcol + 4(i16&3)]
     const int i16 = lane & 15;
     const int vrow = 4 * hi + (i16 >> 2);                          // + 16 t (+8 for the second read)
-    const int vfl = vrow & 7;                                      // row swizzle (key & 7), constant per lane
+    const int vfl = av_vswz(vrow);                                 // row swizzle, constant per lane
     const int vc0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);      // 16-byte chunk within the 32-d half
     int voff[2];
 #pragma unroll
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = 0; t < 2; ++t) {
         const int row = drow + 32 * t;
         koff[t] = (unsigned)(((long long)row * p.kv_seq * p.ldk + ((dpc ^ ((row >> 1) & 7)) << 3)) * 2);
-        voff_g[t] = (unsigned)(((long long)row * p.kv_seq * p.ldv + ((dpc ^ (row & 7)) << 3)) * 2);
+        voff_g[t] = (unsigned)(((long long)row * p.kv_seq * p.ldv + ((dpc ^ av_vswz(row)) << 3)) * 2);
     }
     const long long kstep = 128ll * p.kv_seq * p.ldk, vstep = 128ll * p.kv_seq * p.ldv;  // bytes per 64-key tile
     int k_iss_stage = 0, v_iss_stage = 0, k_iss_key0 = 0, v_iss_key0 = 0;
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int ks = 0; ks < 4; ++ks) kaddr[ks] = smem_lds + l31 * 128 + (((2 * ks + hi) ^ ((l31 >> 1) & 7)) << 4);
     const int i16 = lane & 15;
     const int vrow = 4 * hi + (i16 >> 2);
-    const int vfl = vrow & 7;
+    const int vfl = av_vswz(vrow);
     const int vc0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
     unsigned vaddr[2];
 #pragma unroll
