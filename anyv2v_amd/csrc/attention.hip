@@ -856,6 +856,7 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
 
 __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
     __shared__ __attribute__((aligned(16))) half_t vs[4][16 * 64];
+    __shared__ __attribute__((aligned(16))) half_t os[4][16 * 72];  // output tile, rows padded to 144 bytes
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long unit = (long long)blockIdx.x * 4 + w;  // (batch element, head)
     if (unit >= (long long)p.batch * p.heads) return;      // wave-uniform; no block-level sync in this kernel
@@ -918,7 +919,10 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
     const float inv = 1.0f / sum;
     // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; same-wave LDS write -> read is ordered (in-order DS queue)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    half_t* op = p.O + (obase + (long long)l15 * p.q_seq) * p.ldo + h * 64 + 4 * g;
+    // The MFMA leaves lane (q = l15, g) with 4 of every 16 output channels: stored directly that is 32-byte pieces of 16
+    // different rows per instruction.  Turn the tile through LDS (row stride 144 bytes) so that 8 lanes write one
+    // full 128-byte row segment: two 1-KiB store instructions instead of four scattered 512-byte ones.
+    half_t* const ow = os[w];
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
         const half_t* src = &vs[w][(4 * g + (l15 >> 2)) * 64 + 16 * db + 4 * (l15 & 3)];
@@ -928,12 +932,17 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
         for (int j = 0; j < 4; ++j) vf[j] = (half_t)vt[j];
         f4 o = {0.f, 0.f, 0.f, 0.f};
         o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o, 0, 0, 0);
-        if (l15 < p.Sq) {
-            h4 ov;
+        h4 ov;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[r] * inv);
-            *(h4*)(op + 16 * db) = ov;
-        }
+        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[r] * inv);
+        *(h4*)(ow + l15 * 72 + 16 * db + 4 * g) = ov;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int q = 8 * ps + (lane >> 3), ch = lane & 7;
+        const h8 ov = *(const h8*)(ow + q * 72 + ch * 8);
+        if (q < p.Sq) *(h8*)(p.O + (obase + (long long)q * p.q_seq) * p.ldo + h * 64 + ch * 8) = ov;
     }
 }
 
@@ -1011,7 +1020,7 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     const bool fast = !(d->flags & 1) && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0 &&
                       av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) && av_aligned16(d->O);
     if (!fast) return launch_naive(k, s);
-    if (k.Sq <= 16 && k.Sk <= 16 && !(d->flags & 2)) {  // temporal attention at <= 16 frames: one wave per sequence
+    if (k.Sq <= 16 && k.Sk <= 16 && d->ldo % 8 == 0 && !(d->flags & 2)) {  // temporal attention at <= 16 frames: one wave per sequence
         const long long units = (long long)k.batch * k.heads;
         hipLaunchKernelGGL(short_attn_d64_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, k);
         return av_launch_status("short_attn_d64");
