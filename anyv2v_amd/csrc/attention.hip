@@ -883,15 +883,16 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
             kf[ks] = kok ? *(const h8*)(kp + 32 * ks) : zero8;
         }
     }
-    // V -> LDS row-major [16 keys][64 d]: lane (key = lane >> 2, chunks 2 (lane & 3), +1)
+    // V -> LDS row-major [16 keys][64 d]: 8 lanes fetch one full 128-byte key row per instruction
     {
-        const int key = lane >> 2, c0 = 2 * (lane & 3);
-        const bool ok = key < p.Sk;
-        const half_t* vp = p.V + (vbase + (long long)key * p.kv_seq) * p.ldv + h * 64 + c0 * 8;
-        const h8 v0 = ok ? *(const h8*)vp : zero8;
-        const h8 v1 = ok ? *(const h8*)(vp + 8) : zero8;
-        *(h8*)(&vs[w][key * 64 + c0 * 8]) = v0;
-        *(h8*)(&vs[w][key * 64 + c0 * 8 + 8]) = v1;
+        h8 vv[2];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int key = 8 * ps + (lane >> 3);
+            vv[ps] = key < p.Sk ? *(const h8*)(p.V + (vbase + (long long)key * p.kv_seq) * p.ldv + h * 64 + (lane & 7) * 8) : zero8;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) *(h8*)(&vs[w][(8 * ps + (lane >> 3)) * 64 + (lane & 7) * 8]) = vv[ps];
     }
     // S^T = K Q^T: D[key = 4 g + r][q = l15]
     f4 s = {0.f, 0.f, 0.f, 0.f};
