@@ -67,18 +67,20 @@ def _configs(base, tag):
     return inv, inv_list, ed, ed_list
 
 
-def _run_both_stages(base, tag, frame_parallel=False):
+def _run_both_stages(base, tag, frame_parallel=False, device="cpu"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import cpu_ops_emulation as emu
-    emu.install()
-    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    if device == "cpu":  # TEST-ONLY emulation of the C-ABI ops; on a GPU the runners use the HIP library and HIP graphs
+        import cpu_ops_emulation as emu
+        emu.install()
+        os.environ["ANYV2V_NO_GRAPH"] = "1"
     torch.set_grad_enabled(False)
     from anyv2v_amd import run_group_ddim_inversion as s1, run_group_pnp_edit as s2
     from anyv2v_amd.utils import seed_everything
     inv, inv_list, ed, ed_list = _configs(base, tag)
+    inv.device = ed.device = device
     log = logging.getLogger("e2e")
-    dev = torch.device("cpu")
+    dev = torch.device(device)
     seed_everything(inv.seed)
     s1.main(inv, inv_list, dev, log, synthetic_encoders=True, frame_parallel=frame_parallel)
     seed_everything(ed.seed)
@@ -94,8 +96,19 @@ def _outputs(base, tag):
 
 
 def test_stage1_stage2_file_formats(tmp_path):
+    _check_file_formats(tmp_path, "cpu")
+
+
+@pytest.mark.gpu
+def test_stage1_stage2_on_gpu(tmp_path):
+    """The same two CLI stages on cuda:0 through the HIP library (HIP-graph step engines, real kernels)."""
+    assert torch.cuda.is_available()
+    _check_file_formats(tmp_path, "cuda")
+
+
+def _check_file_formats(tmp_path, device):
     base = _make_workspace(tmp_path)
-    _run_both_stages(base, "single")
+    _run_both_stages(base, "single", device=device)
     inv_dir, out_dir = _outputs(base, "single")
     lat_files = sorted(os.listdir(os.path.join(inv_dir, "ddim_latents")))
     assert len(lat_files) == N_STEPS and all(f.startswith("ddim_latents_") and f.endswith(".pt") for f in lat_files)
@@ -112,7 +125,7 @@ def test_stage1_stage2_file_formats(tmp_path):
         assert g.n_frames == N_FRAMES and g.size == (SIZE, SIZE)
     # stage 1 is skipped when its output exists (reference behaviour, run_group_ddim_inversion.py:118-120)
     mtime = os.path.getmtime(os.path.join(inv_dir, "ddim_latents", lat_files[0]))
-    _run_both_stages(base, "single")
+    _run_both_stages(base, "single", device=device)
     assert os.path.getmtime(os.path.join(inv_dir, "ddim_latents", lat_files[0])) == mtime
 
 
