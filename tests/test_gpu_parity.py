@@ -55,7 +55,9 @@ def test_unet_vs_reference_generated_golden():
 
 
 def test_unet_mini_step_vs_oracle():
-    _assert_all(gc.check_unet_vs_oracle("mini", 3, 4, 8))
+    # calibrate: the HIP path's error must stay within 2x the error of the same oracle model run by PyTorch-ROCm eager in
+    # fp16 on this GPU (SURVEY.md 8(c) tolerance policy)
+    _assert_all(gc.check_unet_vs_oracle("mini", 3, 4, 8, calibrate=True))
     _assert_all(gc.check_unet_vs_oracle("mini", 1, 8, 16, with_pnp=False))
 
 
