@@ -557,28 +557,16 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
 #undef AV_RB
 }
 
-// FR (experimental, flags bit6): "full-row" epilogue.  The two column-waves of a 16-row band exchange their 160-column
-// halves through one shared LDS slab (pair-wise rendezvous on an LDS counter, no block barrier) so that each of them
-// stores 8 complete 640-byte rows (5 whole cache lines) instead of 16 half rows of 2.5 lines.
-template <int MF, bool GEGLU, int MODE, bool TRACE = false, bool SPLIT = false, bool FR = false>
+template <int MF, bool GEGLU, int MODE, bool TRACE = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     constexpr int BM = 64 * MF, BN = 320;  // four wave rows of MF 16-row fragments
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int SLAB_LD = (GEGLU ? 80 : 160) + 8;          // halves; 16-byte aligned rows
     constexpr int SLAB_BYTES = 16 * SLAB_LD * 2;             // per wave
     static_assert(8 * SLAB_BYTES <= STAGE_BYTES, "epilogue slabs must fit in one pipeline stage");
-    constexpr int PLD = 320 + 8;                             // FR: pair slab row stride in halves (656 B, 16-byte aligned)
-    constexpr int PSLAB_BYTES = 16 * PLD * 2;
-    static_assert(4 * PSLAB_BYTES <= STAGE_BYTES, "pair slabs must fit in one pipeline stage");
-    static_assert(!FR || (!GEGLU && !SPLIT), "full-row epilogue: plain tiles only");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
-    __shared__ unsigned pair_cnt[4];  // FR: per wave-row rendezvous counter (4 increments per slab)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-    if constexpr (FR) {
-        if (tid < 4) pair_cnt[tid] = 0;
-        __syncthreads();
-    }
     const int G = gridDim.x;
     const int b0 = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous
     const int tilesM = (p.M + BM - 1) / BM;
@@ -696,79 +684,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
             continue;
         }
         if constexpr (SPLIT) __builtin_unreachable();
-        if constexpr (FR) {
-            half_t* const pslab = (half_t*)(smem + (stage ^ 1) * STAGE_BYTES + wr * PSLAB_BYTES);
-            constexpr int CPR = 40, NITF = 5;  // 16-byte chunks per 320-column row; 8 rows x 40 chunks / 64 lanes
-            unsigned fr_epoch = (unsigned)((tile - b0) / G) * MF;  // slabs this wave pair has finished (MF per tile)
-            const int n_tile = nt * BN;
-            // LDS-only ordering: relaxed atomics + explicit lgkmcnt waits.  (Acquire / release atomics also drain vmcnt -- the
-            // residual prefetch and the previous slab's global stores -- and made this epilogue 1.6x slower than the default.)
-            auto fr_wait = [&](unsigned target) {  // bounded: a protocol bug must not hang the GPU
-                for (int spin = 0; spin < (1 << 22); ++spin) {
-                    const unsigned v = __hip_atomic_load(&pair_cnt[wr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if ((int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                asm volatile("" ::: "memory");
-            };
-            auto fr_signal = [&]() {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's slab writes / reads have completed
-                if (lane_e == 0) __hip_atomic_fetch_add(&pair_cnt[wr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-            h4 bvec[10];
-#pragma unroll
-            for (int nf = 0; nf < 10; ++nf)
-                bvec[nf] = *(const h4*)(p.bias != nullptr ? p.bias + n_wave + nf * 16 + 4 * lq : p.zeros);
-            const bool has_res = p.R != nullptr;
-            h8 rrf[2][NITF];
-            auto res_load_f = [&](int mf, h8 (&dst)[NITF]) {
-#pragma unroll
-                for (int it = 0; it < NITF; ++it) {
-                    const int c = it * 64 + lane_e;
-                    const int row = c / CPR, cc = c - row * CPR;
-                    const int grow = m_wave + mf * 16 + 8 * wc + row;
-                    dst[it] = *(const h8*)(grow < p.M ? p.R + (size_t)grow * p.ldr + n_tile + cc * 8 : p.zeros);
-                }
-            };
-            if (has_res) res_load_f(0, rrf[0]);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                if (has_res && mf + 1 < MF) res_load_f(mf + 1, rrf[(mf + 1) & 1]);
-                const bool has_rv = p.rowvec != nullptr;
-                const int mrow = m_wave + mf * 16 + l15;
-                const half_t* rv = has_rv ? p.rowvec + (size_t)((mrow < p.M ? mrow : 0) / p.rowvec_div) * p.ldrv + n_wave + 4 * lq
-                                          : p.zeros;
-                fr_wait(4 * fr_epoch);  // both waves have read the previous slab out of this buffer
-#pragma unroll
-                for (int nf = 0; nf < 10; ++nf) {
-                    h4 tv = (h4){0, 0, 0, 0};
-                    if (has_rv) tv = *(const h4*)(rv + nf * 16);
-                    h4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[mf][nf][r] + (float)bvec[nf][r] + (float)tv[r]);
-                    *(h4*)(pslab + l15 * PLD + wc * 160 + nf * 16 + 4 * lq) = o;
-                }
-                fr_signal();
-                fr_wait(4 * fr_epoch + 2);  // both halves of the slab are written
-#pragma unroll
-                for (int it = 0; it < NITF; ++it) {
-                    const int c = it * 64 + lane_e;
-                    const int row = c / CPR, cc = c - row * CPR;
-                    const int grow = m_wave + mf * 16 + 8 * wc + row;
-                    h8 v = *(const h8*)(pslab + (8 * wc + row) * PLD + cc * 8);
-                    if (has_res) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rrf[mf & 1][it][e]);
-                    }
-                    if (grow < p.M) *(h8*)(p.C + (size_t)grow * p.ldc + n_tile + cc * 8) = v;
-                }
-                fr_signal();  // (its lgkmcnt(0): the reads above have completed)
-                ++fr_epoch;
-            }
-            if (!has_next) break;
-            tile = next_tile;
-            continue;
-        }
         half_t* const slab = (half_t*)(smem + (stage ^ 1) * STAGE_BYTES + w * SLAB_BYTES);
         constexpr int OUT_W = GEGLU ? 80 : 160;       // output columns of this wave
         constexpr int CPRW = OUT_W / 8;               // 16-byte chunks per slab row
@@ -1022,10 +937,6 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
                     hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, true>), grid, dim3(512), 0, s, k);
                 }
                 return av_launch_status("gemm_big<trace>");
-            }
-            if ((d->flags & 64) && !geglu) {  // experimental full-row epilogue (pair-wise LDS exchange)
-                hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, false, false, true>), grid, dim3(512), 0, s, k);
-                return av_launch_status("gemm_big<full-row>");
             }
             if constexpr (MODE == MODE_LINEAR) {
                 if (geglu)
