@@ -131,19 +131,25 @@ def cpu_baseline():
     inp = gc.config1_inputs(cfg, 3, 8, 32)
     kw = lambda s: dict(fps=inp["fps"][s], image_latents=inp["image_latents"][s], image_embeddings=inp["image_embeddings"][s],
                         encoder_hidden_states=inp["encoder_hidden_states"][s])
+    def timed(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return sorted(ts)
+
     with torch.no_grad():
-        t0 = time.time()
-        oracle(inp["sample"][:1], 981, **kw(slice(0, 1)))
-        t1 = time.time() - t0
+        ts1 = timed(lambda: oracle(inp["sample"][:1], 981, **kw(slice(0, 1))), 3)
+        t1 = ts1[1]  # median of 3 (the first run also pays the allocator / page faults)
         pnp_oracle.init_pnp(oracle, 50, 1.0, 1.0, 1.0)
         pnp_oracle.register_time(oracle, 981)
-        t0 = time.time()
-        oracle(inp["sample"], 981, **kw(slice(0, 3)))
-        t3 = time.time() - t0
+        ts3 = timed(lambda: oracle(inp["sample"], 981, **kw(slice(0, 3))), 2)
+        t3 = ts3[0]  # faster of 2
     fps = 8.0 / (STEPS_PER_STAGE * (t1 + t3))
     return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"config 1 (1 clip x 8f x 256x256): 1 inversion step B=1 ({t1:.2f}s) + 1 PnP step B=3 with hooks ({t3:.2f}s), "
-                      f"fp32 torch on {cores} threads, extrapolated x50 steps per stage",
+            "sample": f"config 1 (1 clip x 8f x 256x256): 1 inversion step B=1 ({t1:.2f}s, median of 3) + 1 PnP step B=3 with "
+                      f"hooks ({t3:.2f}s, faster of 2), fp32 torch on {cores} threads, extrapolated x50 steps per stage",
             "seconds_B1": round(t1, 3), "seconds_B3": round(t3, 3)}
 
 
