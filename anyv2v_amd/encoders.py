@@ -27,10 +27,11 @@ from PIL import Image
 
 
 def _center_crop_wide(image: Image.Image, resolution):
-    """``pipeline_i2vgen_xl.py:1487-1509``: resize to cover, then centre-crop to ``resolution`` = (w, h)."""
+    """``pipeline_i2vgen_xl.py:1487-1509``: resize to cover, then centre-crop to ``resolution`` = (w, h).  The resized
+    size is ``round(width // scale)`` -- a FLOOR division, as the reference writes it (``:1496,1505``)."""
     w, h = image.size
     scale = min(w / resolution[0], h / resolution[1])
-    image = image.resize((round(w / scale), round(h / scale)), resample=Image.BOX)
+    image = image.resize((round(w // scale), round(h // scale)), resample=Image.BOX)
     x1 = (image.width - resolution[0]) // 2
     y1 = (image.height - resolution[1]) // 2
     return image.crop((x1, y1, x1 + resolution[0], y1 + resolution[1]))

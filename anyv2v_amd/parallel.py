@@ -44,15 +44,25 @@ def seed_for_entry(base_seed: int, entry_index: int) -> int:
     return int(base_seed) + 1000003 * int(entry_index)
 
 
-def gather_latents(latents: Optional[torch.Tensor], like_shape, dtype, device) -> List[torch.Tensor]:
-    """all_gather of one ``[1,4,F,h,w]`` latent per rank (512 KiB at 16f x 512^2).  Ranks that had no entry
-    contribute zeros."""
+def gather_latents(latents: Sequence[torch.Tensor], n_entries: int, like_shape, dtype, device) -> torch.Tensor:
+    """The ONE collective of the sharded job: all_gather of every rank's edited latents (``[1,4,F,h,w]`` per entry,
+    512 KiB at 16f x 512^2; RCCL over xGMI on the node, gloo in the CPU tests).
+
+    ``latents``: this rank's results in processing order (entry ``rank``, ``rank + world``, ...; ``shard_entries``).  A rank
+    may hold several entries (14 demo edits on 8 GPUs) or none: every rank contributes ``ceil(n_entries / world)`` slots
+    (zero-padded) in ONE message, and the result is re-ordered to entry order.  Returns ``[n_entries, 4, F, h, w]``."""
     import torch.distributed as dist
     world = dist.get_world_size()
-    x = latents if latents is not None else torch.zeros(like_shape, dtype=dtype, device=device)
-    out = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(out, x.contiguous())
-    return out
+    slots = max(1, -(-int(n_entries) // world))
+    like_shape = tuple(like_shape)[-4:]
+    buf = torch.zeros((slots,) + like_shape, dtype=dtype, device=device)
+    assert len(latents) <= slots, f"{len(latents)} results on this rank but only {slots} slots ({n_entries} entries / {world} ranks)"
+    for k, x in enumerate(latents):
+        assert tuple(x.shape[-4:]) == like_shape, f"entry latents {tuple(x.shape)} != {like_shape}: all entries must share one geometry"
+        buf[k].copy_(x.reshape(like_shape))
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return torch.stack([out[i % world][i // world] for i in range(int(n_entries))])
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -61,7 +61,9 @@ class _StepEngine:
         self.coef = torch.zeros(4, dtype=torch.float32, device=sample.device)
         self.graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         # (a frame-parallel forward contains collectives: run eagerly -- at 128 frames launch overhead is irrelevant)
-        self.use_graphs = _use_graphs() and sample.is_cuda and getattr(pipe.unet, "frame_parallel", None) is None
+        # (likewise with foreign hooks on the seams B1 / B2: torch-style code that may sync, e.g. ``t in cuda_tensor``)
+        self.use_graphs = (_use_graphs() and sample.is_cuda and getattr(pipe.unet, "frame_parallel", None) is None
+                           and not pnp_utils.has_foreign_hooks(pipe.unet))
         B, _, F, H, W = sample.shape
         unet = self.unet
         if not unet._packed:
@@ -273,6 +275,18 @@ class I2VGenXLPipeline:
             latents = latents.to(device)
         return latents * self.scheduler.init_noise_sigma
 
+    @staticmethod
+    def _single_clip(prompt_embeds, num_videos_per_prompt):
+        """The loops drive ONE clip per call (``nb`` batch slots = its CFG / PnP branches).  The reference computes a real
+        batch for a list prompt; here that would silently combine the negative branch of prompt 0 with the positive branch
+        of prompt 1, so it is refused."""
+        if num_videos_per_prompt not in (None, 1):
+            raise ValueError(f"num_videos_per_prompt={num_videos_per_prompt} is not supported: one clip per call (shard clips "
+                             "over processes / GPUs instead, anyv2v_amd.parallel)")
+        if prompt_embeds.shape[0] != 1:
+            raise ValueError(f"got a batch of {prompt_embeds.shape[0]} prompts: one clip per call (the batch dimension holds the "
+                             "CFG / PnP branches of that clip)")
+
     # ------------------------------------------------------------------ conditioning assembly
     def _conditioning(self, prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                       negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents):
@@ -299,7 +313,7 @@ class I2VGenXLPipeline:
                prompt_embeds=None, negative_prompt_embeds=None, output_type: Optional[str] = "pil",
                return_dict: bool = True, cross_attention_kwargs=None, clip_skip: Optional[int] = 1,
                output_dir: Optional[str] = None, image_embeddings=None, image_latents=None,
-               return_trajectory: bool = False):
+               return_trajectory: bool = False, background_save: bool = False):
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, image, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
@@ -308,6 +322,7 @@ class I2VGenXLPipeline:
         pnp_utils.clear_time(self)  # inversion never injects (stage 1 of the reference runs without hooks)
         pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                                              negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
+        self._single_clip(pe, num_videos_per_prompt)
         cfg_on = self.do_classifier_free_guidance
         if cfg_on:  # [uncond, cond] (:1329-1337); zero negative image embedding (:437-439)
             ehs = torch.cat([npe, pe])
@@ -334,7 +349,10 @@ class I2VGenXLPipeline:
             eng.step(t_table[i], coef_table[i], key=("inv",))
             traj[t] = sample[nb - 1:nb].clone()
         if output_dir is not None:
-            traj.save(output_dir)  # ddim_latents_{t}.pt, reference format, written in the background
+            # ddim_latents_{t}.pt, reference format.  Complete when invert() returns (as in the reference, which writes
+            # inside the loop) unless the caller opts into the background writer (the CLI runner does; every reader in
+            # anyv2v_amd.utils joins it first)
+            traj.save(output_dir, background=background_save)
             logger.info(f"saving noisy latents for {len(ts)} timesteps to {output_dir}")
         self._last_trajectory = traj
         inverted = torch.stack([traj[t] for t in reversed(ts)], 1)  # [1, n, 4, F, h, w] (:1436)
@@ -360,6 +378,7 @@ class I2VGenXLPipeline:
         self._guidance_scale = guidance_scale
         pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                                              negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
+        self._single_clip(pe, num_videos_per_prompt)
         cfg_on = self.do_classifier_free_guidance
         pnp_utils.clear_time(self)  # plain CFG sampling (DDIM reconstruction) runs hook-free
         if cfg_on:
@@ -405,6 +424,7 @@ class I2VGenXLPipeline:
         self._guidance_scale = guidance_scale
         pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                                              negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
+        self._single_clip(pe, num_videos_per_prompt)
         # source (ddim inversion) branch: its own prompt, first frame, positive image embedding (:1027-1091)
         if ddim_inv_prompt_embeds is None:
             ddim_inv_prompt_embeds = _clip_text(self._need("text_encoder"), self._need("tokenizer"), ddim_inv_prompt,

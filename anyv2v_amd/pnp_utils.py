@@ -73,11 +73,29 @@ def register_temp_attention_pnp(model, injection_schedule):
 
 
 def injection_state(model):
-    """(conv_on, spatial_on, temporal_on) for the currently registered time -- keys the HIP-graph cache."""
+    """Injection decision of every hook site for the currently registered time: (conv, 8 x spatial, 8 x temporal).  It
+    keys the HIP-graph cache (a captured step bakes each site's decision in), so it is built from ALL 17 sites -- a
+    single site with its own schedule or processor (the reference's commented "Disable PNP" per-module pattern,
+    ``pnp_utils.py:229-232``) gets its own graph instead of silently replaying another state's."""
     from .unet import pnp_on
     unet = model.unet
     r = unet.up_blocks[1].resnets[1]
-    sp = unet.up_blocks[2].attentions[0].transformer_blocks[0].attn1.processor
-    tp = unet.up_blocks[2].temp_attentions[0].transformer_blocks[0].attn1.processor
-    return (pnp_on(r.t, r.injection_schedule), pnp_on(getattr(sp, "t", None), getattr(sp, "injection_schedule", None)),
-            pnp_on(getattr(tp, "t", None), getattr(tp, "injection_schedule", None)))
+    state = [pnp_on(r.t, r.injection_schedule)]
+    for kind in ("attentions", "temp_attentions"):
+        for res, blocks in _ATTN_SITES.items():
+            for block in blocks:
+                p = getattr(unet.up_blocks[res], kind)[block].transformer_blocks[0].attn1.processor
+                state.append(pnp_on(getattr(p, "t", None), getattr(p, "injection_schedule", None)))
+    return tuple(state)
+
+
+def has_foreign_hooks(unet) -> bool:
+    """True when a torch-style processor / ``forward`` from outside this package is plugged into the seams B1 / B2 (e.g.
+    the reference's own ``pnp_utils.py`` hooks): such code may sync or allocate, so steps are not captured into HIP graphs."""
+    from .unet import Attention, ResnetBlock2D
+    for m in unet.modules():
+        if isinstance(m, Attention) and not isinstance(m.processor, HipAttnProcessor):
+            return True
+        if isinstance(m, ResnetBlock2D) and "forward" in m.__dict__:
+            return True
+    return False

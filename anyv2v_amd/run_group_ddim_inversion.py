@@ -23,7 +23,8 @@ from .encoders import attach_synthetic_encoders
 from .parallel import FrameParallel, init_distributed, seed_for_entry, shard_entries
 from .pipeline import I2VGenXLPipeline
 from .schedulers import DDIMInverseScheduler, DDIMScheduler
-from .utils import convert_video_to_frames, export_to_gif, load_ddim_latents_at_t, load_video_frames, seed_everything
+from .utils import (convert_video_to_frames, export_to_gif, inversion_is_complete, load_ddim_latents_at_t, load_video_frames,
+                    seed_everything)
 
 MODEL_ID = "ali-vilab/i2vgen-xl"
 
@@ -38,7 +39,7 @@ def ddim_inversion(config, first_frame, frame_list, pipe: I2VGenXLPipeline, inve
                                num_inference_steps=config.n_steps, guidance_scale=config.cfg,
                                negative_prompt=config.negative_prompt, target_fps=config.target_fps,
                                latents=video_latents_at_0, generator=g, return_dict=False,
-                               output_dir=config.output_dir if write else None)
+                               output_dir=config.output_dir if write else None, background_save=True)
     logging.getLogger(__name__).debug(f"ddim_latents.shape: {ddim_latents.shape}")
     return ddim_latents[0]  # [num_inference_steps, c, num_frames, h, w]
 
@@ -80,7 +81,8 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
         config.video_path = os.path.join(config.video_dir, config.video_name + ".mp4")
         config.video_frames_path = os.path.join(config.video_dir, config.video_name)
-        skip = os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False)
+        skip = (inversion_is_complete(config.output_dir, config.inverse_config.output_dir)
+                and not config.get("force_recompute_latents", False))
         if fp_mode:  # all ranks must take the same decision, before rank 0 starts writing into that directory
             import torch.distributed as dist
             flag = [skip]
@@ -114,11 +116,16 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             t_idx = recon_config.ddim_init_latents_t_idx
             ddim_scheduler.set_timesteps(recon_config.n_steps)
             logger.info(f"ddim_scheduler.timesteps: {ddim_scheduler.timesteps}")
-            # in-memory hand-off of the trajectory (the files are being written in the background)
-            traj = pipe._last_trajectory
+            # ``recon_config.ddim_latents_path`` (``run_group_ddim_inversion.py:156-160``): when it names the directory this
+            # very inversion writes (the template's default), hand the trajectory over in memory -- the files are still
+            # being written in the background; any other directory is read from disk as configured
+            src = recon_config.get("ddim_latents_path", None)
+            same = src is None or os.path.abspath(str(src)) == os.path.abspath(str(config.inverse_config.output_dir))
+            traj = pipe._last_trajectory if same else str(src)
             ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
             reconstructed_video = ddim_sampling(recon_config, first_frame, ddim_latents_at_t, pipe, ddim_scheduler, t_idx, g)
             if writer:
+                pipe._last_trajectory.wait()  # the latents directory is renamed into place when complete
                 os.makedirs(config.output_dir, exist_ok=True)
                 reconstructed_video = [f.resize((512, 512), resample=Image.LANCZOS) for f in reconstructed_video]
                 export_to_gif(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.gif"), fps=10)

@@ -72,7 +72,7 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
     for config_entry in configs_list:
         if config_entry["active"] is False:
             logger.info(f"Skipping config_entry: {config_entry}")
-    last_latents, lat_shape = None, None
+    my_latents, lat_shape = [], None
     for config_entry in shard_entries(configs_list, e_rank, e_world):
         entry_idx = all_active.index(config_entry)
         logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
@@ -116,7 +116,8 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             generator=torch.manual_seed(config.seed), return_dict=True, ddim_init_latents_t_idx=t_idx,
             ddim_inv_latents_path=traj, ddim_inv_prompt=config.ddim_inv_prompt, ddim_inv_1st_frame=src_1st_frame,
             output_type="latent").frames
-        last_latents, lat_shape = edited_latents, tuple(edited_latents.shape)
+        my_latents.append(edited_latents)
+        lat_shape = tuple(edited_latents.shape)
         video = pipe.decode_latents(edited_latents, decode_chunk_size=1)  # (frame-parallel: every rank decodes its frames)
         if not writer:
             continue
@@ -138,11 +139,12 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
     elif world > 1:
         import torch.distributed as dist
         shape = lat_shape or (1, 4, template_config.n_frames, template_config.image_size[1] // 8, template_config.image_size[0] // 8)
-        gathered = gather_latents(last_latents, shape, torch.float16, device)
+        # every entry's latents reach rank 0, in entry order (a rank may have run several entries, or none)
+        gathered = gather_latents(my_latents, len(all_active), shape, torch.float16, device)
         if rank == 0:
             out = os.path.join(template_config.get("data_dir", "."), "gathered_latents.pt")
-            torch.save(torch.cat([g.cpu() for g in gathered]), out)
-            logger.info(f"all_gather of edited latents from {world} ranks -> {out}")
+            torch.save(gathered.cpu(), out)
+            logger.info(f"all_gather of the edited latents of {len(all_active)} entries from {world} ranks -> {out}")
         dist.barrier()
 
 

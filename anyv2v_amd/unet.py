@@ -125,6 +125,19 @@ class Conv2d(nn.Module):
             w = wp
         self._w = w.permute(0, 2, 3, 1).reshape(self.cout, -1).contiguous()  # [Cout, (ky kx cin)]
 
+    def forward(self, x, *unused):
+        """torch-style call on an NCHW tensor (compat seam B2: ``self.conv1(hidden_states)`` inside a replaced
+        ``ResnetBlock2D.forward``, ``i2vgen-xl/pnp_utils.py:78,107,117-122``) -- same HIP kernel behind a layout round trip."""
+        if self._w is None:
+            self.pack()
+        n, c, H, W = x.shape
+        tok = x.to(torch.float16).permute(0, 2, 3, 1).reshape(n * H * W, c).contiguous()
+        if self.pad_cin_to and self.pad_cin_to > c:
+            tok = torch.nn.functional.pad(tok, (0, self.pad_cin_to - c))
+        y = self.tokens(tok, H, W)
+        Ho, Wo = (H, W) if self.k == 1 else ((H + 2 - 3) // self.stride + 1, (W + 2 - 3) // self.stride + 1)
+        return y.view(n, Ho, Wo, self.cout).permute(0, 3, 1, 2)
+
     def tokens(self, x, H, W, *, x1=None, up=False, act=ACT_NONE, rowvec=None, rowvec_div=0, residual=None, out=None,
                asym=False):
         """x: [N*H*W, Cin] tokens -> [N*Ho*Wo, Cout].  ``asym``: zero padding only after the last row / column
@@ -163,6 +176,15 @@ class GroupNorm(nn.Module):
         self.num_groups, self.eps = groups, eps
         self.weight = _param(channels)
         self.bias = _param(channels)
+
+    def forward(self, x):
+        """torch-style call on an NCHW tensor (compat seam B2: ``self.norm1(hidden_states)``, ``pnp_utils.py:48,104``)."""
+        n, c = x.shape[:2]
+        hw = x[0, 0].numel()
+        tok = x.to(torch.float16).reshape(n, c, hw).permute(0, 2, 1).reshape(n * hw, c).contiguous()
+        stats = torch.empty(ops.gn_scratch_floats(n, 1, self.num_groups), dtype=torch.float32, device=x.device)
+        y = ops.groupnorm(tok, self.weight, self.bias, stats, hw, groups=self.num_groups, eps=self.eps)
+        return y.view(n, hw, c).permute(0, 2, 1).reshape(x.shape)
 
 
 class LayerNorm(nn.Module):
@@ -455,7 +477,34 @@ class ResnetBlock2D(nn.Module):
         self.injection_schedule = None
         self._temb_col = 0  # column of this block's time_emb_proj inside ctx.temb_all
 
+    def forward(self, input_tensor, temb, scale: float = 1.0):
+        """torch-style ``ResnetBlock2D.forward(input_tensor[N,Cin,H,W], temb[N,1280])`` (seam B2; the body the reference
+        restates at ``i2vgen-xl/pnp_utils.py:46-126``) on the HIP kernels, without injection.  The network itself never
+        calls this (it runs ``run`` on token matrices); it exists so that the module behaves like the diffusers one."""
+        n, c, H, W = input_tensor.shape
+        h = self.nonlinearity(self.norm1(input_tensor))
+        h = self.conv1(h) + self.time_emb_proj(self.nonlinearity(temb.to(torch.float16)))[:, :, None, None]
+        h = self.conv2(self.nonlinearity(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            input_tensor = self.conv_shortcut(input_tensor)
+        return (input_tensor.to(torch.float16) + h) / self.output_scale_factor
+
+    def _run_foreign(self, ctx, x0, x1, H, W):
+        """Compatibility seam B2: ``module.forward`` was replaced on the instance (the reference's
+        ``register_conv_injection`` does ``conv_module.forward = conv_forward(conv_module)``, ``pnp_utils.py:130-131``).
+        Hand it the NCHW tensors it expects -- its sub-module calls (``self.norm1`` / ``self.conv1`` / ...) still land on
+        the HIP kernels through their torch-style ``forward`` -- and fold the result back into the token layout."""
+        N = x0.shape[0] // (H * W)
+        x = x0 if x1 is None else torch.cat([x0, x1], 1)
+        x = x.view(N, H, W, -1).permute(0, 3, 1, 2)
+        per = N // ctx.emb.shape[0]   # frames per batch element (temb is per clip-branch; the reference repeats it per frame)
+        temb = ctx.emb.repeat_interleave(per, dim=0)
+        out = self.__dict__["forward"](x, temb)
+        return out.to(torch.float16).permute(0, 2, 3, 1).reshape(N * H * W, -1).contiguous()
+
     def run(self, ctx, x0, x1, H, W):
+        if "forward" in self.__dict__:
+            return self._run_foreign(ctx, x0, x1, H, W)
         HW = H * W
         T = x0.shape[0]
         inject = pnp_on(self.t, self.injection_schedule)
@@ -831,6 +880,8 @@ class I2VGenXLUNet(nn.Module):
                        residual=ctx.fps_emb)
         ctx.temb_all = ops.gemm(ops.silu(emb), self._w_temb_all, bias=self._b_temb_all)
         ctx.stem_ctx.temb_all = ctx.temb_all
+        ctx.emb = emb   # [B, 1280] time + fps embedding (what a replaced ResNet forward receives as temb)
+        ctx.stem_ctx.emb = emb[:ctx.stem_ctx.B]
         # stem.  With ``ctx.shared_stem`` (CFG batches [.., negative, positive]: the last two share latent, image latents,
         # fps and timestep and differ only in the cross-attention context) everything up to the first cross-attention
         # -- conv_in, transformer_in, the first ResNet / temporal-conv / self-attention of down_blocks[0] -- runs

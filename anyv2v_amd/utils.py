@@ -6,6 +6,7 @@ import glob
 import logging
 import os
 import random
+import shutil
 import threading
 from typing import Dict, List, Optional
 
@@ -25,10 +26,30 @@ def seed_everything(seed):
     np.random.seed(seed)
 
 
+_PENDING: Dict[str, "LatentTrajectory"] = {}   # output_dir (absolute) -> trajectory whose writer thread is still running
+_PENDING_LOCK = threading.Lock()
+
+
+def wait_for_pending_writes(ddim_latents_path=None):
+    """Join the background writer of ``ddim_latents_path`` (all writers when None).  Every reader of ``ddim_latents_*.pt``
+    in this module calls it first, so ``pipe.invert(output_dir=d)`` followed by ``sample_with_pnp(ddim_inv_latents_path=d)``
+    in one process -- the reference's demo flow, where each file is written synchronously inside the loop
+    (``pipeline_i2vgen_xl.py:1424-1428``) -- never sees a missing or truncated file."""
+    with _PENDING_LOCK:
+        if ddim_latents_path is None:
+            trajs = list(_PENDING.values())
+        else:
+            t = _PENDING.get(os.path.abspath(str(ddim_latents_path)))
+            trajs = [t] if t is not None else []
+    for tr in trajs:
+        tr.wait()
+
+
 def load_ddim_latents_at_t(t, ddim_latents_path):
     """``i2vgen-xl/utils.py:25-30``.  ``ddim_latents_path`` may also be an in-memory ``LatentTrajectory``."""
     if isinstance(ddim_latents_path, LatentTrajectory):
         return ddim_latents_path[int(t)]
+    wait_for_pending_writes(ddim_latents_path)
     ddim_latents_at_t_path = os.path.join(ddim_latents_path, f"ddim_latents_{int(t)}.pt")
     assert os.path.exists(ddim_latents_at_t_path), f"Missing latents at t {t} path {ddim_latents_at_t_path}"
     ddim_latents_at_t = torch.load(ddim_latents_at_t_path, map_location="cpu")
@@ -39,9 +60,19 @@ def load_ddim_latents_at_t(t, ddim_latents_path):
 def load_ddim_latents_at_T(ddim_latents_path):
     if isinstance(ddim_latents_path, LatentTrajectory):
         return ddim_latents_path[max(ddim_latents_path.keys())]
+    wait_for_pending_writes(ddim_latents_path)
     noisest = max(int(x.split("_")[-1].split(".")[0])
                   for x in glob.glob(os.path.join(ddim_latents_path, "ddim_latents_*.pt")))
     return torch.load(os.path.join(ddim_latents_path, f"ddim_latents_{noisest}.pt"), map_location="cpu")
+
+
+def inversion_is_complete(output_dir, latents_dir=None) -> bool:
+    """Stage-1 skip criterion.  The reference skips an entry when ``output_dir`` exists
+    (``run_group_ddim_inversion.py:118-120``); here additionally no half-written latents directory (``*.partial-<pid>``,
+    see ``LatentTrajectory.save``) may sit next to ``latents_dir`` -- a run that crashed mid-write is redone, not skipped."""
+    if not os.path.exists(output_dir):
+        return False
+    return not (latents_dir and glob.glob(os.path.abspath(str(latents_dir)) + ".partial-*"))
 
 
 class LatentTrajectory:
@@ -70,28 +101,58 @@ class LatentTrajectory:
     def __len__(self):
         return len(self._lat)
 
-    def save(self, output_dir: str, background: bool = True):
-        os.makedirs(output_dir, exist_ok=True)
+    def save(self, output_dir: str, background: bool = False):
+        """Write ``ddim_latents_{t}.pt`` (the reference's format).  Every file is written under a temporary name and
+        renamed, and a directory that did not exist before appears under its final name only when it is complete: the
+        runners use "output_dir exists" as the stage-1 skip criterion (``run_group_ddim_inversion.py:118-120``), so a crash
+        mid-write must not leave a partial directory behind.  ``background=True`` returns at once; readers in this module
+        join the writer first (``wait_for_pending_writes``)."""
+        final = os.path.abspath(output_dir)
+        self.wait()
+        for stale in glob.glob(final + ".partial-*"):   # left behind by a run that died mid-write
+            shutil.rmtree(stale, ignore_errors=True)
+        fresh = not os.path.exists(final)
+        stage = f"{final}.partial-{os.getpid()}" if fresh else final
+        os.makedirs(stage, exist_ok=True)
         host = {t: x.detach().to("cpu") for t, x in self._lat.items()}  # one sync for the whole trajectory
 
         def work():
-            for t, x in host.items():
-                torch.save(x, os.path.join(output_dir, f"ddim_latents_{t}.pt"))
+            try:
+                for t, x in host.items():
+                    tmp = os.path.join(stage, f".ddim_latents_{t}.pt.tmp-{os.getpid()}")
+                    torch.save(x, tmp)
+                    os.replace(tmp, os.path.join(stage, f"ddim_latents_{t}.pt"))
+                if fresh:
+                    try:
+                        os.rename(stage, final)
+                    except OSError:  # somebody created `final` meanwhile: move the files over one by one
+                        os.makedirs(final, exist_ok=True)
+                        for name in os.listdir(stage):
+                            os.replace(os.path.join(stage, name), os.path.join(final, name))
+                        os.rmdir(stage)
+            finally:
+                with _PENDING_LOCK:
+                    if _PENDING.get(final) is self:
+                        del _PENDING[final]
 
         if background:
+            with _PENDING_LOCK:
+                _PENDING[final] = self
             self._writer = threading.Thread(target=work, daemon=False)
             self._writer.start()
         else:
             work()
 
     def wait(self):
-        if self._writer is not None:
-            self._writer.join()
+        w = self._writer
+        if w is not None and w is not threading.current_thread():
+            w.join()
             self._writer = None
 
     @classmethod
     def load(cls, ddim_latents_path: str, device=None, timesteps=None) -> "LatentTrajectory":
         tr = cls()
+        wait_for_pending_writes(ddim_latents_path)
         if timesteps is None:
             timesteps = [int(x.split("_")[-1].split(".")[0])
                          for x in glob.glob(os.path.join(ddim_latents_path, "ddim_latents_*.pt"))]

@@ -85,19 +85,27 @@ def install_stubs():
 
 
 def _load(path: str, name: str):
-    spec = importlib.util.spec_from_file_location(name, path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    """Import one reference file with the stand-ins visible, then take them out of ``sys.modules`` again: the loaded
+    module keeps the names it imported, and nothing else in the process (``transformers`` probes ``torchvision`` with
+    ``importlib.util.find_spec``) ever sees a fake package."""
+    before = set(sys.modules)
+    install_stubs()
+    try:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k in set(sys.modules) - before:
+            if k == "torchvision" or k.startswith("torchvision.") or k == "diffusers" or k.startswith("diffusers."):
+                del sys.modules[k]
     return mod
 
 
 def load_reference_pnp_utils():
     """The reference's ``i2vgen-xl/pnp_utils.py``, verbatim."""
-    install_stubs()
     return _load(os.path.join(REFERENCE_ROOT, "i2vgen-xl", "pnp_utils.py"), "_ref_pnp_utils")
 
 
 def load_reference_inverse_scheduler():
     """The reference's vendored ``consisti2v/ddim_inverse_scheduler.py``, verbatim."""
-    install_stubs()
     return _load(os.path.join(REFERENCE_ROOT, "consisti2v", "ddim_inverse_scheduler.py"), "_ref_ddim_inverse")

@@ -659,6 +659,98 @@ def check_unet_golden():
     return out
 
 
+def check_foreign_hooks(source="oracle"):
+    """Seams B1 / B2: torch-style hook code from OUTSIDE the product package drives the native UNet.
+
+    ``source="reference"``: the reference's own ``i2vgen-xl/pnp_utils.py`` (imported verbatim through
+    ``oracle.ref_stubs``; only where /root/reference exists, i.e. the CPU suite) -- its ``register_conv_injection``
+    replaces ``up_blocks[1].resnets[1].forward`` (``pnp_utils.py:130-131``) and its ``register_*_attention_pnp`` plug
+    ``ModifiedSpaAttnProcessor`` / ``ModifiedTmpAttnProcessor`` objects into 16 ``attn1.processor`` slots (``:235-242,340-347``).
+    ``source="oracle"``: ``oracle.pnp_oracle``'s restatement of the same hooks (pinned to the reference by the golden
+    fixture) -- what the GPU box can run.  The result must equal the fixture produced by the reference hooks on the oracle
+    UNet, and the native hooks' result on the same model."""
+    import types
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.unet import Attention, ResnetBlock2D
+    out = []
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "pnp_hooks_mini.pt"))
+    inp = {k: v.to(DEV) for k, v in gold["inputs"].items()}
+    kw = dict(fps=inp["fps"], image_latents=inp["image_latents"].half(), image_embeddings=inp["image_embeddings"].half(),
+              encoder_hidden_states=inp["encoder_hidden_states"].half())
+    sample = inp["sample"].half()
+    n, p = gold["n_steps"], gold["pnp"]
+    ts = torch.arange(n).flip(0) * (1000 // n) + 1
+    k = lambda name: ts[: int(n * p[name])]
+    # native hooks first (reference result for "same model, same kernels")
+    native, _, _ = build_pair("mini", gold["mini_seed"])
+    pipe = types.SimpleNamespace(unet=native)
+    pnp_utils.register_conv_injection(pipe, k("pnp_f_t"))
+    pnp_utils.register_spatial_attention_pnp(pipe, k("pnp_spatial_attn_t"))
+    pnp_utils.register_temp_attention_pnp(pipe, k("pnp_temp_attn_t"))
+    v_native = {}
+    for t in (981, 701, 301, 101):
+        pnp_utils.register_time(pipe, t)
+        v_native[t] = native(sample, t, **kw)[0].float().cpu()
+    # foreign hooks on a fresh native model
+    native, _, _ = build_pair("mini", gold["mini_seed"])
+    pipe = types.SimpleNamespace(unet=native)
+    calls = {"attn": 0, "resnet": 0}
+    orig_a, orig_r = Attention._run_foreign, ResnetBlock2D._run_foreign
+
+    def count_a(self, *a, **kk):
+        calls["attn"] += 1
+        return orig_a(self, *a, **kk)
+
+    def count_r(self, *a, **kk):
+        calls["resnet"] += 1
+        return orig_r(self, *a, **kk)
+
+    Attention._run_foreign, ResnetBlock2D._run_foreign = count_a, count_r
+    try:
+        if source == "reference":
+            from oracle import ref_stubs
+            ref = ref_stubs.load_reference_pnp_utils()
+            ref.register_conv_injection(pipe, k("pnp_f_t"))
+            ref.register_spatial_attention_pnp(pipe, k("pnp_spatial_attn_t"))
+            ref.register_temp_attention_pnp(pipe, k("pnp_temp_attn_t"))
+            reg_time = lambda t: ref.register_time(pipe, t)
+        else:
+            from oracle import pnp_oracle
+            pnp_oracle.register_conv_injection(native, k("pnp_f_t"))
+            pnp_oracle.register_spatial_attention_pnp(native, k("pnp_spatial_attn_t"))
+            pnp_oracle.register_temp_attention_pnp(native, k("pnp_temp_attn_t"))
+            reg_time = lambda t: pnp_oracle.register_time(native, t)
+        assert pnp_utils.has_foreign_hooks(native)
+        for t in (981, 701, 301, 101):
+            reg_time(t)
+            v = native(sample, t, **kw)[0].float().cpu()
+            out.append(_res(f"native UNet driven by the {source} hook code t={t} vs reference pnp_utils fixture", v, gold[f"v_hook_t{t}"], 3e-2))
+            out.append(_res(f"native UNet: {source} hook code == native hooks t={t}", v, v_native[t], 6e-3))
+    finally:
+        Attention._run_foreign, ResnetBlock2D._run_foreign = orig_a, orig_r
+    # 16 foreign processors + 1 replaced ResNet forward, 4 forwards
+    out.append(dict(name=f"seam B1: Attention._run_foreign ran 16 x 4 times ({calls['attn']})", err=float(calls["attn"] != 64), l2=0.0, tol=0.5,
+                    ok=calls["attn"] == 64))
+    out.append(dict(name=f"seam B2: ResnetBlock2D replaced forward ran 4 times ({calls['resnet']})", err=float(calls["resnet"] != 4), l2=0.0,
+                    tol=0.5, ok=calls["resnet"] == 4))
+    # the module's own torch-style forward (NCHW in / out) == its token-layout run
+    blk = native.up_blocks[2].resnets[0]
+    del_forward = native.up_blocks[1].resnets[1].__dict__.pop("forward", None)  # noqa: F841 (restore the class forward)
+    g = torch.Generator().manual_seed(3)
+    N_, H_ = 4, 8
+    x = (torch.randn(N_, blk.in_channels, H_, H_, generator=g)).half().to(DEV)
+    temb = torch.randn(N_, native.cfg.time_embed_dim, generator=g).half().to(DEV)
+    y = blk(x, temb)
+    xf, tf = x.float().cpu(), temb.float().cpu()
+    P = {kk: vv.float().cpu() for kk, vv in blk.state_dict().items()}
+    h = F.conv2d(F.silu(F.group_norm(xf, 32, P["norm1.weight"], P["norm1.bias"], 1e-5)), P["conv1.weight"], P["conv1.bias"], padding=1)
+    h = h + F.linear(F.silu(tf), P["time_emb_proj.weight"], P["time_emb_proj.bias"])[:, :, None, None]
+    h = F.conv2d(F.silu(F.group_norm(h, 32, P["norm2.weight"], P["norm2.bias"], 1e-5)), P["conv2.weight"], P["conv2.bias"], padding=1)
+    ref_y = F.conv2d(xf, P["conv_shortcut.weight"], P["conv_shortcut.bias"]) + h
+    out.append(_res("ResnetBlock2D torch-style forward(NCHW, temb) vs torch fp32", y.float().cpu(), ref_y, 6e-3))
+    return out
+
+
 def config1_inputs(cfg, B, Fr=8, hw=32, seed=8888):
     """BASELINE config 1 inputs: random latents, frame-position planes, seed 8888."""
     g = torch.Generator().manual_seed(seed)

@@ -154,11 +154,15 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     from anyv2v_amd.parallel import gather_latents, init_distributed, shard_entries
     r, lr, w = init_distributed("gloo")
-    entries = [{"active": True, "id": i} for i in range(5)]
+    entries = [{"active": i != 3, "id": i} for i in range(6)]   # 5 active entries: rank 0 runs three, rank 1 two
     mine = shard_entries(entries, r, w)
-    lat = torch.full((1, 4, 2, 3, 3), float(sum(e["id"] for e in mine)), dtype=torch.float16)
-    got = gather_latents(lat, lat.shape, lat.dtype, "cpu")
-    torch.save([float(g[0, 0, 0, 0, 0]) for g in got], os.path.join(out_dir, f"r{r}.pt"))
+    lats = [torch.full((1, 4, 2, 3, 3), float(e["id"]), dtype=torch.float16) for e in mine]
+    got = gather_latents(lats, 5, (1, 4, 2, 3, 3), torch.float16, "cpu")
+    assert tuple(got.shape) == (5, 4, 2, 3, 3)
+    torch.save([float(g[0, 0, 0, 0]) for g in got], os.path.join(out_dir, f"r{r}.pt"))
+    none = gather_latents([], 1, (1, 4, 2, 3, 3), torch.float16, "cpu") if r == 1 else \
+        gather_latents([torch.ones(1, 4, 2, 3, 3, dtype=torch.float16)], 1, (1, 4, 2, 3, 3), torch.float16, "cpu")
+    assert float(none.sum()) == 4 * 2 * 3 * 3     # a rank without entries contributes an (ignored) zero slot
     dist.barrier()
     dist.destroy_process_group()
 
@@ -168,7 +172,7 @@ def test_all_gather_of_edited_latents_world2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert a == b == [0.0 + 2 + 4, 1.0 + 3]  # rank0 got entries 0,2,4; rank1 got 1,3
+    assert a == b == [0.0, 1.0, 2.0, 4.0, 5.0]  # EVERY active entry's latents, in entry order, on every rank
 
 
 def _bench_worker(rank, world, port, out_dir):

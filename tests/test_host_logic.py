@@ -48,6 +48,20 @@ def test_native_unet_vs_reference_generated_golden(cpu_ops):
     _ok(gc.check_unet_golden())
 
 
+def test_reference_pnp_utils_drives_the_native_unet(cpu_ops):
+    """Seams B1 / B2: the reference's OWN ``i2vgen-xl/pnp_utils.py`` (verbatim, via oracle.ref_stubs) registered on
+    ``anyv2v_amd.unet.I2VGenXLUNet`` -- 16 foreign attention processors + the replaced ResNet ``forward`` -- reproduces
+    the reference-generated fixture and the native hooks."""
+    from oracle import ref_stubs
+    if not ref_stubs.reference_available():
+        pytest.skip("needs /root/reference")
+    _ok(gc.check_foreign_hooks("reference"))
+
+
+def test_oracle_hook_code_drives_the_native_unet(cpu_ops):
+    _ok(gc.check_foreign_hooks("oracle"))
+
+
 def test_native_unet_vs_oracle_with_and_without_pnp(cpu_ops):
     _ok(gc.check_unet_vs_oracle("mini", 3, 4, 8))
     _ok(gc.check_unet_vs_oracle("mini", 1, 8, 16, with_pnp=False))
@@ -125,14 +139,22 @@ def test_init_pnp_schedule_semantics():
     # sites: not block 0 of up_blocks[1] (pnp_utils.py:235)
     assert unet.up_blocks[1].attentions[0].transformer_blocks[0].attn1.processor.injection_schedule is None
     pnp_utils.register_time(pipe, 801)
-    assert pnp_utils.injection_state(pipe) == (True, True, True)
+    # (conv, 8 spatial sites, 8 temporal sites): every site contributes to the HIP-graph key
+    assert pnp_utils.injection_state(pipe) == (True,) + (True,) * 8 + (True,) * 8
     pnp_utils.register_time(pipe, 781)
-    assert pnp_utils.injection_state(pipe) == (True, False, True)
+    assert pnp_utils.injection_state(pipe) == (True,) + (False,) * 8 + (True,) * 8
     pnp_utils.register_time(pipe, 701)
-    assert pnp_utils.injection_state(pipe) == (False, False, True)
+    assert pnp_utils.injection_state(pipe) == (False,) + (False,) * 8 + (True,) * 8
+    # one site with its own schedule ("Disable PNP" per module, pnp_utils.py:229-232) changes the key
+    one = unet.up_blocks[3].attentions[1].transformer_blocks[0].attn1.processor
+    saved, one.injection_schedule = one.injection_schedule, frozenset()
+    pnp_utils.register_time(pipe, 801)
+    st = pnp_utils.injection_state(pipe)
+    assert st != (True,) * 17 and sum(st) == 16
+    one.injection_schedule = saved
     assert pnp_on(1000, frozenset()) and not pnp_on(999, frozenset())  # magic t == 1000 (pnp_utils.py:109)
     pnp_utils.clear_time(pipe)
-    assert pnp_utils.injection_state(pipe) == (False, False, False)
+    assert pnp_utils.injection_state(pipe) == (False,) * 17
     assert output_suffix(cfg, 0) == "ddim_init_latents_t_idx_0_nsteps_50_cfg_9.0_pnpf0.29_pnps0.2_pnpt1.0"
 
 
@@ -152,6 +174,63 @@ def test_latent_trajectory_store_roundtrip(tmp_path):
         load_ddim_latents_at_t(41, str(d))
     tr2 = LatentTrajectory.load(str(d))
     assert sorted(tr2.keys()) == [1, 21, 981]
+
+
+def test_background_trajectory_writer_never_races_its_readers(tmp_path, monkeypatch):
+    """invert(output_dir=d) then sample_with_pnp(ddim_inv_latents_path=d) in one process.  With the background
+    writer every reader joins it first; files appear atomically; a fresh directory appears only when complete."""
+    import time
+    from anyv2v_amd import utils
+    from anyv2v_amd.utils import LatentTrajectory, inversion_is_complete, load_ddim_latents_at_T, load_ddim_latents_at_t
+    real_save = torch.save
+
+    def slow_save(obj, path, *a, **k):
+        time.sleep(0.05)
+        return real_save(obj, path, *a, **k)
+
+    monkeypatch.setattr(utils.torch, "save", slow_save)
+    tr = LatentTrajectory()
+    for t in range(1, 400, 20):
+        tr[t] = torch.full((1, 4, 2, 3, 3), float(t), dtype=torch.float16)
+    out = tmp_path / "exp"
+    d = out / "ddim_latents"
+    tr.save(str(d), background=True)
+    assert not d.exists() and not inversion_is_complete(str(out), str(d))   # staged under *.partial-<pid> until complete
+    assert float(load_ddim_latents_at_t(381, str(d))[0, 0, 0, 0, 0]) == 381      # joins the writer instead of asserting
+    assert d.exists() and inversion_is_complete(str(out), str(d)) and not utils._PENDING
+    assert len(os.listdir(d)) == 20 and all(n.startswith("ddim_latents_") for n in os.listdir(d))
+    tr.save(str(d), background=True)                                                # directory exists: per-file atomic replace
+    assert float(load_ddim_latents_at_T(str(d)).max()) == 381
+    assert len(LatentTrajectory.load(str(d))) == 20
+    # a crashed writer's leftovers make the entry "not complete" and are cleaned by the next save
+    os.makedirs(str(d) + ".partial-99999")
+    assert not inversion_is_complete(str(out), str(d))
+    tr.save(str(d))                                                                 # default: synchronous
+    assert inversion_is_complete(str(out), str(d))
+
+
+def test_one_clip_per_call_and_crop_rounding(cpu_ops):
+    from PIL import Image
+    from anyv2v_amd.encoders import _center_crop_wide
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler
+    native, _, ocfg = gc.build_pair("mini", 1234)
+    pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+    inp = gc.config1_inputs(ocfg, 2, 4, 8)
+    kw = dict(image_embeddings=inp["image_embeddings"][:1].half(), image_latents=inp["image_latents"][:1].half(), height=64,
+              width=64, num_frames=4, num_inference_steps=2, guidance_scale=1.0, target_fps=8, latents=inp["sample"][:1].half())
+    with pytest.raises(ValueError, match="one clip per call"):
+        pipe.invert(prompt_embeds=inp["encoder_hidden_states"].half(), **kw)           # a batch of two prompts
+    with pytest.raises(ValueError, match="num_videos_per_prompt"):
+        pipe.invert(prompt_embeds=inp["encoder_hidden_states"][:1].half(), num_videos_per_prompt=2, **kw)
+    # pipeline_i2vgen_xl.py:1496,1505: round(width // scale) -- 1003x600 -> 512x512: scale 1.171875, 1003 // scale = 855.0
+    # (1003 / scale = 855.89 would round to 856 and shift the crop window)
+    img = Image.fromarray((np.arange(600 * 1003 * 3) % 251).astype(np.uint8).reshape(600, 1003, 3))
+    scale = min(1003 / 512, 600 / 512)
+    ref = img.resize((round(1003 // scale), round(600 // scale)), resample=Image.BOX)
+    x1, y1 = (ref.width - 512) // 2, (ref.height - 512) // 2
+    assert ref.width == 855
+    assert np.array_equal(np.asarray(_center_crop_wide(img, (512, 512))), np.asarray(ref.crop((x1, y1, x1 + 512, y1 + 512))))
 
 
 def test_pipeline_input_checks():
