@@ -38,169 +38,6 @@ __device__ __forceinline__ long long attn_row(long long i, int inner, long long 
     return (i / inner) * so + (i % inner) * si;
 }
 
-__global__ __launch_bounds__(256) void flash_attn_d64_kernel(const AttnK p) {
-    __shared__ __attribute__((aligned(16))) char smem[16384];
-    char* const Ks = smem;
-    char* const VT = smem + 8192;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int bid = blockIdx.x;
-    const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int qt = bid % p.q_tiles;
-    const int bh = bid / p.q_tiles;
-    const int h = bh % p.heads;
-    const int i = bh / p.heads;  // batch element
-
-    const int iq = p.qk_mod > 0 ? i % p.qk_mod : i;
-    const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
-    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
-    const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-
-    // ---- Q fragments (B operand of S^T): lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7]
-    const int q0 = qt * 128 + w * 32;
-    const bool wave_active = q0 < p.Sq;
-    const int qrow = q0 + l31;
-    h8 qf[4];
-    {
-        const int qr = qrow < p.Sq ? qrow : p.Sq - 1;
-        const half_t* qp = p.Q + (qbase + (long long)qr * p.q_seq) * p.ldq + h * 64 + 8 * hi;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h8*)(qp + 16 * ks);
-    }
-
-    // ---- staging assignment
-    const int skey = tid >> 3;   // K: keys skey, skey + 32
-    const int sdc = tid & 7;     // 16-byte chunk along d
-    const int vk0 = 2 * (tid >> 3);  // V: keys vk0, vk0 + 1
-    h8 rk[2], rv[2];
-    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto load_tile = [&](int key0) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int key = key0 + skey + 32 * t;
-            rk[t] = key < p.Sk ? *(const h8*)(p.K + (kbase + (long long)key * p.kv_seq) * p.ldk + h * 64 + sdc * 8) : zero8;
-            const int vkey = key0 + vk0 + t;
-            rv[t] = vkey < p.Sk ? *(const h8*)(p.V + (vbase + (long long)vkey * p.kv_seq) * p.ldv + h * 64 + sdc * 8) : zero8;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int key = skey + 32 * t;
-            *(h8*)(Ks + key * 128 + ((sdc ^ ((key >> 1) & 7)) << 4)) = rk[t];
-        }
-        // V^T: pack the two adjacent keys of this thread for each of its 8 d's
-        const int pos = (vk0 & ~12) | ((vk0 & 4) << 1) | ((vk0 & 8) >> 1);  // swap key bits 2 and 3
-        const int chunk = pos >> 3, within = pos & 7;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = sdc * 8 + e;
-            h2 pr = {rv[0][e], rv[1][e]};
-            *(h2*)(VT + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4) + within * 2) = pr;
-        }
-    };
-
-    f16v oacc[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    const float c = p.scale_log2;
-
-    const int ntiles = (p.Sk + 63) / 64;
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int j = 0; j < ntiles; ++j) {
-        const bool has_next = j + 1 < ntiles;
-        if (has_next) load_tile((j + 1) * 64);
-        if (wave_active) {
-            // ---- S^T = K Q^T  (two 32-key blocks)
-            f16v sacc[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-                const int key = 32 * kb + l31;
-                const char* krow = Ks + key * 128;
-                const int fk = (key >> 1) & 7;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const h8 kf = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
-                }
-            }
-            // ---- mask the key tail, online softmax
-            const int key_base = j * 64 + 4 * hi;
-            float mx = -1e30f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2);
-                    if (key >= p.Sk) sacc[kb][r] = -1e30f;
-                    mx = fmaxf(mx, sacc[kb][r]);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f((m_run - m_new) * c);
-            const float mc = m_new * c;
-            m_run = m_new;
-            float psum = 0.f;
-            h8 pf[4];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = exp2f(fmaf(sacc[kb][r], c, -mc));
-                    psum += pv;
-                    pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
-                }
-            l_run = l_run * alpha + psum;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                oacc[0][r] *= alpha;
-                oacc[1][r] *= alpha;
-            }
-            // ---- O^T += V^T P^T
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int d = 32 * db + l31;
-                const char* vrow = VT + d * 128;
-                const int fd = (d >> 1) & 7;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const h8 vf = *(const h8*)(vrow + (((2 * t + hi) ^ fd) << 4));
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t], oacc[db], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-        if (has_next) store_tile();
-        __syncthreads();
-    }
-
-    if (wave_active && qrow < p.Sq) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
-        half_t* op = p.O + (obase + (long long)qrow * p.q_seq) * p.ldo + h * 64 + 4 * hi;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                h4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[db][4 * g + e] * inv);
-                *(h4*)(op + 32 * db + 8 * g) = o;
-            }
-    } else if (wave_active) {
-        // keep the shuffle convergent for partially filled waves
-        (void)__shfl_xor(l_run, 32, 64);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // v2: same math / fragment layouts as flash_attn_d64_kernel, but K and V tiles are fetched by LDS-DMA
 // (global_load_lds, 16 B per lane) into a 4-stage LDS ring three tiles ahead, with counted s_waitcnt vmcnt and ONE
@@ -487,362 +324,6 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// v3 (EXPERIMENTAL, opt-in through flag bit5; kept as a measured negative result): the v2 data path (LDS-DMA rings,
-// swapped MFMAs, hardware-transposed V^T fragments) with the KV loop software-pipelined INSIDE each wave.  In v2 a wave
-// runs QK^T (8 MFMAs) -> softmax (~150 VALU) -> PV (8 MFMAs) strictly in sequence and relies on the other waves of its
-// SIMD to fill the matrix pipe while it is on the VALU.  Here iteration j carries three independent streams in one
-// straight-line body:
-//     VALU : softmax of tile j          (scores produced by the previous iteration)
-//     MFMA : O^T += V^T P^T of tile j-1 (probabilities produced by the previous iteration)
-//     MFMA : S^T  = K Q^T   of tile j+1
-// so every MFMA is issued with independent VALU work behind it in the same wave (sched_group_barrier interleave).
-// Costs: scores and probabilities are double-buffered in registers (2 x 32 + 2 x 16 VGPRs -> 250 VGPRs, two waves per
-// SIMD instead of three), K needs tiles j+1..j+3 and V tiles j-1..j+2 resident, i.e. separate rings of 3 and 4 stages
-// (56 KiB per block, two blocks per CU).  All LDS reads are inline asm behind explicit lgkmcnt waits (V^T fragments
-// first, then K), the cross-half maximum is v_permlane32_swap instead of an LDS shuffle (no compiler-inserted
-// lgkmcnt(0) in the body), and the O rescale is unconditional.
-// Measured (profiles/r01_attn_probe.txt, r01_issue_probe.txt): bit-compatible with v2 up to the row-sum order, but
-// 1.55 ms against v2's 1.30 ms at (48, 5, 4096, 64).  The microbenchmark explains it: on this part 16 MFMAs + the
-// softmax's ~160 VALU instructions cost ~470 ns per SIMD whether they are interleaved inside one wave or issued as
-// separate phases by three co-resident waves (MFMA alone 345 ns, VALU alone 290-315 ns; packed fp32 and dot
-// instructions do not overlap with MFMA at all), so the in-wave pipeline buys nothing and pays for its third wave.
-// Same products and accumulation order per output as v2; only the row sum is accumulated as two interleaved partials.
-// Requires Sq % 128 == 0 (every wave active); Sk arbitrary.
-typedef float f2v __attribute__((ext_vector_type(2)));
-
-template <int OFF>
-__device__ __forceinline__ h8 lds_rd128(unsigned lds_addr) {
-    h8 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(OFF));
-    return r;
-}
-
-template <int K>
-struct IC {
-    static constexpr int value = K;
-};
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_d64_v3_kernel(
-    const AttnK p, const half_t* zeros) {
-    constexpr int TILE = 8192, KST = 3, VST = 4;
-    __shared__ __attribute__((aligned(16))) char smem[(KST + VST) * TILE];
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int bid = blockIdx.x;
-    const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int qt = bid % p.q_tiles;
-    const int bh = bid / p.q_tiles;
-    const int h = bh % p.heads;
-    const int i = bh / p.heads;
-
-    const int iq = p.qk_mod > 0 ? i % p.qk_mod : i;
-    const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
-    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
-    const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-
-    const int qrow = qt * 128 + w * 32 + l31;
-    h8 qf[4];
-    {
-        const half_t* qp = p.Q + (qbase + (long long)qrow * p.q_seq) * p.ldq + h * 64 + 8 * hi;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h8*)(qp + 16 * ks);
-    }
-
-    // ---- LDS-DMA: same per-thread assignment and source-side swizzles as v2; K and V rings advance separately
-    const int drow = tid >> 3, dpc = tid & 7;
-    const int nt = (p.Sk + 63) / 64;
-    // wave-uniform tile pointers (SGPRs, advanced by scalar adds) + constant 32-bit per-lane byte offsets
-    const char* kptr = (const char*)(p.K + kbase * p.ldk + h * 64);
-    const char* vptr = (const char*)(p.V + vbase * p.ldv + h * 64);
-    unsigned koff[2], voff_g[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int row = drow + 32 * t;
-        koff[t] = (unsigned)(((long long)row * p.kv_seq * p.ldk + ((dpc ^ ((row >> 1) & 7)) << 3)) * 2);
-        voff_g[t] = (unsigned)(((long long)row * p.kv_seq * p.ldv + ((dpc ^ av_vswz(row)) << 3)) * 2);
-    }
-    const long long kstep = 128ll * p.kv_seq * p.ldk, vstep = 128ll * p.kv_seq * p.ldv;  // bytes per 64-key tile
-    int k_iss_stage = 0, v_iss_stage = 0, k_iss_key0 = 0, v_iss_key0 = 0;
-    const int w_s = __builtin_amdgcn_readfirstlane(w);  // wave index in an SGPR: the DMA's LDS base (m0) stays scalar
-    // Only the last real tile (ragged) and the tiles past the end need the per-row test; every other issue is two bare
-    // DMA instructions (SGPR base + VGPR offset) and a scalar pointer advance (wave-uniform branch).
-    auto issue_tile = [&](const char*& base, const unsigned (&off)[2], long long step, char* st, int key0) {
-        if (key0 + 64 <= p.Sk) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) glds16_attn((const half_t*)(base + off[t]), st + (t * 256 + w_s * 64) * 16);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                glds16_attn(key0 + drow + 32 * t < p.Sk ? (const half_t*)(base + off[t]) : zeros,
-                            st + (t * 256 + w_s * 64) * 16);
-        }
-        base += step;
-    };
-    auto issue_k = [&]() {
-        issue_tile(kptr, koff, kstep, smem + k_iss_stage * TILE, k_iss_key0);
-        k_iss_key0 += 64;
-        if (++k_iss_stage == KST) k_iss_stage = 0;
-    };
-    auto issue_v = [&]() {
-        issue_tile(vptr, voff_g, vstep, smem + (KST + v_iss_stage) * TILE, v_iss_key0);
-        v_iss_key0 += 64;
-        v_iss_stage = (v_iss_stage + 1) & (VST - 1);
-    };
-
-    // ---- fragment addresses (bytes, LDS address space)
-    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned kaddr[4];  // K[key = l31 (+32 kb)][d = 16 ks + 8 hi ..]: chunk (2 ks + hi) ^ ((key >> 1) & 7)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = smem_lds + l31 * 128 + (((2 * ks + hi) ^ ((l31 >> 1) & 7)) << 4);
-    const int i16 = lane & 15;
-    const int vrow = 4 * hi + (i16 >> 2);
-    const int vfl = av_vswz(vrow);
-    const int vc0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
-    unsigned vaddr[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-        vaddr[db] = smem_lds + KST * TILE + vrow * 128 + (((4 * db + vc0) ^ vfl) << 4) + (i16 & 1) * 8;
-
-    f16v oacc[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
-    f16v sacc[2][2];  // [parity][key block]
-    h8 pf[2][4];      // [parity][16-key step]
-    float m_run = -1e30f, l_run = 0.f;
-    const float c = p.scale_log2;
-    int k_rd_stage = 0;  // ring stage of the K tile the next QK^T reads
-    int v_rd_stage = 0;  // ring stage of the V tile the next PV reads
-
-#define A3_TR8(dst, base)                                                                              \
-    dst[0] = lds_tr16<0>(base);    dst[1] = lds_tr16<1024>(base); dst[2] = lds_tr16<2048>(base);        \
-    dst[3] = lds_tr16<3072>(base); dst[4] = lds_tr16<4096>(base); dst[5] = lds_tr16<5120>(base);        \
-    dst[6] = lds_tr16<6144>(base); dst[7] = lds_tr16<7168>(base)
-#define A3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define A3_PIN(x) asm volatile("" : "+v"(x))
-
-    auto read_k = [&](h8 (&kf)[2][4]) {
-        const unsigned so = (unsigned)k_rd_stage * TILE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf[0][ks] = lds_rd128<0>(kaddr[ks] + so);
-            kf[1][ks] = lds_rd128<4096>(kaddr[ks] + so);
-        }
-        if (++k_rd_stage == KST) k_rd_stage = 0;
-    };
-    auto read_v = [&](fp16x4v_t (&va)[8], fp16x4v_t (&vb)[8]) {
-        const unsigned so = (unsigned)v_rd_stage * TILE;
-        A3_TR8(va, vaddr[0] + so);
-        A3_TR8(vb, vaddr[1] + so);
-        v_rd_stage = (v_rd_stage + 1) & (VST - 1);
-    };
-    // exp2(s * c - m * c) for one 32-key block: 16 scores per lane -> two 8-half P fragments, packed math
-    auto exp_block = [&](const f16v& s, float mc, f2v& psum, h8& p0, h8& p1) {
-        const f2v cc = {c, c}, mm = {-mc, -mc};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f2v x = {s[r], s[r + 1]};
-            const f2v a = __builtin_elementwise_fma(x, cc, mm);
-            const f2v e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-            psum += e;
-            h8& dst = r < 8 ? p0 : p1;
-            dst[r & 7] = (half_t)e[0];
-            dst[(r & 7) + 1] = (half_t)e[1];
-        }
-    };
-
-    // ---- prologue: DMA stream order K0 K1 V0 K2 V1 == the steady-state order "iteration i issues K(i+3), V(i+2)".
-    // Tiles past the end are issued too (their rows fail the `ok` test and copy the zero line into a free stage): the
-    // stream then has the same shape for every Sk and one vmcnt immediate serves every iteration.
-    issue_k();
-    issue_k();
-    issue_v();
-    issue_k();
-    issue_v();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // K0 landed; K1 V0 K2 V1 may be in flight
-    __builtin_amdgcn_s_barrier();
-    {
-        h8 kf[2][4];
-        read_k(kf);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            sacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][ks], qf[ks], ks == 0 ? z : sacc[0][0], 0, 0, 0);
-            sacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][ks], qf[ks], ks == 0 ? z : sacc[0][1], 0, 0, 0);
-        }
-    }
-
-    // ---- one pipelined iteration: softmax(j) | PV(j-1) | QK(j+1).  PAR = j & 1 selects the register set of tile j.
-    auto body = [&](auto par_c, auto prev_c, auto next_c, int j) {
-        constexpr int PAR = decltype(par_c)::value;
-        constexpr bool HAS_PREV = decltype(prev_c)::value != 0, HAS_NEXT = decltype(next_c)::value != 0;
-        f16v(&Sc)[2] = sacc[PAR];
-        f16v(&Sn)[2] = sacc[PAR ^ 1];
-        h8(&Pn)[4] = pf[PAR];
-        h8(&Pp)[4] = pf[PAR ^ 1];
-
-        if (HAS_NEXT)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K(j+1) landed; V(j) K(j+2) V(j+1) may be in flight
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // last tile: V(j) must have landed for the drain
-        __builtin_amdgcn_s_barrier();
-        fp16x4v_t va[8], vb[8];
-        h8 kf[2][4];
-        if (HAS_PREV) read_v(va, vb);
-        if (HAS_NEXT) read_k(kf);
-        __builtin_amdgcn_sched_barrier(0);  // reads first: the DMA address math and the max chain cover their latency
-        if (HAS_NEXT) {
-            issue_k();
-            issue_v();
-        }
-
-        if (!HAS_NEXT && (p.Sk & 63) != 0) {  // key tail: only the last tile can hold masked keys
-            const int key_base = j * 64 + 4 * hi;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) Sc[kb][r] = -1e30f;
-        }
-        // segment 0 (VALU only, covers the LDS latency): row maximum
-        float mx = Sc[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, Sc[kb][r]);
-        {
-            const unsigned mu = __float_as_uint(mx);
-            const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
-        f2v psum = {0.f, 0.f};
-
-        // segment 1: PV(j-1) MFMAs + first half of the exponentials
-        if (HAS_PREV) {
-            if (HAS_NEXT)
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        exp_block(Sc[0], mc, psum, Pn[0], Pn[1]);
-        if (HAS_PREV) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(va[2 * t], va[2 * t + 1]), Pp[t], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vb[2 * t], vb[2 * t + 1]), Pp[t], oacc[1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                A3_SGB(0x008, 1);
-                A3_SGB(0x002, 5);
-            }
-            A3_PIN(oacc[0]);
-            A3_PIN(oacc[1]);
-        }
-        // (empty asm "+v" pins: without them LLVM sinks the softmax into the next iteration's blocks, behind the MFMAs)
-        A3_PIN(Pn[0]);
-        A3_PIN(Pn[1]);
-        A3_PIN(psum);
-        // segment 2: QK(j+1) MFMAs + second half of the exponentials + O / l rescale
-        __builtin_amdgcn_sched_barrier(0);
-        if (HAS_NEXT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        exp_block(Sc[1], mc, psum, Pn[2], Pn[3]);
-        if (HAS_NEXT) {
-            const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                Sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][ks], qf[ks], ks == 0 ? z : Sn[0], 0, 0, 0);
-                Sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][ks], qf[ks], ks == 0 ? z : Sn[1], 0, 0, 0);
-            }
-        }
-        oacc[0] *= alpha;
-        oacc[1] *= alpha;
-        l_run = fmaf(l_run, alpha, psum[0] + psum[1]);
-        if (HAS_NEXT) {
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                A3_SGB(0x008, 1);
-                A3_SGB(0x002, 7);
-            }
-            A3_PIN(Sn[0]);
-            A3_PIN(Sn[1]);
-        }
-        A3_PIN(Pn[2]);
-        A3_PIN(Pn[3]);
-        A3_PIN(oacc[0]);
-        A3_PIN(oacc[1]);
-        A3_PIN(l_run);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    if (nt == 1) {
-        body(IC<0>(), IC<0>(), IC<0>(), 0);
-    } else {
-        body(IC<0>(), IC<0>(), IC<1>(), 0);
-        int j = 1;
-        for (; j + 2 < nt; j += 2) {
-            body(IC<1>(), IC<1>(), IC<1>(), j);
-            body(IC<0>(), IC<1>(), IC<1>(), j + 1);
-        }
-        if (j + 1 < nt) {
-            body(IC<1>(), IC<1>(), IC<1>(), j);
-            ++j;
-        }
-        if (j & 1)
-            body(IC<1>(), IC<1>(), IC<0>(), j);
-        else
-            body(IC<0>(), IC<1>(), IC<0>(), j);
-    }
-    // ---- drain: PV of the last tile (its V landed before the last iteration's barrier)
-    {
-        fp16x4v_t va[8], vb[8];
-        read_v(va, vb);
-        h8 pl[4];
-        const bool odd = ((nt - 1) & 1) != 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pl[t] = odd ? pf[1][t] : pf[0][t];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(va[2 * t], va[2 * t + 1]), pl[t], oacc[0], 0, 0, 0);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vb[2 * t], vb[2 * t + 1]), pl[t], oacc[1], 0, 0, 0);
-        }
-    }
-#undef A3_TR8
-#undef A3_SGB
-#undef A3_PIN
-
-    float l_tot;
-    {
-        const unsigned lu = __float_as_uint(l_run);
-        const auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
-        l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const float inv = 1.0f / l_tot;
-    half_t* op = p.O + (obase + (long long)qrow * p.q_seq) * p.ldo + h * 64 + 4 * hi;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            h4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[db][4 * g + e] * inv);
-            *(h4*)(op + 32 * db + 8 * g) = o;
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Short-sequence attention (S <= 16, head_dim 64): the temporal self-attention of TransformerTemporalModel at the
 // benchmark's 16 frames (pnp_utils.py:247-334).  HBM-bound (4 x 2 KiB per (clip, pixel, head)); one WAVE owns one
 // (batch element, head):
@@ -1028,10 +509,6 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     }
     const long long nwg = (long long)k.batch * k.heads * k.q_tiles;
     AV_CHECK(nwg < (1ll << 31), "attention: grid too large");
-    if (d->flags & 4) {  // v1: register-staged single-tile prefetch (kept for A/B and as a cross-check)
-        hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nwg), dim3(256), 0, s, k);
-        return av_launch_status("flash_attn_d64");
-    }
     static const half_t* zeros = nullptr;
     if (zeros == nullptr) {
         void* ptr = nullptr;
@@ -1043,12 +520,6 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
         const long long nwg3 = (long long)k.qk_mod * k.heads * k.q_tiles;
         hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<pnp3>");
-    }
-    if ((d->flags & 32) && k.Sq % 128 == 0 && !(d->flags & 8)) {
-        // experimental v3 (in-wave software pipeline): correct, but measured 15-20 % slower than v2 on MI355X -- see the
-        // kernel's header and profiles/r01_issue_probe.txt.  Opt-in through flag bit5.
-        hipLaunchKernelGGL(flash_attn_d64_v3_kernel, dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
-        return av_launch_status("flash_attn_d64_v3");
     }
     hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
     return av_launch_status("flash_attn_d64_v2");

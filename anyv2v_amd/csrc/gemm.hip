@@ -926,6 +926,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         if (fills || (d->flags & 8)) {
             k.tilesN = d->N / 320;
             const dim3 grid(tiles_big < 256 ? tiles_big : 256);
+#ifdef ANYV2V_EXPERIMENTS  // probe build only (make experiments -> tools/libanyv2v_hip_experiments.so; tools/gemm_trace.py)
             if ((d->flags & 32) && d->workspace != nullptr && (size_t)grid.x * 32 * sizeof(long long) <= (size_t)d->workspace_bytes) {
                 k.trace = (long long*)d->workspace;  // debug: phase timestamps of each block's first tile
                 if constexpr (MODE == MODE_LINEAR) {
@@ -938,6 +939,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
                 }
                 return av_launch_status("gemm_big<trace>");
             }
+#endif
             if constexpr (MODE == MODE_LINEAR) {
                 if (geglu)
                     hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR>), grid, dim3(512), 0, s, k);
@@ -967,6 +969,8 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         }
     }
     const dim3 grid(tiles * k.splits);
+#ifdef ANYV2V_EXPERIMENTS  // probe build only: per-block phase timestamps (flag 32) and K-loop knock-outs (flags 64..448,
+                           // wrong results by design) -- tools/gemm_trace.py.  The product library has neither instantiation.
     if ((d->flags & 32) && glds && k.splits == 1 && d->workspace != nullptr &&
         (size_t)grid.x * 32 * sizeof(long long) <= (size_t)d->workspace_bytes) {  // debug: per-block phase timestamps
         k.trace = (long long*)d->workspace;
@@ -986,6 +990,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         if (ko == 5) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 5>), grid, dim3(256), 0, s, k);
         return av_launch_status("gemm_mfma<knock-out>");
     }
+#endif
 #define AV_LAUNCH2(NF_, GEGLU_)                                                                          \
     do {                                                                                                 \
         if (glds)                                                                                   \

@@ -15,7 +15,7 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU, ACT_F32OUT = 0, 1, 2, 3, 4
 
 # global knobs (tests flip them to cross-check kernel variants)
 FORCE_NAIVE = False   # route GEMM / attention through the reference-grade kernels
-ATTN_FLAGS = int(os.environ.get("ANYV2V_ATTN_FLAGS", "0"))  # bit1 (2): no short kernel; bit2 (4): v1 flash; bit3 (8): PnP launches as per-branch aliasing (no shared-softmax kernel); bit5 (32): experimental in-wave pipelined v3 kernel for plain launches
+ATTN_FLAGS = int(os.environ.get("ANYV2V_ATTN_FLAGS", "0"))  # bit1 (2): no short kernel; bit3 (8): PnP launches as per-branch aliasing (no shared-softmax kernel)
 GEMM_FLAGS = int(os.environ.get("ANYV2V_GEMM_FLAGS", "0"))  # bit2 (4): no persistent 192x320 kernel; bit3 (8): force it; bit4 (16): no split-K
 USE_GLDS = os.environ.get("ANYV2V_GLDS", "1") == "1"   # LDS-DMA (global_load_lds) staging variant of the GEMM
 

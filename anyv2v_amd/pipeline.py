@@ -370,7 +370,10 @@ class I2VGenXLPipeline:
                  decode_chunk_size: Optional[int] = 1, generator=None, latents: Optional[torch.Tensor] = None,
                  prompt_embeds=None, negative_prompt_embeds=None, output_type: Optional[str] = "pil",
                  return_dict: bool = True, cross_attention_kwargs=None, clip_skip: Optional[int] = 1,
-                 ddim_init_latents_t_idx: Optional[int] = 1, image_embeddings=None, image_latents=None):
+                 ddim_init_latents_t_idx: Optional[int] = 1, image_embeddings=None, image_latents=None,
+                 latents_trace: Optional[dict] = None):
+        """``latents_trace``: optional dict, filled with t -> latents after the step at t (drift reports; not a reference
+        argument)."""
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, image, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
@@ -401,6 +404,8 @@ class I2VGenXLPipeline:
         coef_table = self.scheduler.coefficient_table(ts, device)
         for i, t in enumerate(ts):
             eng.step(t_table[i], coef_table[i], key=("cfg",))
+            if latents_trace is not None:
+                latents_trace[t] = sample[nb - 1:nb].clone()
         return self._finish(sample[nb - 1:nb].clone(), output_type, decode_chunk_size, return_dict)
 
     # ------------------------------------------------------------------ A2: PnP edit (:892-1193)
@@ -414,7 +419,8 @@ class I2VGenXLPipeline:
                         clip_skip: Optional[int] = 1, ddim_init_latents_t_idx: Optional[int] = 1,
                         ddim_inv_latents_path: Union[str, LatentTrajectory, None] = None, ddim_inv_prompt=None,
                         ddim_inv_1st_frame=None, image_embeddings=None, image_latents=None,
-                        ddim_inv_prompt_embeds=None, ddim_inv_image_embeddings=None, ddim_inv_image_latents=None):
+                        ddim_inv_prompt_embeds=None, ddim_inv_image_embeddings=None, ddim_inv_image_latents=None,
+                        latents_trace: Optional[dict] = None):
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, image, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
@@ -483,9 +489,11 @@ class I2VGenXLPipeline:
                     eng_nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale, dup_slots=[0],
                                             shared_stem=True)
                 eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-nosrc",))
-                continue
-            sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)
-            eng.step(t_table[i], coef_table[i], key=("pnp",) + state)
+            else:
+                sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)
+                eng.step(t_table[i], coef_table[i], key=("pnp",) + state)
+            if latents_trace is not None:
+                latents_trace[t] = sample[nb - 1:nb].clone()
         return self._finish(sample[nb - 1:nb].clone(), output_type, decode_chunk_size, return_dict)
 
     def _finish(self, latents, output_type, decode_chunk_size, return_dict):

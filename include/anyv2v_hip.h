@@ -62,9 +62,8 @@ typedef struct AnyV2VGemmDesc {
     int32_t F, HW;                      /* mode 2: frames per clip, pixels per frame */
     int32_t act;
     int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging; bit2: never use the
-                            persistent 192x320 kernel; bit3: always use it when the shape allows; bit4: no split-K;
-                            debug only: bit5 = per-block phase timestamps into the workspace, bits 6-8 = K-loop
-                            knock-outs (wrong results by design) -- see tools/gemm_trace.py */
+                            persistent 192x320 kernel; bit3: always use it when the shape allows; bit4: no split-K.
+                            All other bits are ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
 } AnyV2VGemmDesc;
@@ -125,10 +124,9 @@ typedef struct AnyV2VAttnDesc {
     int32_t kv_div;
     int32_t qk_mod;
     float scale;
-    int32_t flags;      /* bit0: force the naive reference kernel; bit1: no short-sequence kernel; bit2: register-staged
-                           v1 kernel; bit3: PnP launches (batch == 3 qk_mod) as per-branch aliasing on the v2 kernel instead
-                           of the shared-softmax kernel; bit5: plain launches with Sq % 128 == 0 on the experimental
-                           in-wave pipelined v3 kernel (measured slower than v2; kept for A/B measurements) */
+    int32_t flags;      /* bit0: force the naive reference kernel; bit1: no short-sequence kernel; bit3: PnP launches
+                           (batch == 3 qk_mod) as per-branch aliasing on the plain kernel instead of the shared-softmax
+                           kernel.  All other bits are ignored. */
 } AnyV2VAttnDesc;
 
 int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);

@@ -5,6 +5,9 @@
 1. ``pnp_hooks_mini.pt``: the reference's ``i2vgen-xl/pnp_utils.py`` (imported verbatim via
    ``oracle.ref_stubs``) registered on the mini oracle UNet; v-predictions for a 3-way batch at
    timesteps that are on all / some / none of the injection schedules, plus the un-hooked output.
+   ``pnp_hooks_full_config1.pt`` (``--full``, ~1 min of CPU): the same at full width -- the 1.42 B-parameter oracle at
+   BASELINE config 1 (3 x 8 f x 256^2, weights seed 1234, inputs seed 8888 = ``tests/gpu_checks.config1_inputs``), the
+   reference's hooks registered on all 17 sites; v-predictions at t=981 (every site injecting) and t=301 (temporal only).
 2. ``inverse_scheduler.pt``: the reference's vendored ``consisti2v/ddim_inverse_scheduler.py``
    constructed with the config logged at ``i2vgen-xl/demo.ipynb:1208-1226``: alphas_cumprod table,
    timesteps for n=50/500, and inverse steps on seeded tensors.
@@ -66,6 +69,32 @@ def gen_hooks():
             print(k, tuple(v.shape), float(v.abs().max()))
 
 
+def gen_hooks_full():
+    """Full-width fixture.  Only outputs are stored (2 x 393 KB fp32): weights and inputs are
+    re-derived from their seeds by the tests."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_checks as gc
+    ref = ref_stubs.load_reference_pnp_utils()
+    cfg = UNetConfig.i2vgen_xl()
+    unet = build_oracle(cfg, random_state_dict(cfg, MINI_SEED), dtype=torch.float32)
+    inp = gc.config1_inputs(cfg, 3, 8, 32, seed=INPUT_SEED)
+    inp = {k: (v.half().float() if v.is_floating_point() else v) for k, v in inp.items()}   # the tests feed fp16-rounded inputs
+    kw = dict(fps=inp["fps"], image_latents=inp["image_latents"], image_embeddings=inp["image_embeddings"],
+              encoder_hidden_states=inp["encoder_hidden_states"])
+    out = {"weights_seed": MINI_SEED, "input_seed": INPUT_SEED, "pnp": PNP, "n_steps": N_STEPS, "shape": tuple(inp["sample"].shape)}
+    with torch.no_grad():
+        pipe = types.SimpleNamespace(unet=unet)
+        ts = torch.arange(N_STEPS).flip(0) * (1000 // N_STEPS) + 1
+        ref.register_conv_injection(pipe, ts[: int(N_STEPS * PNP["pnp_f_t"])])
+        ref.register_spatial_attention_pnp(pipe, ts[: int(N_STEPS * PNP["pnp_spatial_attn_t"])])
+        ref.register_temp_attention_pnp(pipe, ts[: int(N_STEPS * PNP["pnp_temp_attn_t"])])
+        for t in (981, 301):
+            ref.register_time(pipe, t)
+            out[f"v_hook_t{t}"] = unet(inp["sample"], t, **kw)[0].clone()
+            print(f"v_hook_t{t}", tuple(out[f"v_hook_t{t}"].shape), float(out[f"v_hook_t{t}"].abs().max()))
+    torch.save(out, os.path.join(HERE, "pnp_hooks_full_config1.pt"))
+
+
 def gen_scheduler():
     mod = ref_stubs.load_reference_inverse_scheduler()
     cfgd = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="squaredcos_cap_v2",
@@ -89,5 +118,8 @@ def gen_scheduler():
 
 if __name__ == "__main__":
     assert ref_stubs.reference_available(), "needs /root/reference"
-    gen_hooks()
-    gen_scheduler()
+    if "--full" in sys.argv:
+        gen_hooks_full()
+    else:
+        gen_hooks()
+        gen_scheduler()

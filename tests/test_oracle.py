@@ -133,3 +133,28 @@ def test_branch_independence_and_shared_softmax_identities():
     ref = torch.nn.functional.scaled_dot_product_attention(qi, ki, v)
     p = torch.softmax(q[0] @ k[0].transpose(-1, -2) / 8 ** 0.5, -1)
     torch.testing.assert_close(torch.stack([p @ v[i] for i in range(3)]), ref, rtol=1e-10, atol=1e-10)
+
+
+def test_full_width_fixture_pins_the_oracle_hooks_at_config1():
+    """``tests/golden/pnp_hooks_full_config1.pt`` was produced by the REFERENCE's ``pnp_utils.py`` on the 1.42 B-parameter
+    oracle at BASELINE config 1 (the ``cpu_baseline`` workload).  ``oracle.pnp_oracle``'s restatement of the hooks must
+    reproduce it at full width (one forward, every site injecting) -- the fixture is what the ``-m gpu`` N1 test then holds
+    the HIP path to."""
+    import gpu_checks as gc
+    gold = torch.load(os.path.join(GOLD, "pnp_hooks_full_config1.pt"))
+    assert gold["weights_seed"] == 1234 and gold["input_seed"] == 8888 and gold["pnp"] == dict(pnp_f_t=0.2, pnp_spatial_attn_t=0.5, pnp_temp_attn_t=0.8)
+    cfg = UNetConfig.i2vgen_xl()
+    unet = build_oracle(cfg, random_state_dict(cfg, gold["weights_seed"]), dtype=torch.float32)
+    inp = gc.config1_inputs(cfg, 3, 8, 32, seed=gold["input_seed"])
+    inp = {k: (v.half().float() if v.is_floating_point() else v) for k, v in inp.items()}
+    assert tuple(inp["sample"].shape) == tuple(gold["shape"])
+    ts = list(range(981, 0, -20))
+    pnp_oracle.register_conv_injection(unet, ts[:10])
+    pnp_oracle.register_spatial_attention_pnp(unet, ts[:25])
+    pnp_oracle.register_temp_attention_pnp(unet, ts[:40])
+    pnp_oracle.register_time(unet, 981)
+    with torch.no_grad():
+        v = unet(inp["sample"], 981, fps=inp["fps"], image_latents=inp["image_latents"], image_embeddings=inp["image_embeddings"],
+                 encoder_hidden_states=inp["encoder_hidden_states"])[0]
+    ref = gold["v_hook_t981"]
+    assert float((v - ref).abs().max() / ref.abs().max()) < 1e-4

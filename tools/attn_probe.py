@@ -53,9 +53,7 @@ for _ in range(40):
                   q_strides=(4096, 0, 1), kv_strides=(4096, 0, 1))
 torch.cuda.synchronize()
 del _w, _o
-for flags, name in ((0, "v2"), (32, "v3 in-wave pipeline"), (4, "v1 reg-staged")):
-    if quick and flags == 4:
-        continue
+for flags, name in ((0, "v2"),) + tuple((int(f), f"flag {f}") for f in os.environ.get("ATTN_PROBE_FLAGS", "").split(",") if f):
     ops.ATTN_FLAGS = flags
     attn_case(f"[{name}] spatial 64x64 B=3", 48, 5, 4096, 10)
     attn_case(f"[{name}] spatial 64x64 B=1", 16, 5, 4096, 10)

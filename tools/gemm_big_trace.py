@@ -8,7 +8,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from anyv2v_amd import ops  # noqa: E402
+from anyv2v_amd import _lib, ops  # noqa: E402
+
+# probe build with the trace / knock-out instantiations (make -C anyv2v_amd/csrc experiments); never the product library
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "libanyv2v_hip_experiments.so")
 
 dev = "cuda"
 lines = []
