@@ -18,6 +18,8 @@
 // conflict-free for the 32-row ds_read_b128 fragment pattern.  Keys inside a V^T row are permuted (bits 2<->3)
 // so that the 8 keys a lane needs for one MFMA K-step are one contiguous 16-byte read.
 // Next KV tile is prefetched global->registers while the current one is consumed (async-stage split, T14).
+#include <type_traits>
+
 #include "common.h"
 
 struct AttnK {
@@ -89,11 +91,28 @@ __device__ __forceinline__ h8 join8(fp16x4v_t a, fp16x4v_t b) {
 //            P = softmax(Q_src K_src^T) is identical for all three branches -- one block computes it once per KV
 //            tile and applies it to V_src, V_uncond, V_cond (1/3 of the QK^T MFMAs and 1/3 of the exp/VALU work,
 //            which is what bounds this kernel at head_dim 64).  Exact: same products, same order per branch.
-template <int STAGES, int NV>
-__global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
+//
+// SM = softmax form.
+//   SM = 0 : textbook online softmax with a deferred rescale -- per score: fma (scale, subtract max), exp2, max, add.
+//   SM = 1 : the VALU work that bounds this kernel at head_dim 64 is cut to exp2 + add per score:
+//            * Q is pre-multiplied by scale * log2(e) once per block (one fp16 rounding of Q, the same size as the
+//              rounding Q already carries from the projection GEMM), so the MFMA output is already in log2 units;
+//            * the running maximum is SUBTRACTED BY THE MFMA: the first QK^T MFMA of a tile takes a 16-register block
+//              holding -m (all registers equal: a lane owns one query column) as its C operand and writes S - m to the
+//              score registers (D != C), so there is no per-score fma;
+//            * no per-tile row maximum: softmax is shift-invariant and the maximum only guards the exponent range, so
+//              the tile is exponentiated against the OLD maximum and the row sum that is needed anyway doubles as the
+//              range check -- all P >= 0, hence a lane's partial sum <= 2^10 bounds every P of that lane.  Only when
+//              some lane of the wave exceeds it (and on tile 0, where no maximum is known yet) the wave takes the
+//              textbook path on the same score registers: true maximum, rescale O and l, re-exponentiate.
+//            Exact in the same sense as the deferred rescale (P differs by the rounding of a shifted exponent).
+// NW = waves per block (4: 128 query rows, 8: 256 query rows sharing one K / V ring -- half the LDS-DMA and ring LDS per query)
+template <int STAGES, int NV, int SM, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
     constexpr int TILE_BYTES = 8192, STAGE_BYTES = (1 + NV) * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
-    constexpr int LPT = 2 * (1 + NV);                                                      // LDS-DMA per thread per tile
-    static_assert((PRE == 2 && LPT == 4) || PRE == 1, "vmcnt immediates below");
+    constexpr int NT = 64 * NW, DI = 512 / NT;      // threads; LDS-DMA instructions per thread and 8-KiB tile matrix (512 chunks of 16 B)
+    constexpr int LPT = DI * (1 + NV);              // LDS-DMA per thread per tile
+    static_assert((PRE == 2 && (LPT == 4 || LPT == 2)) || PRE == 1, "vmcnt immediates below");
     __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
         vbase[b] = attn_row(ib / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
     }
 
-    const int q0 = qt * 128 + w * 32;
+    const int q0 = qt * (32 * NW) + w * 32;
     const bool wave_active = q0 < p.Sq;
     const int qrow = q0 + l31;
     h8 qf[4];
@@ -126,6 +145,12 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
         const half_t* qp = p.Q + (qbase + (long long)qr * p.q_seq) * p.ldq + h * 64 + 8 * hi;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h8*)(qp + 16 * ks);
+        if constexpr (SM == 1 || SM == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)((float)qf[ks][e] * p.scale_log2);
+        }
     }
 
     // DMA assignment: instruction t (0,1), chunk slot = t*256 + tid -> row = slot >> 3, physical chunk = tid & 7.
@@ -137,10 +162,10 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     const char* vptr[NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b) vptr[b] = (const char*)(p.V + vbase[b] * p.ldv + h * 64);
-    unsigned koff[2], voff_g[2];
+    unsigned koff[DI], voff_g[DI];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int row = drow + 32 * t;
+    for (int t = 0; t < DI; ++t) {
+        const int row = drow + (NT / 8) * t;
         koff[t] = (unsigned)(((long long)row * p.kv_seq * p.ldk + ((dpc ^ ((row >> 1) & 7)) << 3)) * 2);
         voff_g[t] = (unsigned)(((long long)row * p.kv_seq * p.ldv + ((dpc ^ av_vswz(row)) << 3)) * 2);
     }
@@ -151,21 +176,21 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
         char* st = smem + stage * STAGE_BYTES;
         if (issue_key0 + 64 <= p.Sk) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                glds16_attn((const half_t*)(kptr + koff[t]), st + (t * 256 + w_s * 64) * 16);
+            for (int t = 0; t < DI; ++t) {
+                glds16_attn((const half_t*)(kptr + koff[t]), st + (t * NT + w_s * 64) * 16);
 #pragma unroll
                 for (int b = 0; b < NV; ++b)
-                    glds16_attn((const half_t*)(vptr[b] + voff_g[t]), st + (1 + b) * TILE_BYTES + (t * 256 + w_s * 64) * 16);
+                    glds16_attn((const half_t*)(vptr[b] + voff_g[t]), st + (1 + b) * TILE_BYTES + (t * NT + w_s * 64) * 16);
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const bool ok = issue_key0 + drow + 32 * t < p.Sk;  // only the last tile can be ragged
-                glds16_attn(ok ? (const half_t*)(kptr + koff[t]) : zeros, st + (t * 256 + w_s * 64) * 16);
+            for (int t = 0; t < DI; ++t) {
+                const bool ok = issue_key0 + drow + (NT / 8) * t < p.Sk;  // only the last tile can be ragged
+                glds16_attn(ok ? (const half_t*)(kptr + koff[t]) : zeros, st + (t * NT + w_s * 64) * 16);
 #pragma unroll
                 for (int b = 0; b < NV; ++b)
                     glds16_attn(ok ? (const half_t*)(vptr[b] + voff_g[t]) : zeros,
-                                st + (1 + b) * TILE_BYTES + (t * 256 + w_s * 64) * 16);
+                                st + (1 + b) * TILE_BYTES + (t * NT + w_s * 64) * 16);
             }
         }
         kptr += kstep;
@@ -179,8 +204,11 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     for (int b = 0; b < NV; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[b][0][r] = oacc[b][1][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = SM >= 1 ? 0.f : -1e30f, l_run = 0.f;
     const float c = p.scale_log2;
+    f16v negm;  // SM == 1: -m_run in every register, the C operand of each tile's first QK^T MFMA
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
     // V^T fragment addressing (ds_read_b64_tr_b16): lane i16 of a 16-lane group supplies &V[kb + (i16>>2)][dcol + 4(i16&3)]
     const int i16 = lane & 15;
@@ -198,28 +226,54 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     int stage = 0;
     for (int j = 0; j < ntiles; ++j) {
         const int ahead = ntiles - 1 - j;  // tiles issued after tile j that may still be in flight (<= PRE - 1)
-        if (PRE >= 2 && ahead >= 1)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // PRE == 2 implies LPT == 4 (NV == 1)
+        if (PRE >= 2 && ahead >= 1 && LPT == 4)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // PRE == 2: one tile (LPT instructions) may stay in flight
+        else if (PRE >= 2 && ahead >= 1)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (j + PRE < ntiles) issue((stage + PRE) % STAGES);
-        if (wave_active) {
+        if constexpr (SM >= 2) {
+          constexpr bool PRESCALED = SM == 2;  // SM == 3: unscaled Q, P = exp2(fma(s, c, -m c)) in fp32 (one more VALU per score)
+          if (wave_active) {
+            // ---- chunked form: the tile is processed as four 16-key online-softmax steps, so that the P V MFMAs of step t run in
+            // the matrix pipe while the exp2 / add / convert VALU work of step t + 1 issues (a wave issues in order, but an MFMA
+            // only occupies the pipe), and the V^T fragments are fetched 16 keys at a time (8 registers per branch instead of 32)
             const char* Ks = smem + stage * STAGE_BYTES;
-            f16v sacc[2];
+            const unsigned ks_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ks;
+            h8 kf[2][4];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
                 const int key = 32 * kb + l31;
                 const char* krow = Ks + key * 128;
                 const int fk = (key >> 1) & 7;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const h8 kf = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
-                }
+                for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
             }
+            f16v sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f16v cinit = negm;
+                if constexpr (!PRESCALED) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+                }
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][0], qf[0], cinit, 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < 4; ++ks)
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
+            }
+            // issue order: the first block's four K fragments, then its MFMAs with the second block's reads slotted in, then the
+            // rest (left alone, hipcc sinks every read next to its MFMA behind a full lgkmcnt(0): eight exposed LDS round trips)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (j == ntiles - 1 && (p.Sk & 63) != 0) {  // key tail: only the last tile can hold masked keys
                 const int key_base = j * 64 + 4 * hi;
 #pragma unroll
@@ -228,6 +282,115 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                     for (int r = 0; r < 16; ++r)
                         if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) sacc[kb][r] = -1e30f;
             }
+            auto chunk = [&](auto tc) {
+                constexpr int t = decltype(tc)::value, kb = t >> 1, r0 = 8 * (t & 1);
+                fp16x4v_t vt[NV][2][2];
+#pragma unroll
+                for (int b = 0; b < NV; ++b) {
+                    const unsigned vb_lds = ks_lds + (1 + b) * TILE_BYTES;
+                    vt[b][0][0] = lds_tr16<2 * t * 1024>(vb_lds + voff[0]);
+                    vt[b][0][1] = lds_tr16<(2 * t + 1) * 1024>(vb_lds + voff[0]);
+                    vt[b][1][0] = lds_tr16<2 * t * 1024>(vb_lds + voff[1]);
+                    vt[b][1][1] = lds_tr16<(2 * t + 1) * 1024>(vb_lds + voff[1]);
+                }
+                float e[8];
+                float nmc = -m_run * c;  // (!PRESCALED)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    e[i] = __builtin_amdgcn_exp2f(PRESCALED ? sacc[kb][r0 + i] : fmaf(sacc[kb][r0 + i], c, nmc));
+                float ps = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+                const bool first = j == 0 && t == 0;  // no maximum known yet
+                // range check by the partial row sum (all P >= 0); !(x <= T) also catches inf / nan
+                if (first || __any(!(ps <= 1024.0f))) {
+                    float mx = sacc[kb][r0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, sacc[kb][r0 + i]);
+                    {
+                        const unsigned mu = __float_as_uint(mx);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                    }
+                    // PRESCALED: mx is relative to the old maximum (the registers hold S - m_old), else a raw score.  Very first step:
+                    // taken as is (O = l = 0, nothing to rescale); afterwards the maximum never moves down (alpha <= 1).
+                    if constexpr (!PRESCALED) mx = first ? mx : (fmaxf(mx, m_run) - m_run);  // -> relative, >= 0
+                    if (!first) {
+                        mx = fmaxf(mx, 0.f);
+                        const float alpha = __builtin_amdgcn_exp2f(PRESCALED ? -mx : -mx * c);
+                        l_run *= alpha;
+#pragma unroll
+                        for (int b = 0; b < NV; ++b)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                oacc[b][0][r] *= alpha;
+                                oacc[b][1][r] *= alpha;
+                            }
+                    }
+                    m_run += mx;
+                    if constexpr (PRESCALED) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+                        // this step's and the tile's remaining scores were taken against the old maximum
+#pragma unroll
+                        for (int kb2 = kb; kb2 < 2; ++kb2)
+#pragma unroll
+                            for (int r = (kb2 == kb ? r0 : 0); r < 16; ++r) sacc[kb2][r] -= mx;
+                    }
+                    nmc = -m_run * c;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        e[i] = __builtin_amdgcn_exp2f(PRESCALED ? sacc[kb][r0 + i] : fmaf(sacc[kb][r0 + i], c, nmc));
+                    ps = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+                }
+                l_run += ps;
+                h8 pfc;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pfc[i] = (half_t)e[i];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < NV; ++b) {
+                    oacc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vt[b][0][0], vt[b][0][1]), pfc, oacc[b][0], 0, 0, 0);
+                    oacc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vt[b][1][0], vt[b][1][1]), pfc, oacc[b][1], 0, 0, 0);
+                }
+            };
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{});
+            if constexpr (PRESCALED) asm volatile("" : "+v"(negm));  // keep the block in registers (no re-materialisation by 16 v_mov)
+          }
+        } else
+        if (wave_active) {
+            const char* Ks = smem + stage * STAGE_BYTES;
+            f16v sacc[2];
+            auto qk_scores = [&]() {  // S^T (SM == 1: minus the running maximum, in log2 units) for this wave's 32 queries x 64 keys
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if constexpr (SM == 1) {
+                        sacc[kb] = negm;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                    }
+                    const int key = 32 * kb + l31;
+                    const char* krow = Ks + key * 128;
+                    const int fk = (key >> 1) & 7;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const h8 kf = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                    }
+                }
+                if (j == ntiles - 1 && (p.Sk & 63) != 0) {  // key tail: only the last tile can hold masked keys
+                    const int key_base = j * 64 + 4 * hi;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) sacc[kb][r] = -1e30f;
+                }
+            };
+            qk_scores();
             // V^T fragments of the first (branch, d-half) unit: issued now, they land while the softmax runs on the VALU
             const unsigned ks_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ks;
             fp16x4v_t va[8], vb[8];
@@ -239,6 +402,67 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
     _Pragma("unroll") for (int t = 0; t < 4; ++t) acc =                                                \
         __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(src[2 * t], src[2 * t + 1]), pf[t], acc, 0, 0, 0)
             AV_TR8(va, ks_lds + TILE_BYTES + voff[0]);
+            float psum = 0.f;
+            h8 pf[4];
+            if constexpr (SM == 1) {
+                bool slow = j == 0;  // tile 0 has no maximum yet
+                if (!slow) {
+                    // fast path: P = exp2(S - m_old) straight from the MFMA output (each score register dies at its exp2); four
+                    // partial sums keep the adds off one dependency chain
+                    float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(sacc[kb][r]);
+                            ps4[r & 3] += pv;
+                            pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
+                        }
+                    psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+                    // range check by the row sum (all P >= 0); !(x <= T) also catches inf / nan
+                    slow = __any(!(psum <= 1024.0f));
+                    if (slow) qk_scores();  // rare: recompute the scores instead of keeping 32 registers alive for this branch
+                }
+                if (slow) {
+                    float mx = -1e30f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+                    {
+                        const unsigned mu = __float_as_uint(mx);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                    }
+                    // mx is relative to the old maximum (the registers hold S - m_old).  Tile 0: take it as is (O = l = 0, nothing
+                    // to rescale); later tiles: the maximum never moves down (alpha <= 1).
+                    if (j > 0) {
+                        mx = fmaxf(mx, 0.f);
+                        const float alpha = __builtin_amdgcn_exp2f(-mx);
+                        l_run *= alpha;
+#pragma unroll
+                        for (int b = 0; b < NV; ++b)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                oacc[b][0][r] *= alpha;
+                                oacc[b][1][r] *= alpha;
+                            }
+                    }
+                    m_run += mx;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+                    psum = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - mx);
+                            psum += pv;
+                            pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
+                        }
+                }
+                asm volatile("" : "+v"(negm));  // keep the block in registers (no per-tile re-materialisation by 16 v_mov)
+            } else {
             float mx = -1e30f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -252,9 +476,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
             const float m_new = fmaxf(m_run, mx);
             // Deferred rescale: the running maximum is only advanced (and O, l rescaled) when some row of the wave
             // would otherwise see a probability above 2^8; until then P = exp2((s - m_run) c) is taken against the
-            // OLD maximum.  Softmax is shift-invariant, fp16 / fp32 are floating point, so the result only differs in
-            // the last bit of P's rounding -- but on random data the maximum moves in ~85 % of the 64 tiles and after
-            // the first tile almost never by 2^8, so 16 v_pk_mul + 1 v_exp per tile and wave disappear.
+            // OLD maximum.
             if (__any((m_new - m_run) * c > 8.0f)) {
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
                 l_run *= alpha;
@@ -268,8 +490,6 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                 m_run = m_new;
             }
             const float mc = m_run * c;
-            float psum = 0.f;
-            h8 pf[4];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -278,6 +498,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_v2_kernel(const AttnK p, c
                     psum += pv;
                     pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
                 }
+            }
             l_run += psum;
             // O^T += V^T P^T, one (branch, d-half) unit at a time; the next unit's transpose reads are in flight
             // while the current unit's 4 MFMAs run (two register sets, counted lgkmcnt)
@@ -518,10 +739,32 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     if (k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8)) {
         // PnP injection step: one softmax per source element, three V / O streams (flag bit3 forces the aliasing form)
         const long long nwg3 = (long long)k.qk_mod * k.heads * k.q_tiles;
-        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
+        if (d->flags & 16)
+            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 0>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
+        else if (d->flags & 32)
+            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 1>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
+        else if (d->flags & 64)
+            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 3>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
+        else
+            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 2>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<pnp3>");
     }
-    hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    if (d->flags & 16)
+        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 0>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    else if (d->flags & 32)
+        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 1>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    else if (d->flags & 64)
+        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 3>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    else if (d->flags & 128) {  // 8 waves per block
+        k.q_tiles = (d->Sq + 255) / 256;
+        const long long nwg8 = (long long)k.batch * k.heads * k.q_tiles;
+        if (d->flags & 256)
+            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 2, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
+        else
+            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 3, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
+    }
+    else
+        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 2>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
     return av_launch_status("flash_attn_d64_v2");
 }
 

@@ -403,6 +403,64 @@ def _sdpa(q, k, v):  # [b, h, s, d] fp32
     return F.scaled_dot_product_attention(q.float(), k.float(), v.float())
 
 
+def check_attention_forced_rescale():
+    """The flash kernel exponentiates every 16-key step against the OLD running maximum and uses the partial row sum as the
+    range check; the textbook path (true maximum, rescale of O and l, re-exponentiation) only runs when that check trips and
+    on the very first step.  Bounded random data never takes the branch after the first step, so it is forced here (MI355X
+    guide rule 26): spiked keys at chosen positions (start / middle of a tile, last key, ragged tail), a first step whose
+    scores sit far BELOW the rest (maximum has to climb), far ABOVE the rest (everything after underflows), and scores that
+    overflow fp32 exp2 against the old maximum (inf in the check).  Reference: fp32 SDPA on the same fp16 inputs."""
+    out = []
+    for name, S, Sk, build in (
+        ("spike at key 70 (2nd tile, 1st step)", 256, 256, lambda q, k: _spike(q, k, [70], 6.0)),
+        ("spikes at keys 5, 200, 255 (every path of a tile)", 256, 256, lambda q, k: _spike(q, k, [5, 200, 255], 5.0)),
+        ("spike in the ragged tail (key 144 of 145)", 128, 145, lambda q, k: _spike(q, k, [144], 6.0)),
+        ("first 16 keys far below the rest", 128, 512, lambda q, k: _shift_first(q, k, -4.0)),
+        ("first 16 keys far above the rest", 128, 512, lambda q, k: _shift_first(q, k, 4.0)),
+        ("exp2 overflow against the old maximum (|s c| ~ 400)", 128, 320, lambda q, k: _spike(q, k, [100, 300], 40.0)),
+    ):
+        b, h = 2, 2
+        C = 64 * h
+        q2 = rnd(b * S, C, scale=1.0, seed=1234)
+        kv = rnd(b * Sk, 2 * C, scale=1.0, seed=4321)
+        build(q2.view(b, S, h, 64), kv[:, :C].view(b, Sk, h, 64))
+        q = q2.view(b, S, h, 64).transpose(1, 2)
+        k = kv[:, :C].reshape(b, Sk, h, 64).transpose(1, 2)
+        v = kv[:, C:].reshape(b, Sk, h, 64).transpose(1, 2)
+        ref = _sdpa(q, k, v).transpose(1, 2).reshape(b * S, C)
+        o = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
+        ops.attention(q2, kv[:, :C], kv[:, C:], o, batch=b, heads=h, Sq=S, Sk=Sk, inner=1, q_strides=(S, 0, 1),
+                      kv_strides=(Sk, 0, 1))
+        out.append(_res(f"attn[flash] forced rescale: {name}", o, ref, 6e-3))
+        if S == Sk:  # the shared-softmax kernel on the same Q / K (three V streams)
+            b3 = 3
+            qkv3 = rnd(b3 * S, 3 * C, scale=1.0, seed=99)
+            qkv3[:S, :C] = q2[:S]
+            qkv3[:S, C:2 * C] = kv[:S, :C]
+            o3 = torch.zeros(b3 * S, C, dtype=torch.float16, device=DEV)
+            ops.attention(qkv3[:, :C], qkv3[:, C:2 * C], qkv3[:, 2 * C:], o3, batch=b3, heads=h, Sq=S, Sk=S, inner=1,
+                          q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=1)
+            q3, k3, v3 = (qkv3[:, i * C:(i + 1) * C].view(b3, S, h, 64).transpose(1, 2).clone() for i in range(3))
+            q3[1], k3[1], q3[2], k3[2] = q3[0], k3[0], q3[0], k3[0]
+            out.append(_res(f"attn[shared softmax] forced rescale: {name}", o3,
+                            _sdpa(q3, k3, v3).transpose(1, 2).reshape(b3 * S, C), 6e-3))
+    return out
+
+
+def _spike(q, k, keys, gain):
+    """k[:, key] := gain * (a query row's direction): that row's score at `key` dwarfs the others (in place, views of fp16)."""
+    for n, key in enumerate(keys):
+        rows = q[:, (7 + 13 * n) % q.shape[1]]            # [b, h, 64]: a different query row per spike
+        k[:, key] = (gain * rows.float()).half()
+
+
+def _shift_first(q, k, gain):
+    """The first 16 keys get scores far below (gain < 0) / above (gain > 0) all later ones for EVERY query: both q and the
+    first keys receive a large common component."""
+    q[..., 0] = 6.0
+    k[:, :16, :, 0] = gain * 6.0
+
+
 def check_attention(naive_too=True):
     out = []
     for naive in ((False, True) if naive_too else (False,)):
@@ -506,6 +564,7 @@ def check_attention(naive_too=True):
         q, k, v = (qkv3[:, i * C:(i + 1) * C].view(b3, S, h, 64).transpose(1, 2).clone() for i in range(3))
         q[1], k[1], q[2], k[2] = q[0], k[0], q[0], k[0]
         out.append(_res(f"attn[shared softmax] {name}", o3, _sdpa(q, k, v).transpose(1, 2).reshape(b3 * S, C), 6e-3))
+    out += check_attention_forced_rescale()
     B_, HW, h, Fr = 2, 12, 2, 128  # temporal sequences of 128 frames (BASELINE config 5): frame stride HW
     C = 64 * h
     qkv = rnd(B_ * Fr * HW, 3 * C)
