@@ -91,27 +91,28 @@ __device__ __forceinline__ h8 join8(fp16x4v_t a, fp16x4v_t b) {
 //            P = softmax(Q_src K_src^T) is identical for all three branches -- one block computes it once per KV
 //            tile and applies it to V_src, V_uncond, V_cond (1/3 of the QK^T MFMAs and 1/3 of the exp/VALU work,
 //            which is what bounds this kernel at head_dim 64).  Exact: same products, same order per branch.
+// NW = waves per block (4: 128 query rows; 8: 256 query rows sharing one K / V ring -- half the LDS-DMA and ring LDS per
+//      query, 4 waves per SIMD at <= 128 VGPRs).
 //
-// SM = softmax form.
-//   SM = 0 : textbook online softmax with a deferred rescale -- per score: fma (scale, subtract max), exp2, max, add.
-//   SM = 1 : the VALU work that bounds this kernel at head_dim 64 is cut to exp2 + add per score:
-//            * Q is pre-multiplied by scale * log2(e) once per block (one fp16 rounding of Q, the same size as the
-//              rounding Q already carries from the projection GEMM), so the MFMA output is already in log2 units;
-//            * the running maximum is SUBTRACTED BY THE MFMA: the first QK^T MFMA of a tile takes a 16-register block
-//              holding -m (all registers equal: a lane owns one query column) as its C operand and writes S - m to the
-//              score registers (D != C), so there is no per-score fma;
-//            * no per-tile row maximum: softmax is shift-invariant and the maximum only guards the exponent range, so
-//              the tile is exponentiated against the OLD maximum and the row sum that is needed anyway doubles as the
-//              range check -- all P >= 0, hence a lane's partial sum <= 2^10 bounds every P of that lane.  Only when
-//              some lane of the wave exceeds it (and on tile 0, where no maximum is known yet) the wave takes the
-//              textbook path on the same score registers: true maximum, rescale O and l, re-exponentiate.
-//            Exact in the same sense as the deferred rescale (P differs by the rounding of a shifted exponent).
-// NW = waves per block (4: 128 query rows, 8: 256 query rows sharing one K / V ring -- half the LDS-DMA and ring LDS per query)
-template <int STAGES, int NV, int SM, int NW = 4>
+// Softmax form.  A KV tile is processed as FOUR 16-key online-softmax steps: the P V MFMAs of step t execute in the matrix
+// pipe while the exp2 / add / convert VALU work of step t + 1 issues, and the V^T fragments are fetched 16 keys at a time.
+// There is no per-step row maximum: softmax is shift-invariant and the maximum only guards the exponent range, so each step
+// is exponentiated against the OLD running maximum, P = exp2(fma(s, c, -m c)), and the partial row sum that is needed anyway
+// doubles as the range check -- all P >= 0, hence "sum <= 2^10" bounds every P of the lane (fp16 holds 2^16).  Only when some
+// lane of the wave trips the check (and on the very first step, where no maximum is known) the wave takes the textbook path on
+// the same score registers: true maximum, rescale of O and l, re-exponentiation.  Exact in the sense that P only differs by the
+// rounding of a shifted exponent; on the UNet's data the branch is taken on the first step of a row and practically never again
+// (tests/gpu_checks.py::check_attention_forced_rescale forces it).  Per score this leaves fma + exp2 + add + 1/2 cvt_pk
+// (the textbook form had a max on top and a deferred-rescale test per tile): 154 -> ~120 VALU per wave and KV tile.
+// Measured forms that were dropped (profiles/r02_attn_softmax_forms_ab*.txt): Q pre-multiplied by scale * log2(e) with the
+// running maximum subtracted by the MFMA (C operand = a 16-register block of -m, D != C) removes the fma as well and is as fast
+// as this form, but costs a second fp16 rounding of Q (error 3e-4 -> 7e-4, growing with |s c|); one whole-tile softmax without
+// the 16-key steps needs 185 VGPRs (2 waves per SIMD) or spills.
+template <int STAGES, int NV, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
     constexpr int TILE_BYTES = 8192, STAGE_BYTES = (1 + NV) * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
-    constexpr int NT = 64 * NW, DI = 512 / NT;      // threads; LDS-DMA instructions per thread and 8-KiB tile matrix (512 chunks of 16 B)
-    constexpr int LPT = DI * (1 + NV);              // LDS-DMA per thread per tile
+    constexpr int NT = 64 * NW, DI = 512 / NT;  // threads; LDS-DMA instructions per thread and 8-KiB tile matrix (512 chunks of 16 B)
+    constexpr int LPT = DI * (1 + NV);          // LDS-DMA per thread per tile
     static_assert((PRE == 2 && (LPT == 4 || LPT == 2)) || PRE == 1, "vmcnt immediates below");
     __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
 
@@ -145,15 +146,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
         const half_t* qp = p.Q + (qbase + (long long)qr * p.q_seq) * p.ldq + h * 64 + 8 * hi;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h8*)(qp + 16 * ks);
-        if constexpr (SM == 1 || SM == 2) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)((float)qf[ks][e] * p.scale_log2);
-        }
     }
 
-    // DMA assignment: instruction t (0,1), chunk slot = t*256 + tid -> row = slot >> 3, physical chunk = tid & 7.
+    // DMA assignment: instruction t, chunk slot = t * NT + tid -> row = slot >> 3, physical chunk = tid & 7.
     // Wave-uniform tile pointers (SGPRs, advanced by scalar adds) + constant 32-bit per-lane byte offsets; only the
     // ragged last tile needs the per-row test (wave-uniform branch), every other issue is bare DMA instructions.
     const int drow = tid >> 3, dpc = tid & 7;
@@ -204,15 +199,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
     for (int b = 0; b < NV; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[b][0][r] = oacc[b][1][r] = 0.f;
-    float m_run = SM >= 1 ? 0.f : -1e30f, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;  // m_run is set by the very first step
     const float c = p.scale_log2;
-    f16v negm;  // SM == 1: -m_run in every register, the C operand of each tile's first QK^T MFMA
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
     // V^T fragment addressing (ds_read_b64_tr_b16): lane i16 of a 16-lane group supplies &V[kb + (i16>>2)][dcol + 4(i16&3)]
     const int i16 = lane & 15;
-    const int vrow = 4 * hi + (i16 >> 2);                          // + 16 t (+8 for the second read)
+    const int vrow = 4 * hi + (i16 >> 2);                          // + 8 (second read) + 16 t
     const int vfl = av_vswz(vrow);                                 // row swizzle, constant per lane
     const int vc0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);      // 16-byte chunk within the 32-d half
     int voff[2];
@@ -234,14 +226,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (j + PRE < ntiles) issue((stage + PRE) % STAGES);
-        if constexpr (SM >= 2) {
-          constexpr bool PRESCALED = SM == 2;  // SM == 3: unscaled Q, P = exp2(fma(s, c, -m c)) in fp32 (one more VALU per score)
-          if (wave_active) {
-            // ---- chunked form: the tile is processed as four 16-key online-softmax steps, so that the P V MFMAs of step t run in
-            // the matrix pipe while the exp2 / add / convert VALU work of step t + 1 issues (a wave issues in order, but an MFMA
-            // only occupies the pipe), and the V^T fragments are fetched 16 keys at a time (8 registers per branch instead of 32)
+        if (wave_active) {
             const char* Ks = smem + stage * STAGE_BYTES;
             const unsigned ks_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ks;
+            // ---- S^T = K Q^T for this wave's 32 queries x 64 keys
             h8 kf[2][4];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -254,21 +242,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
             f16v sacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                f16v cinit = negm;
-                if constexpr (!PRESCALED) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
-                }
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][0], qf[0], cinit, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-                for (int ks = 1; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
             }
             // issue order: the first block's four K fragments, then its MFMAs with the second block's reads slotted in, then the
             // rest (left alone, hipcc sinks every read next to its MFMA behind a full lgkmcnt(0): eight exposed LDS round trips)
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i4 = 0; i4 < 4; ++i4) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
@@ -282,8 +266,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
                     for (int r = 0; r < 16; ++r)
                         if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) sacc[kb][r] = -1e30f;
             }
-            auto chunk = [&](auto tc) {
+            // ---- four 16-key steps: score registers r0 .. r0 + 7 of block kb are keys 16 t + {0..3, 8..11} + 4 hi
+            auto step = [&](auto tc) {
                 constexpr int t = decltype(tc)::value, kb = t >> 1, r0 = 8 * (t & 1);
+                // V^T fragments of this k-step for every branch and both d-halves (asm reads: invisible to hipcc's waitcnt
+                // bookkeeping, consumed behind the explicit lgkmcnt(0) + sched_barrier below)
                 fp16x4v_t vt[NV][2][2];
 #pragma unroll
                 for (int b = 0; b < NV; ++b) {
@@ -294,28 +281,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
                     vt[b][1][1] = lds_tr16<(2 * t + 1) * 1024>(vb_lds + voff[1]);
                 }
                 float e[8];
-                float nmc = -m_run * c;  // (!PRESCALED)
+                float nmc = -m_run * c;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    e[i] = __builtin_amdgcn_exp2f(PRESCALED ? sacc[kb][r0 + i] : fmaf(sacc[kb][r0 + i], c, nmc));
+                for (int i8 = 0; i8 < 8; ++i8) e[i8] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 + i8], c, nmc));  // raw v_exp_f32
                 float ps = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
                 const bool first = j == 0 && t == 0;  // no maximum known yet
                 // range check by the partial row sum (all P >= 0); !(x <= T) also catches inf / nan
                 if (first || __any(!(ps <= 1024.0f))) {
                     float mx = sacc[kb][r0];
 #pragma unroll
-                    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, sacc[kb][r0 + i]);
-                    {
+                    for (int i8 = 1; i8 < 8; ++i8) mx = fmaxf(mx, sacc[kb][r0 + i8]);
+                    {  // the other 8 keys of the step sit in the partner half-wave: v_permlane32_swap (VALU, no LDS round trip)
                         const unsigned mu = __float_as_uint(mx);
                         const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
                         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                     }
-                    // PRESCALED: mx is relative to the old maximum (the registers hold S - m_old), else a raw score.  Very first step:
-                    // taken as is (O = l = 0, nothing to rescale); afterwards the maximum never moves down (alpha <= 1).
-                    if constexpr (!PRESCALED) mx = first ? mx : (fmaxf(mx, m_run) - m_run);  // -> relative, >= 0
-                    if (!first) {
-                        mx = fmaxf(mx, 0.f);
-                        const float alpha = __builtin_amdgcn_exp2f(PRESCALED ? -mx : -mx * c);
+                    if (first) {
+                        m_run = mx;  // O = l = 0: nothing to rescale
+                    } else {
+                        const float m_new = fmaxf(m_run, mx);  // the maximum never moves down (alpha <= 1)
+                        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
                         l_run *= alpha;
 #pragma unroll
                         for (int b = 0; b < NV; ++b)
@@ -324,203 +309,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
                                 oacc[b][0][r] *= alpha;
                                 oacc[b][1][r] *= alpha;
                             }
-                    }
-                    m_run += mx;
-                    if constexpr (PRESCALED) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-                        // this step's and the tile's remaining scores were taken against the old maximum
-#pragma unroll
-                        for (int kb2 = kb; kb2 < 2; ++kb2)
-#pragma unroll
-                            for (int r = (kb2 == kb ? r0 : 0); r < 16; ++r) sacc[kb2][r] -= mx;
+                        m_run = m_new;
                     }
                     nmc = -m_run * c;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        e[i] = __builtin_amdgcn_exp2f(PRESCALED ? sacc[kb][r0 + i] : fmaf(sacc[kb][r0 + i], c, nmc));
+                    for (int i8 = 0; i8 < 8; ++i8) e[i8] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 + i8], c, nmc));
                     ps = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
                 }
                 l_run += ps;
-                h8 pfc;
+                h8 pf;  // already the B operand of O^T += V^T P^T
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pfc[i] = (half_t)e[i];
+                for (int i8 = 0; i8 < 8; ++i8) pf[i8] = (half_t)e[i8];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int b = 0; b < NV; ++b) {
-                    oacc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vt[b][0][0], vt[b][0][1]), pfc, oacc[b][0], 0, 0, 0);
-                    oacc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vt[b][1][0], vt[b][1][1]), pfc, oacc[b][1], 0, 0, 0);
+                    oacc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vt[b][0][0], vt[b][0][1]), pf, oacc[b][0], 0, 0, 0);
+                    oacc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(vt[b][1][0], vt[b][1][1]), pf, oacc[b][1], 0, 0, 0);
                 }
             };
-            chunk(std::integral_constant<int, 0>{});
-            chunk(std::integral_constant<int, 1>{});
-            chunk(std::integral_constant<int, 2>{});
-            chunk(std::integral_constant<int, 3>{});
-            if constexpr (PRESCALED) asm volatile("" : "+v"(negm));  // keep the block in registers (no re-materialisation by 16 v_mov)
-          }
-        } else
-        if (wave_active) {
-            const char* Ks = smem + stage * STAGE_BYTES;
-            f16v sacc[2];
-            auto qk_scores = [&]() {  // S^T (SM == 1: minus the running maximum, in log2 units) for this wave's 32 queries x 64 keys
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    if constexpr (SM == 1) {
-                        sacc[kb] = negm;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-                    }
-                    const int key = 32 * kb + l31;
-                    const char* krow = Ks + key * 128;
-                    const int fk = (key >> 1) & 7;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const h8 kf = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
-                    }
-                }
-                if (j == ntiles - 1 && (p.Sk & 63) != 0) {  // key tail: only the last tile can hold masked keys
-                    const int key_base = j * 64 + 4 * hi;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (key_base + 32 * kb + (r & 3) + 8 * (r >> 2) >= p.Sk) sacc[kb][r] = -1e30f;
-                }
-            };
-            qk_scores();
-            // V^T fragments of the first (branch, d-half) unit: issued now, they land while the softmax runs on the VALU
-            const unsigned ks_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ks;
-            fp16x4v_t va[8], vb[8];
-#define AV_TR8(dst, base)                                                                              \
-    dst[0] = lds_tr16<0>(base);    dst[1] = lds_tr16<1024>(base); dst[2] = lds_tr16<2048>(base);        \
-    dst[3] = lds_tr16<3072>(base); dst[4] = lds_tr16<4096>(base); dst[5] = lds_tr16<5120>(base);        \
-    dst[6] = lds_tr16<6144>(base); dst[7] = lds_tr16<7168>(base)
-#define AV_PV4(acc, src)                                                                               \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) acc =                                                \
-        __builtin_amdgcn_mfma_f32_32x32x16_f16(join8(src[2 * t], src[2 * t + 1]), pf[t], acc, 0, 0, 0)
-            AV_TR8(va, ks_lds + TILE_BYTES + voff[0]);
-            float psum = 0.f;
-            h8 pf[4];
-            if constexpr (SM == 1) {
-                bool slow = j == 0;  // tile 0 has no maximum yet
-                if (!slow) {
-                    // fast path: P = exp2(S - m_old) straight from the MFMA output (each score register dies at its exp2); four
-                    // partial sums keep the adds off one dependency chain
-                    float ps4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float pv = __builtin_amdgcn_exp2f(sacc[kb][r]);
-                            ps4[r & 3] += pv;
-                            pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
-                        }
-                    psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-                    // range check by the row sum (all P >= 0); !(x <= T) also catches inf / nan
-                    slow = __any(!(psum <= 1024.0f));
-                    if (slow) qk_scores();  // rare: recompute the scores instead of keeping 32 registers alive for this branch
-                }
-                if (slow) {
-                    float mx = -1e30f;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-                    {
-                        const unsigned mu = __float_as_uint(mx);
-                        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-                        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-                    }
-                    // mx is relative to the old maximum (the registers hold S - m_old).  Tile 0: take it as is (O = l = 0, nothing
-                    // to rescale); later tiles: the maximum never moves down (alpha <= 1).
-                    if (j > 0) {
-                        mx = fmaxf(mx, 0.f);
-                        const float alpha = __builtin_amdgcn_exp2f(-mx);
-                        l_run *= alpha;
-#pragma unroll
-                        for (int b = 0; b < NV; ++b)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                oacc[b][0][r] *= alpha;
-                                oacc[b][1][r] *= alpha;
-                            }
-                    }
-                    m_run += mx;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-                    psum = 0.f;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - mx);
-                            psum += pv;
-                            pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
-                        }
-                }
-                asm volatile("" : "+v"(negm));  // keep the block in registers (no per-tile re-materialisation by 16 v_mov)
-            } else {
-            float mx = -1e30f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            {  // cross-half maximum by v_permlane32_swap: VALU, no LDS-queue round trip (ds_bpermute) in the softmax
-                const unsigned mu = __float_as_uint(mx);
-                const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            const float m_new = fmaxf(m_run, mx);
-            // Deferred rescale: the running maximum is only advanced (and O, l rescaled) when some row of the wave
-            // would otherwise see a probability above 2^8; until then P = exp2((s - m_run) c) is taken against the
-            // OLD maximum.
-            if (__any((m_new - m_run) * c > 8.0f)) {
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-                l_run *= alpha;
-#pragma unroll
-                for (int b = 0; b < NV; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        oacc[b][0][r] *= alpha;
-                        oacc[b][1][r] *= alpha;
-                    }
-                m_run = m_new;
-            }
-            const float mc = m_run * c;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mc));  // raw v_exp_f32 (args <= 8)
-                    psum += pv;
-                    pf[2 * kb + (r >> 3)][r & 7] = (half_t)pv;
-                }
-            }
-            l_run += psum;
-            // O^T += V^T P^T, one (branch, d-half) unit at a time; the next unit's transpose reads are in flight
-            // while the current unit's 4 MFMAs run (two register sets, counted lgkmcnt)
-#pragma unroll
-            for (int b = 0; b < NV; ++b) {
-                const unsigned vbase_lds = ks_lds + (1 + b) * TILE_BYTES;
-                AV_TR8(vb, vbase_lds + voff[1]);
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                AV_PV4(oacc[b][0], va);
-                if (b + 1 < NV) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    AV_TR8(va, vbase_lds + TILE_BYTES + voff[0]);
-                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                AV_PV4(oacc[b][1], vb);
-            }
-#undef AV_TR8
-#undef AV_PV4
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
         }
         if (++stage == STAGES) stage = 0;
     }
@@ -739,32 +550,18 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     if (k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8)) {
         // PnP injection step: one softmax per source element, three V / O streams (flag bit3 forces the aliasing form)
         const long long nwg3 = (long long)k.qk_mod * k.heads * k.q_tiles;
-        if (d->flags & 16)
-            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 0>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
-        else if (d->flags & 32)
-            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 1>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
-        else if (d->flags & 64)
-            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 3>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
-        else
-            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 2>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
+        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 4>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<pnp3>");
     }
-    if (d->flags & 16)
-        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 0>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
-    else if (d->flags & 32)
-        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 1>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
-    else if (d->flags & 64)
-        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 3>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
-    else if (d->flags & 128) {  // 8 waves per block
+    // 8-wave blocks (256 query rows per K / V ring) for launches that still fill the chip with them and whose KV loop is long
+    // enough to amortise the bigger block (measured: 1.19 -> 1.09 ms at 48 x 5 x 4096^2, equal at 1024^2, slower at Sk = 145)
+    const long long nwg8 = (long long)k.batch * k.heads * ((d->Sq + 255) / 256);
+    if (!(d->flags & 4) && d->Sk >= 1024 && d->Sq >= 1024 && nwg8 >= 1024) {
         k.q_tiles = (d->Sq + 255) / 256;
-        const long long nwg8 = (long long)k.batch * k.heads * k.q_tiles;
-        if (d->flags & 256)
-            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 2, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
-        else
-            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 3, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
+        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
+        return av_launch_status("flash_attn_d64_v2<8 waves>");
     }
-    else
-        hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 2>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 4>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
     return av_launch_status("flash_attn_d64_v2");
 }
 

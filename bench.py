@@ -55,13 +55,32 @@ def measure_kernel(fn, iters=20, warm=10):
     return e0.elapsed_time(e1) / iters  # ms per launch, HIP events on the launching stream
 
 
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the newest profiles/r*_traffic.json -- written by tools/pmc_traffic.py from the
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (kernel name, git commit and the raw counters are recorded there).  The bench
+    cannot collect PMC counters itself (they need a rocprofv3 pass per counter group), so the value is `null` unless such a file
+    names this kernel; it is never a literal in this file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        rec = json.load(open(files[-1]))
+        for k, v in rec.get("kernels", {}).items():
+            if kernel_key in k:
+                return int(v["hbm_bytes_per_launch"]), {"file": os.path.relpath(files[-1], ROOT), "commit": rec.get("commit"),
+                                                        "kernel": k}
+    except Exception:
+        pass
+    return None, None
+
+
 def roofline_spatial_attention(device, pnp=False):
     """Spatial self-attention at the PnP-step shape (N=48 images, 5 heads, S=4096, d=64): 4*N*h*S^2*d FLOP.
 
-    pnp=False: the plain launch (every branch its own Q, K, V) -- flash_attn_d64_v2_kernel<3,1>; algorithmic FLOP ==
-    executed FLOP.  `traffic` is the HBM byte count per launch from the PMC passes recorded in
-    profiles/r01_attention_pmc.md (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE: 377.63 MB + 125.83 MB for the plain
-    launch, 212.92 MB + 125.84 MB for the shared-softmax launch), not re-measured here.
+    pnp=False: the plain launch (every branch its own Q, K, V) -- flash_attn_d64_v2_kernel<3,1,8> (8-wave blocks); algorithmic
+    FLOP == executed FLOP.  `traffic` is the HBM byte count per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) read from
+    the newest profiles/r*_traffic.json (see measured_traffic), or null.
     pnp=True: the launch the edit loop actually issues on injection steps (Q/K of all three branches alias the source
     branch) -- flash_attn_d64_v2_kernel<2,3> shares one S/softmax over three V streams, so it executes 2/3 of the
     reference op's MFMA FLOP; `achieved` prices the reference op's algorithmic FLOP (as the contract defines it) and
@@ -76,11 +95,11 @@ def roofline_spatial_attention(device, pnp=False):
     ms = measure_kernel(fn)
     flops = 4.0 * N * h * S * S * d
     ach = flops / (ms * 1e-3) / 1e12
-    r = {"bound": "mfma", "kernel": ("flash_attn_d64_v2_kernel<2,3> (spatial self-attn under PnP q/k injection, shared softmax, "
-                                     if pnp else "flash_attn_d64_v2_kernel<3,1> (spatial self-attn, ") + "N=48 h=5 S=4096 d=64)",
+    traffic, src = measured_traffic("flash_attn_d64_v2_kernel<2, 3, 4>" if pnp else "flash_attn_d64_v2_kernel<3, 1, 8>")
+    r = {"bound": "mfma", "kernel": ("flash_attn_d64_v2_kernel<2,3,4> (spatial self-attn under PnP q/k injection, shared softmax, "
+                                     if pnp else "flash_attn_d64_v2_kernel<3,1,8> (spatial self-attn, ") + "N=48 h=5 S=4096 d=64)",
          "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
-         "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
-         "traffic": 338765414 if pnp else 503455949}
+         "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src}
     if pnp:
         r["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
     return r
@@ -98,9 +117,10 @@ def roofline_conv(device):
     ms = measure_kernel(fn)
     flops = 2.0 * N * H * H * 9 * C * C
     ach = flops / (ms * 1e-3) / 1e12
+    traffic, src = measured_traffic("gemm_big_kernel<3, false, 1")
     return {"bound": "mfma", "kernel": "gemm_big_kernel<3,false,conv2d> (conv3x3 320->320 @64x64, N=48; persistent 192x320 tiles)", "achieved": round(ach, 2),
             "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": None}
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src}
 
 
 def effective_cpus() -> int:
@@ -119,7 +139,7 @@ def effective_cpus() -> int:
 def cpu_baseline():
     """The oracle (fp32 PyTorch restatement of the reference UNet + the PnP hooks) timed on this host's cores on a
     bounded sample: ONE inversion step (B=1) + ONE PnP step (B=3, all hooks on) of BASELINE config 1
-    (1 clip x 8 frames x 256x256), extrapolated to the 50+50-step job: frames/s = 8 / (50 * (t1 + t3))."""
+    (1 clip x 8 frames x 256x256), extrapolated to the 50+50-step job: frames/s = 8 / (50 * (t1 + t3)).  About 30 s on 16 cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import pnp_oracle
     from oracle.unet_oracle import UNetConfig, build_random_oracle
@@ -139,18 +159,86 @@ def cpu_baseline():
             ts.append(time.time() - t0)
         return sorted(ts)
 
-    with torch.no_grad():
-        ts1 = timed(lambda: oracle(inp["sample"][:1], 981, **kw(slice(0, 1))), 3)
-        t1 = ts1[1]  # median of 3 (the first run also pays the allocator / page faults)
+    with torch.no_grad():  # one untimed warm-up, then the median of 3, for both step kinds
+        f1 = lambda: oracle(inp["sample"][:1], 981, **kw(slice(0, 1)))
+        f1()
+        t1 = timed(f1, 3)[1]
         pnp_oracle.init_pnp(oracle, 50, 1.0, 1.0, 1.0)
         pnp_oracle.register_time(oracle, 981)
-        ts3 = timed(lambda: oracle(inp["sample"], 981, **kw(slice(0, 3))), 2)
-        t3 = ts3[0]  # faster of 2
+        f3 = lambda: oracle(inp["sample"], 981, **kw(slice(0, 3)))
+        f3()
+        t3 = timed(f3, 3)[1]
     fps = 8.0 / (STEPS_PER_STAGE * (t1 + t3))
     return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"config 1 (1 clip x 8f x 256x256): 1 inversion step B=1 ({t1:.2f}s, median of 3) + 1 PnP step B=3 with "
-                      f"hooks ({t3:.2f}s, faster of 2), fp32 torch on {cores} threads, extrapolated x50 steps per stage",
+            "sample": f"config 1 (1 clip x 8f x 256x256): 1 inversion step B=1 ({t1:.2f}s) + 1 PnP step B=3 with hooks ({t3:.2f}s), "
+                      f"each 1 warm-up + median of 3, fp32 torch on {cores} threads, extrapolated x50 steps per stage",
             "seconds_B1": round(t1, 3), "seconds_B3": round(t3, 3)}
+
+
+def whole_clip(pipe, device, seed):
+    """ONE whole BASELINE config-3 clip through the product pipeline, end to end on the GPU, next to the steady-state number:
+    native AutoencoderKL encode of 16 synthetic 512x512 frames (+ first-frame latent) -> pipe.invert (50 steps, trajectory
+    written to ddim_latents_{t}.pt files) -> pipe.sample_with_pnp (50 steps, the reference's default schedules 0.2 / 0.2 / 0.5
+    of configs/group_pnp_edit/template.yaml:38-40, cfg 9.0) -> native VAE decode to 16 PIL frames.  CLIP text / image embeddings
+    are synthetic tensors (the towers are not part of this timing).  Run twice: the first clip pays HIP-graph capture."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.encoders import attach_native_vae
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    from anyv2v_amd.utils import wait_for_pending_writes
+    attach_native_vae(pipe, random_init_seed=0)
+    rng = np.random.default_rng(seed)
+    frames = [Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)) for _ in range(FRAMES)]
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *sh: torch.randn(*sh, generator=g).to(torch.float16).to(device)
+    ehs, ie = r(3, 77, 1024), r(3, 1, 1024)
+    out = {}
+    for tag in ("first", "second"):
+        tmp = tempfile.mkdtemp(prefix="anyv2v_bench_clip_")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lat = pipe.encode_vae_video(frames, device, height=512, width=512)
+        first = pipe.vae.encode_image(frames[0], device, 512, 512)
+        il = pipe.prepare_image_latents_from_first_frame_latent(first, FRAMES)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pipe.register_modules(scheduler=DDIMInverseScheduler())
+        traj = pipe.invert(prompt_embeds=ehs[:1], image_embeddings=ie[:1], image_latents=il, height=512, width=512,
+                           num_frames=FRAMES, num_inference_steps=STEPS_PER_STAGE, guidance_scale=1.0, target_fps=8, latents=lat,
+                           output_dir=tmp, background_save=True, return_trajectory=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        sched = DDIMScheduler()
+        sched.set_timesteps(STEPS_PER_STAGE)
+        pipe.register_modules(scheduler=sched)
+        k = lambda ratio: sched.timesteps[: int(STEPS_PER_STAGE * ratio)]
+        pnp_utils.register_conv_injection(pipe, k(0.2))
+        pnp_utils.register_spatial_attention_pnp(pipe, k(0.2))
+        pnp_utils.register_temp_attention_pnp(pipe, k(0.5))
+        T = max(traj.keys())
+        video = pipe.sample_with_pnp(prompt_embeds=ehs[2:3], negative_prompt_embeds=ehs[1:2], image_embeddings=ie[2:3],
+                                     image_latents=il, height=512, width=512, num_frames=FRAMES,
+                                     num_inference_steps=STEPS_PER_STAGE, guidance_scale=9.0, target_fps=8, latents=traj[T].clone(),
+                                     output_type="pil", decode_chunk_size=1, ddim_init_latents_t_idx=0, ddim_inv_latents_path=traj,
+                                     ddim_inv_prompt_embeds=ehs[:1], ddim_inv_image_embeddings=ie[:1],
+                                     ddim_inv_image_latents=il).frames[0]
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        wait_for_pending_writes(tmp)
+        t4 = time.perf_counter()
+        pnp_utils.clear_time(pipe)
+        nfiles = len([f for f in os.listdir(tmp) if f.startswith("ddim_latents_")])
+        shutil.rmtree(tmp, ignore_errors=True)
+        out[tag] = {"seconds": round(t4 - t0, 3), "frames_per_s": round(FRAMES / (t4 - t0), 4), "vae_encode_s": round(t1 - t0, 3),
+                    "invert_50_steps_s": round(t2 - t1, 3), "pnp_edit_50_steps_plus_vae_decode_s": round(t3 - t2, 3),
+                    "trajectory_files_flush_s": round(t4 - t3, 3), "trajectory_files": nfiles, "frames_out": len(video)}
+    out["what"] = ("one config-3 clip end to end: native VAE encode (16 x 512x512) + pipe.invert 50 steps (+ddim_latents_t.pt files) + "
+                   "pipe.sample_with_pnp 50 steps (schedules 0.2/0.2/0.5, cfg 9) + native VAE decode; synthetic CLIP embeddings; "
+                   "'first' includes HIP-graph capture")
+    return out
 
 
 def finish_distributed(dist, dt, latents, world, device):
@@ -170,6 +258,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-clip", action="store_true", help="skip the end-to-end timing of one whole clip")
     ap.add_argument("--seed", type=int, default=8888)
     args = ap.parse_args()
 
@@ -259,12 +348,19 @@ def main():
                                    "1 inversion step + 1 edit step = 1/50 clip; I2VGen-XL 3D-UNet 1.42B params, random init",
                        "steps_per_stage": STEPS_PER_STAGE, "frames": FRAMES, "latent": [4, FRAMES, LAT, LAT],
                        "hip_graphs": os.environ.get("ANYV2V_NO_GRAPH", "0") != "1", "finite": finite,
-                       "excluded": "VAE encode/decode, CLIP encoders, file I/O (SURVEY 8(f) F1/F2)"},
+                       "excluded": "`value` is the steady-state loop rate: VAE encode/decode, CLIP encoders and file I/O are outside "
+                                   "(SURVEY 8(f) F1/F2); the `clip` object times one whole clip including VAE and the trajectory files"},
         }
         if not args.no_roofline:  # rank 0, after the timed region (the other ranks wait at destroy_process_group)
             line["roofline"] = roofline_spatial_attention(device)
             line["roofline_pnp"] = roofline_spatial_attention(device, pnp=True)
             line["roofline_gemm"] = roofline_conv(device)
+        if world == 1 and not args.no_clip:
+            del e_inv, e_pnp
+            torch.cuda.empty_cache()
+            pnp_utils.clear_time(pipe)
+            line["clip"] = whole_clip(pipe, device, args.seed)
+            e_inv = e_pnp = None
         if world == 1 and not args.no_cpu_baseline:
             del pipe, e_inv, e_pnp
             torch.cuda.empty_cache()

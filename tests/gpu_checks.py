@@ -565,6 +565,24 @@ def check_attention(naive_too=True):
         q[1], k[1], q[2], k[2] = q[0], k[0], q[0], k[0]
         out.append(_res(f"attn[shared softmax] {name}", o3, _sdpa(q, k, v).transpose(1, 2).reshape(b3 * S, C), 6e-3))
     out += check_attention_forced_rescale()
+    # 8-wave (256-query) blocks: taken for launches with >= 1024 such blocks and Sq, Sk >= 1024; the same launch forced onto
+    # 4-wave blocks (flag bit2) must give the same bits (a wave's instruction stream does not depend on the block shape)
+    b, h, S = 13, 5, 4096
+    C = 64 * h
+    qkv = rnd(b * S, 3 * C, scale=1.0, seed=2024)
+    o8 = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
+    o4 = torch.zeros_like(o8)
+    kw8 = dict(batch=b, heads=h, Sq=S, Sk=S, inner=1, q_strides=(S, 0, 1), kv_strides=(S, 0, 1))
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o8, **kw8)
+    saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | 4
+    try:
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o4, **kw8)
+    finally:
+        ops.ATTN_FLAGS = saved
+    out.append(_res("attn[flash] 8-wave blocks == 4-wave blocks (b13 h5 S4096)", o8, o4.float(), 1e-6))
+    q, k, v = (qkv[:2 * S, i * C:(i + 1) * C].view(2, S, h, 64).transpose(1, 2) for i in range(3))
+    out.append(_res("attn[flash] 8-wave blocks vs fp32 SDPA (first 2 of b13 h5 S4096)", o8[:2 * S],
+                    _sdpa(q, k, v).transpose(1, 2).reshape(2 * S, C), 6e-3))
     B_, HW, h, Fr = 2, 12, 2, 128  # temporal sequences of 128 frames (BASELINE config 5): frame stride HW
     C = 64 * h
     qkv = rnd(B_ * Fr * HW, 3 * C)

@@ -1,5 +1,6 @@
-"""A/B of the flash kernel's softmax forms (dev flags 16 = textbook + deferred rescale, 32 = whole-tile fast path, 0 = chunked
-16-key steps): parity of each form on the full attention check, then interleaved timing at the UNet's shapes.
+"""A/B of flash-kernel variants selected by AnyV2VAttnDesc.flags (SM_FORMS="flag:name,..."; default: 8-wave dispatch vs 4-wave
+blocks only) or of two builds (ANYV2V_LIB): parity of each on the full attention check, then interleaved timing at the UNet's shapes.
+(Round 2 used it with development flags for the softmax forms: profiles/r02_attn_softmax_forms_ab*.txt.)
 Writes gpurun_out/attn_sm_ab.txt.   python tools/attn_sm_ab.py"""
 import os
 import sys
@@ -17,7 +18,7 @@ from anyv2v_amd import ops  # noqa: E402
 
 dev = "cuda"
 lines = []
-FORMS = [(int(f), n) for f, n in (a.split(":") for a in os.environ.get("SM_FORMS", "16:textbook,0:chunk-prescaled,64:chunk-exact,128:exact-8w,384:prescaled-8w").split(","))]
+FORMS = [(int(f), n) for f, n in (a.split(":") for a in os.environ.get("SM_FORMS", "0:default,4:4-wave-blocks").split(","))]
 
 
 def say(s):
