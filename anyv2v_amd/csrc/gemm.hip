@@ -557,7 +557,7 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
 #undef AV_RB
 }
 
-template <int MF, bool GEGLU, int MODE, bool TRACE = false, bool SPLIT = false, bool COOP = true>
+template <int MF, bool GEGLU, int MODE, bool TRACE = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     constexpr int BM = 64 * MF, BN = 320;  // four wave rows of MF 16-row fragments
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -664,7 +664,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
         landed = true;
         rederive = true;
 
-        // ---------------- wave-private epilogue: 4 slabs of 16 rows x 160 (GEGLU: 80) output columns ----------------
+        // ---------------- wave-private epilogue: MF slabs of 16 rows x 160 (GEGLU: 80) output columns ----------------
+        // (measured alternatives, both bit-equal and slower: pair-wise LDS exchange for full-row stores, round 1; a block-cooperative
+        //  form -- four barrier-separated steps through LDS, all 512 threads storing whole rows -- round 2, 5-40 % slower on the
+        //  3-clip shapes: with one block per CU nothing overlaps its serial steps.  profiles/r02_gemm_coop_epilogue_ab.txt)
         // the epilogue's lane-derived offsets must not be hoisted out of the tile loop (they would live across the K loop
         // and spill): launder the lane id once per tile
         int lane_e = lane;
@@ -684,115 +687,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
             continue;
         }
         if constexpr (SPLIT) __builtin_unreachable();
-        if constexpr (COOP) {
-            // ---------------- block-cooperative epilogue ----------------
-            // Phase A (all waves): accumulators -> (+bias, +temb row vector | GEGLU) -> packed fp16 registers.
-            // Phase B: four steps, one per wave row: its two waves drop their 48 x 320 (GEGLU: 160) slice into one of two LDS
-            // regions (inside the just-consumed stage; the other stage holds the next tile's prefetched K-tile 0), one block
-            // barrier, then ALL 512 threads add the residual and store the 48 rows as 16-byte chunks of whole rows: with
-            // ldc == N every wave instruction writes one contiguous KiB.  The wave-private form it replaces wrote 320-byte half
-            // rows (2.5 cache lines, the middle line shared by two waves) and, because vmcnt retires in order, waited for its
-            // own previous stores whenever it waited for the next residual slab.  Here the residual of step q + 1 is requested
-            // before step q's stores, so every wait is a counted one that leaves the stores in flight.
-            constexpr int OUT_W = GEGLU ? 160 : 320;  // output columns of the block tile
-            constexpr int NJ = GEGLU ? 5 : 10;        // 4-column groups per fragment row and wave
-            constexpr int ROW_B = OUT_W * 2 + 8;      // LDS row pitch (648 / 328 bytes: conflict-free 8-byte writes)
-            constexpr int QROWS = MF * 16;            // rows per step
-            constexpr int REG_B = QROWS * ROW_B;
-            static_assert(2 * REG_B <= STAGE_BYTES, "two epilogue regions must fit in one pipeline stage");
-            constexpr int CPR = OUT_W / 8;            // 16-byte chunks per output row (40 / 20)
-            constexpr int RPI = 480 / CPR;            // rows per store iteration: 480 of the 512 threads, thread = (row, chunk)
-            constexpr int NITC = QROWS / RPI;         // store iterations per step (4 / 2)
-            static_assert(RPI * CPR == 480 && NITC * RPI == QROWS, "store phase geometry");
-            char* const cbuf = smem + (stage ^ 1) * STAGE_BYTES;
-            int tid_e = tid;
-            asm volatile("" : "+v"(tid_e));  // (see lane_e above: keep the epilogue's address math out of the K loop)
-            const int wr_e = tid_e >> 7, wc_e = (tid_e >> 6) & 1;
-            const int n_out_blk = nt * OUT_W;
-            h4 bvec[10];
-#pragma unroll
-            for (int nf = 0; nf < 10; ++nf)
-                bvec[nf] = *(const h4*)(p.bias != nullptr ? p.bias + n_wave + nf * 16 + 4 * lq : p.zeros);
-            h4 oh[MF][NJ];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                if constexpr (GEGLU) {
-#pragma unroll
-                    for (int np = 0; np < 5; ++np)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float hv = (float)(half_t)(acc[mf][2 * np][r] + (float)bvec[2 * np][r]);
-                            const float gv = (float)(half_t)(acc[mf][2 * np + 1][r] + (float)bvec[2 * np + 1][r]);
-                            oh[mf][np][r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
-                        }
-                } else {
-                    const bool has_rv = p.rowvec != nullptr;
-                    const int mrow = m_wave + mf * 16 + l15;
-                    const half_t* rv = has_rv ? p.rowvec + (size_t)((mrow < p.M ? mrow : 0) / p.rowvec_div) * p.ldrv + n_wave + 4 * lq
-                                              : p.zeros;
-#pragma unroll
-                    for (int nf = 0; nf < 10; ++nf) {
-                        h4 tv = (h4){0, 0, 0, 0};
-                        if (has_rv) tv = *(const h4*)(rv + nf * 16);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) oh[mf][nf][r] = (half_t)(acc[mf][nf][r] + (float)bvec[nf][r] + (float)tv[r]);
-                    }
-                }
-            }
-            const bool has_res = p.R != nullptr;
-            // store-phase thread -> (row r0 of each RPI-row group, 16-byte chunk cc): both fixed per thread, so every address
-            // below is one per-thread base plus a wave-uniform multiple of the leading dimension
-            const bool storer = tid_e < 480;
-            const int r0 = tid_e / CPR, cc = tid_e - r0 * CPR;
-            const int m0 = mt * BM + r0;
-            const half_t* rbase = p.R + (size_t)m0 * p.ldr + n_out_blk + cc * 8;
-            half_t* cbase = p.C + (size_t)m0 * p.ldc + n_out_blk + cc * 8;
-            const int lds_rd = r0 * ROW_B + cc * 16;
-            h8 rr[2][NITC];
-            auto res_load = [&](int q, h8 (&dst)[NITC]) {
-#pragma unroll
-                for (int it = 0; it < NITC; ++it) {
-                    const int dm = q * QROWS + it * RPI;
-                    const bool ok = storer && m0 + dm < p.M;
-                    dst[it] = *(const h8*)(ok ? rbase + (size_t)dm * p.ldr : p.zeros);
-                }
-            };
-            if (has_res) res_load(0, rr[0]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                char* const reg = cbuf + (q & 1) * REG_B;
-                if (wr_e == q) {
-#pragma unroll
-                    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            *(h4*)(reg + (mf * 16 + l15) * ROW_B + (wc_e * (OUT_W / 2) + j * 16 + 4 * lq) * 2) = oh[mf][j];
-                }
-                if (has_res && q + 1 < 4) res_load(q + 1, rr[(q + 1) & 1]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int it = 0; it < NITC; ++it) {
-                    const int dm = q * QROWS + it * RPI;
-                    const bool ok = storer && m0 + dm < p.M;
-                    h8 v = *(const h8*)(reg + (storer ? lds_rd + it * RPI * ROW_B : 0));
-                    if (has_res) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[q & 1][it][e]);
-                    }
-                    if (ok) *(h8*)(cbase + (size_t)dm * p.ldc) = v;
-                }
-            }
-            if constexpr (TRACE) {
-                if (tid == 0 && tile == b0) {
-                    p.trace[(size_t)blockIdx.x * 32 + 27] = (long long)__builtin_amdgcn_s_memtime();
-                    p.trace[(size_t)blockIdx.x * 32 + 28] = nk;
-                }
-            }
-            if (!has_next) break;
-            tile = next_tile;
-            continue;
-        }
         half_t* const slab = (half_t*)(smem + (stage ^ 1) * STAGE_BYTES + w * SLAB_BYTES);
         constexpr int OUT_W = GEGLU ? 80 : 160;       // output columns of this wave
         constexpr int CPRW = OUT_W / 8;               // 16-byte chunks per slab row
@@ -1049,17 +943,6 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
                 return av_launch_status("gemm_big<trace>");
             }
 #endif
-            if (d->flags & 512) {  // A/B: wave-private epilogue
-                if constexpr (MODE == MODE_LINEAR) {
-                    if (geglu)
-                        hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR, false, false, false>), grid, dim3(512), 0, s, k);
-                    else
-                        hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR, false, false, false>), grid, dim3(512), 0, s, k);
-                } else {
-                    hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, false, false, false>), grid, dim3(512), 0, s, k);
-                }
-                return av_launch_status("gemm_big<wave-private epilogue>");
-            }
             if constexpr (MODE == MODE_LINEAR) {
                 if (geglu)
                     hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR>), grid, dim3(512), 0, s, k);

@@ -109,3 +109,86 @@ def load_reference_pnp_utils():
 def load_reference_inverse_scheduler():
     """The reference's vendored ``consisti2v/ddim_inverse_scheduler.py``, verbatim."""
     return _load(os.path.join(REFERENCE_ROOT, "consisti2v", "ddim_inverse_scheduler.py"), "_ref_ddim_inverse")
+
+
+def load_reference_consisti2v_models():
+    """The reference's in-tree restatements of the diffusers building blocks, verbatim:
+    ``consisti2v/consisti2v/models/videoldm_attention.py`` (``ConditionalAttention`` -- diffusers' ``Attention`` constructor,
+    head reshapes and score arithmetic), ``videoldm_transformer_blocks.py`` (``BasicConditionalTransformerBlock`` /
+    ``Transformer2DConditionModel`` -- block order, ``double_self_attention``, the spatial transformer's norm / proj / permute
+    wrapper) and ``videoldm_unet_blocks.py`` (``Conv3DLayer``, the (3,1,1) temporal convolution).  Everything they import
+    from diffusers is a stand-in: plain torch layers, and ``FeedForward`` is the ORACLE's own (its arithmetic lives in
+    diffusers 0.26.3 and stays unpinned).  Returns (attention module, transformer-blocks module, unet-blocks module)."""
+    import torch
+    from torch import nn
+    from oracle import unet_oracle as uo
+
+    before = set(sys.modules)
+    install_stubs()
+    try:
+        class _Logger:
+            def __getattr__(self, k):
+                return lambda *a, **kw: None
+
+        class _Dummy(nn.Module):
+            def __init__(self, *a, **kw):
+                super().__init__()
+
+        class LoRACompatibleLinear(nn.Linear):
+            def forward(self, x, scale: float = 1.0):
+                return super().forward(x)
+
+        class LoRACompatibleConv(nn.Conv2d):
+            def forward(self, x, scale: float = 1.0):
+                return super().forward(x)
+
+        class FeedForward(uo.FeedForward):  # diffusers signature in front of the oracle's arithmetic (NOT a pin of GEGLU)
+            def __init__(self, dim, dropout=0.0, activation_fn="geglu", final_dropout=False, **kw):
+                super().__init__(dim, None, activation_fn)
+
+            def forward(self, x, scale: float = 1.0):
+                return super().forward(x)
+
+        class Transformer2DModelOutput:
+            def __init__(self, sample):
+                self.sample = sample
+
+        ident = lambda cls: cls
+        _mod("diffusers.utils", USE_PEFT_BACKEND=True, BaseOutput=object, deprecate=lambda *a, **k: None,
+             logging=types.SimpleNamespace(get_logger=lambda *a, **k: _Logger()), is_torch_version=lambda *a, **k: True)
+        _mod("diffusers.utils.import_utils", is_xformers_available=lambda: False)
+        _mod("diffusers.utils.torch_utils", randn_tensor=None, maybe_allow_in_graph=ident)
+        _mod("diffusers.models.lora", LoRACompatibleLinear=LoRACompatibleLinear, LoRACompatibleConv=LoRACompatibleConv,
+             LoRALinearLayer=_Dummy)
+        ap = _mod("diffusers.models.attention_processor", AttnProcessor2_0=uo.AttnProcessor2_0, Attention=_Dummy)
+        for n in ("AttnAddedKVProcessor", "AttnAddedKVProcessor2_0", "AttnProcessor", "SpatialNorm", "CustomDiffusionAttnProcessor",
+                  "CustomDiffusionXFormersAttnProcessor", "SlicedAttnAddedKVProcessor", "XFormersAttnAddedKVProcessor",
+                  "LoRAAttnAddedKVProcessor", "XFormersAttnProcessor", "LoRAXFormersAttnProcessor", "LoRAAttnProcessor",
+                  "LoRAAttnProcessor2_0", "SlicedAttnProcessor", "AttentionProcessor"):
+            setattr(ap, n, type(n, (), {}))
+        ap.LORA_ATTENTION_PROCESSORS = ()
+        _mod("diffusers.models.embeddings", ImagePositionalEmbeddings=_Dummy, PatchEmbed=_Dummy)
+        _mod("diffusers.models.attention", AdaLayerNorm=_Dummy, AdaLayerNormZero=_Dummy, FeedForward=FeedForward,
+             GatedSelfAttentionDense=_Dummy)
+        _mod("diffusers.models.modeling_utils", ModelMixin=nn.Module)
+        _mod("diffusers.models.transformer_2d", Transformer2DModelOutput=Transformer2DModelOutput)
+        _mod("diffusers.models.unet_2d_blocks", DownBlock2D=_Dummy, UpBlock2D=_Dummy)
+        _mod("diffusers.models.resnet", ResnetBlock2D=uo.ResnetBlock2D, Downsample2D=uo.Downsample2D, Upsample2D=uo.Upsample2D)
+        _mod("diffusers.models.dual_transformer_2d", DualTransformer2DModel=_Dummy)
+        _mod("diffusers.models.activations", get_activation=lambda name: nn.SiLU())
+        import typing
+        _mod("beartype", beartype=ident)
+        _mod("beartype.typing", Literal=typing.Literal, Union=typing.Union, Optional=typing.Optional)
+        pkg_dir = os.path.join(REFERENCE_ROOT, "consisti2v", "consisti2v", "models")
+        pkg = types.ModuleType("_ref_consisti2v_models")
+        pkg.__path__ = [pkg_dir]
+        sys.modules["_ref_consisti2v_models"] = pkg
+        import importlib
+        att = importlib.import_module("_ref_consisti2v_models.videoldm_attention")
+        blocks = importlib.import_module("_ref_consisti2v_models.videoldm_transformer_blocks")
+        ublocks = importlib.import_module("_ref_consisti2v_models.videoldm_unet_blocks")
+    finally:
+        for k in set(sys.modules) - before:
+            if k.split(".")[0] in ("torchvision", "diffusers", "beartype"):
+                del sys.modules[k]
+    return att, blocks, ublocks

@@ -1,0 +1,31 @@
+"""Launch the bench's roofline kernels a few times each so that a `rocprofv3 --pmc ...` pass stays short: spatial self-attention at
+the graded shape (N=48, h=5, S=4096, d=64; plain and PnP shared-softmax launch) and the conv3x3 320->320 @64x64 (N=48).
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o t -- python tools/pmc_targets.py
+(one pass per counter group; summarise with tools/pmc_traffic.py / tools/pmc_summary.py)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from anyv2v_amd import ops  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+N, h, S = 48, 5, 4096
+C = 64 * h
+q = torch.randn(N * S, 3 * C, device="cuda").half()
+o = torch.empty(N * S, C, dtype=torch.float16, device="cuda")
+for qk_mod in (0, N // 3):
+    for _ in range(reps):
+        ops.attention(q[:, :C], q[:, C:2 * C], q[:, 2 * C:], o, batch=N, heads=h, Sq=S, Sk=S, inner=1,
+                      q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=qk_mod)
+H = 64
+x = torch.randn(N * H * H, C, device="cuda").half()
+w = (torch.randn(C, 9 * C, device="cuda") / (9 * C) ** 0.5).half()
+b = torch.zeros(C, dtype=torch.float16, device="cuda")
+out = torch.empty(N * H * H, C, dtype=torch.float16, device="cuda")
+for _ in range(reps):
+    ops.gemm(x, w, bias=b, mode=ops.MODE_CONV2D, conv=(H, H, H, H, 1, 0), out=out)
+torch.cuda.synchronize()
+print("done")
