@@ -34,6 +34,7 @@ struct AttnK {
     float scale_log2;
     int q_tiles;
     int head_dim;
+    int causal;  // generic kernel only: key j is visible to query s iff j <= s (CLIP text tower)
 };
 
 __device__ __forceinline__ long long attn_row(long long i, int inner, long long so, long long si) {
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Generic reference kernel: one thread per (batch, head, query); any head_dim <= 64, any strides.
+// Generic reference kernel: one thread per (batch, head, query); any head_dim <= 128, any strides, optional causal mask.
 __global__ void attn_naive_kernel(const AttnK p) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)p.batch * p.heads * p.Sq;
@@ -475,7 +476,7 @@ __global__ void attn_naive_kernel(const AttnK p) {
     const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
     const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
     const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-    float q[64], o[64];
+    float q[128], o[128];
     const half_t* qp = p.Q + (qbase + (long long)s * p.q_seq) * p.ldq + h * D;
     for (int d = 0; d < D; ++d) {
         q[d] = (float)qp[d];
@@ -483,7 +484,8 @@ __global__ void attn_naive_kernel(const AttnK p) {
     }
     float m = -1e30f, l = 0.f;
     const float c = p.scale_log2;
-    for (int k = 0; k < p.Sk; ++k) {
+    const int kend = p.causal ? (s + 1 < p.Sk ? s + 1 : p.Sk) : p.Sk;
+    for (int k = 0; k < kend; ++k) {
         const half_t* kp = p.K + (kbase + (long long)k * p.kv_seq) * p.ldk + h * D;
         float sc = 0.f;
         for (int d = 0; d < D; ++d) sc += q[d] * (float)kp[d];
@@ -517,6 +519,7 @@ static int fill(const AnyV2VAttnDesc* d, AttnK& k, int head_dim) {
     k.scale_log2 = d->scale * 1.4426950408889634f;
     k.q_tiles = (d->Sq + 127) / 128;
     k.head_dim = head_dim;
+    k.causal = 0;
     return ANYV2V_OK;
 }
 
@@ -566,9 +569,10 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
 }
 
 extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream) {
-    AV_CHECK(head_dim > 0 && head_dim <= 64, "attention_small: head_dim must be in 1..64");
+    AV_CHECK(head_dim > 0 && head_dim <= 128, "attention_small: head_dim must be in 1..128");
     AttnK k;
     int rc = fill(d, k, head_dim);
     if (rc != ANYV2V_OK) return rc;
+    k.causal = (d->flags & 16) ? 1 : 0;
     return launch_naive(k, (hipStream_t)stream);
 }

@@ -219,6 +219,87 @@ class HFImageEncoder:
         return self.model(pixel_values=x).image_embeds[:, None].to(torch.float16)  # [1,1,1024]
 
 
+class NativeTextEncoder:
+    """The checkpoint's CLIP text tower on the HIP kernels (``anyv2v_amd.clip.CLIPTextTower``) behind ``text_encoder.encode``:
+    ``encode_prompt`` of the reference (``pipeline_i2vgen_xl.py:224-409``) -- pad / truncate to ``model_max_length``, and with
+    ``clip_skip`` hidden state ``-(clip_skip + 1)`` followed by ``final_layer_norm`` (``:312-324``).  The tokenizer (host-side BPE
+    string processing) is ``transformers.CLIPTokenizer``."""
+
+    def __init__(self, tower, tokenizer):
+        self.tower, self.tokenizer = tower, tokenizer
+
+    def to(self, device):
+        self.tower.to(device)
+        return self
+
+    @torch.no_grad()
+    def encode(self, prompts, device, clip_skip=None):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        ids = self.tokenizer(prompts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                             return_tensors="pt").input_ids
+        return self.tower.ensure(device).encode_ids(ids, clip_skip)
+
+
+class NativeImageEncoder:
+    """The checkpoint's CLIP vision tower + projection on the HIP kernels (``anyv2v_amd.clip.CLIPVisionTower``) behind
+    ``image_encoder.encode`` -- ``_encode_image`` (``pipeline_i2vgen_xl.py:411-441``); same pre-processing as HFImageEncoder."""
+
+    def __init__(self, tower, crop=224):
+        self.tower, self.crop = tower, crop
+
+    def to(self, device):
+        self.tower.to(device)
+        return self
+
+    @torch.no_grad()
+    def encode(self, image, width, device):
+        img = _center_crop_wide(image, (width, width)).resize((self.crop, self.crop), resample=Image.BILINEAR)
+        x = (_pil_to_tensor(img) + 1.0) * 0.5  # [1,3,224,224] in [0,1]
+        mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+        x = (x - mean) / std
+        return self.tower.ensure(device).image_embeds(x)[:, None]  # [1,1,1024]
+
+
+def _load_tower_files(folder: str):
+    """(config dict, state dict) of one transformers model folder: config.json + model(.fp16).safetensors / pytorch_model.bin."""
+    import json
+    import os
+    cfg = json.load(open(os.path.join(folder, "config.json")))
+    for name in ("model.fp16.safetensors", "model.safetensors"):
+        f = os.path.join(folder, name)
+        if os.path.isfile(f):
+            from safetensors.torch import load_file
+            return cfg, load_file(f)
+    for name in ("pytorch_model.fp16.bin", "pytorch_model.bin"):
+        f = os.path.join(folder, name)
+        if os.path.isfile(f):
+            return cfg, torch.load(f, map_location="cpu")
+    raise FileNotFoundError(f"no weights file in {folder}")
+
+
+def attach_native_clip_encoders(pipe, root: str):
+    """Load ``<root>/text_encoder``, ``<root>/tokenizer``, ``<root>/image_encoder`` (the sub-folders of the
+    ``ali-vilab/i2vgen-xl`` checkpoint) onto the native towers when they exist locally.  Returns True when attached."""
+    import os
+    from .clip import CLIPTextTower, CLIPTowerConfig, CLIPVisionTower
+    need = [os.path.join(root, d) for d in ("text_encoder", "tokenizer", "image_encoder")]
+    if not all(os.path.isdir(d) for d in need):
+        return False
+    from transformers import CLIPTokenizer
+    pipe.tokenizer = CLIPTokenizer.from_pretrained(need[1])
+    tcfg, tsd = _load_tower_files(need[0])
+    vcfg, vsd = _load_tower_files(need[2])
+    pipe.text_encoder = NativeTextEncoder(CLIPTextTower(CLIPTowerConfig.from_hf(tcfg, "text"), tsd), pipe.tokenizer)
+    vc = CLIPTowerConfig.from_hf(vcfg, "vision")
+    if vc.projection_dim is None:
+        vc.projection_dim = vcfg.get("projection_dim")
+    pipe.image_encoder = NativeImageEncoder(CLIPVisionTower(vc, vsd), crop=vc.image_size or 224)
+    pipe.feature_extractor = object()
+    return True
+
+
 def attach_hf_clip_encoders(pipe, root: str):
     """Load ``<root>/text_encoder``, ``<root>/tokenizer``, ``<root>/image_encoder`` (the sub-folders of the
     ``ali-vilab/i2vgen-xl`` checkpoint) with ``transformers`` when they exist locally.  Returns True when attached."""

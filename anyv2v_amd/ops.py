@@ -182,8 +182,9 @@ def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = No
 
 
 def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_strides, kv_div=1, qk_mod=0,
-              scale=0.125, head_dim=64, naive=False):
-    """Strided multi-head attention over token matrices; see anyv2v_hip.h for the addressing."""
+              scale=0.125, head_dim=64, naive=False, causal=False):
+    """Strided multi-head attention over token matrices; see anyv2v_hip.h for the addressing.  ``causal`` (CLIP text tower)
+    and head_dim != 64 run on the small generic kernel."""
     lib = _lib.load()
     for t, n in ((q, "Q"), (k, "K"), (v, "V"), (out, "O")):
         _rowmajor(t, n)
@@ -194,8 +195,8 @@ def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_stri
     d.q_outer, d.q_inner, d.q_seq = q_strides
     d.kv_outer, d.kv_inner, d.kv_seq = kv_strides
     d.kv_div, d.qk_mod, d.scale = kv_div, qk_mod, scale
-    d.flags = (1 if (naive or FORCE_NAIVE) else 0) | ATTN_FLAGS
-    if head_dim == 64:
+    d.flags = (1 if (naive or FORCE_NAIVE) else 0) | ATTN_FLAGS | (16 if causal else 0)
+    if head_dim == 64 and not causal:
         _lib.check(lib.anyv2v_attention_f16(C.byref(d), _stream()), "anyv2v_attention_f16")
     else:
         _lib.check(lib.anyv2v_attention_small_f16(C.byref(d), head_dim, _stream()), "anyv2v_attention_small_f16")

@@ -127,7 +127,7 @@ def softmax_rows(s, scale, out=None):
 
 
 def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_strides, kv_div=1, qk_mod=0, scale=0.125,
-              head_dim=64, naive=False):
+              head_dim=64, naive=False, causal=False):
     i = torch.arange(batch)
     iq = i % qk_mod if qk_mod > 0 else i
 
@@ -141,7 +141,7 @@ def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_stri
     Q = q.float()[rq].view(batch, Sq, heads, D).transpose(1, 2)
     K = k.float()[rk].view(batch, Sk, heads, D).transpose(1, 2)
     V = v.float()[rv].view(batch, Sk, heads, D).transpose(1, 2)
-    O = F.scaled_dot_product_attention(Q, K, V, scale=scale).transpose(1, 2).reshape(batch, Sq, heads * D)
+    O = F.scaled_dot_product_attention(Q, K, V, scale=scale, is_causal=bool(causal)).transpose(1, 2).reshape(batch, Sq, heads * D)
     out[ro.reshape(-1)] = _h(O.reshape(batch * Sq, heads * D))
     return out
 

@@ -39,7 +39,8 @@ torch.set_num_threads(min(torch.get_num_threads(), _effective_cpus()))
 
 
 def _rel(a: torch.Tensor, b: torch.Tensor):
-    a, b = a.float(), b.float()
+    a = a.float()
+    b = b.float().to(a.device)
     denom = b.abs().max().clamp_min(1e-6)
     return float((a - b).abs().max() / denom), float((a - b).norm() / b.norm().clamp_min(1e-12))
 
@@ -628,6 +629,60 @@ def check_attention(naive_too=True):
     out.append(_res("attn small head_dim 4", o, ref, 6e-3))
     return out
 
+
+
+# ------------------------------------------------------------------------------------------------ CLIP towers (F1)
+def check_clip():
+    """``anyv2v_amd.clip`` on the real kernels vs ``transformers``' CLIPTextModel / CLIPVisionModelWithProjection in
+    fp32 on the CPU, same weights: a tiny pair (3 / 2 layers) and the checkpoint's widths (text 1024 / 16 heads x 64 / 4096 with
+    77 tokens and the causal mask; vision ViT-H/14: 1280 / 16 heads x 80 / 5120, 257 tokens, projection 1024) at 2 layers."""
+    import transformers
+    from anyv2v_amd.clip import CLIPTextTower, CLIPTowerConfig, CLIPVisionTower
+    out = []
+    for tag, tk, vk in (
+        ("tiny", dict(vocab_size=100, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                      max_position_embeddings=16),
+         dict(hidden_size=160, intermediate_size=320, num_hidden_layers=2, num_attention_heads=2, image_size=224, patch_size=32,
+              projection_dim=24)),
+        ("checkpoint widths, 2 layers", dict(vocab_size=1000, hidden_size=1024, intermediate_size=4096, num_hidden_layers=2,
+                                             num_attention_heads=16, max_position_embeddings=77),
+         dict(hidden_size=1280, intermediate_size=5120, num_hidden_layers=2, num_attention_heads=16, image_size=224, patch_size=14,
+              projection_dim=1024)),
+    ):
+        torch.manual_seed(7)
+        tcfg = transformers.CLIPTextConfig(bos_token_id=1, eos_token_id=2, hidden_act="gelu", **tk)
+        vcfg = transformers.CLIPVisionConfig(hidden_act="gelu", **vk)
+        tm, vm = transformers.CLIPTextModel(tcfg).eval(), transformers.CLIPVisionModelWithProjection(vcfg).eval()
+        with torch.no_grad():
+            for m in (tm, vm):
+                for n_, p_ in m.named_parameters():
+                    if p_.dim() >= 2:
+                        p_.normal_(0, 0.6 / p_.shape[-1] ** 0.5 if p_.dim() == 2 else 0.02)
+                    elif "bias" in n_:
+                        p_.normal_(0, 0.05)
+            # the comparison is against fp32 on the weights the towers hold in fp16
+            for m in (tm, vm):
+                for p_ in m.parameters():
+                    p_.copy_(p_.half().float())
+        S = tk["max_position_embeddings"]
+        ids = torch.randint(3, tk["vocab_size"], (3, S))
+        ids[:, -2:] = 2
+        text = CLIPTextTower(CLIPTowerConfig.from_hf(tcfg.to_dict()), tm.state_dict()).to(DEV)
+        with torch.no_grad():
+            want = tm(ids, output_hidden_states=True)
+        ln = getattr(tm, "text_model", tm).final_layer_norm
+        hs = text.hidden_states(ids)
+        out.append(_res(f"clip text [{tag}] last hidden state (pre-LN, causal)", hs[-1], want.hidden_states[-1], 6e-3))
+        for skip in (None, 1):
+            with torch.no_grad():
+                ref = want.last_hidden_state if skip is None else ln(want.hidden_states[-(skip + 1)])
+            out.append(_res(f"clip text [{tag}] encode clip_skip={skip}", text.encode_ids(ids, skip), ref, 8e-3))
+        vis = CLIPVisionTower(CLIPTowerConfig.from_hf(vcfg.to_dict()), vm.state_dict()).to(DEV)
+        px = torch.randn(2, 3, 224, 224)
+        with torch.no_grad():
+            ref = vm(pixel_values=px.half().float()).image_embeds
+        out.append(_res(f"clip vision [{tag}] image_embeds", vis.image_embeds(px), ref, 8e-3))
+    return out
 
 # ------------------------------------------------------------------------------------------------ elementwise
 def check_elementwise():

@@ -306,6 +306,95 @@ def test_hf_clip_adapters_follow_the_reference_encode_paths():
     assert HFImageEncoder(vm).encode(img, 512, torch.device("cpu")).shape == (1, 1, 24)
 
 
+def _tiny_clip_pair(transformers, head_dim_text=64, head_dim_vis=80):
+    """Randomly initialised tiny CLIP towers with the head dims of the checkpoint's (text 64, vision 80) + their state dicts."""
+    torch.manual_seed(0)
+    tcfg = transformers.CLIPTextConfig(vocab_size=100, hidden_size=2 * head_dim_text, intermediate_size=256, num_hidden_layers=3,
+                                       num_attention_heads=2, max_position_embeddings=16, bos_token_id=1, eos_token_id=2,
+                                       hidden_act="gelu")
+    vcfg = transformers.CLIPVisionConfig(hidden_size=2 * head_dim_vis, intermediate_size=320, num_hidden_layers=2,
+                                         num_attention_heads=2, image_size=224, patch_size=32, projection_dim=24, hidden_act="gelu")
+    tm, vm = transformers.CLIPTextModel(tcfg).eval(), transformers.CLIPVisionModelWithProjection(vcfg).eval()
+    with torch.no_grad():  # the default init leaves most activations ~0: make every layer matter
+        for m in (tm, vm):
+            for n_, p_ in m.named_parameters():
+                if p_.dim() >= 2:
+                    p_.normal_(0, 0.08)
+                elif "bias" in n_:
+                    p_.normal_(0, 0.05)
+    return tm, vm, tcfg, vcfg
+
+
+def test_native_clip_towers_vs_transformers(cpu_ops):
+    """``anyv2v_amd.clip`` (the towers behind encode_prompt / _encode_image, pipeline_i2vgen_xl.py:224-441) on the
+    emulated ops vs ``transformers``' own CLIPTextModel / CLIPVisionModelWithProjection in fp32 on the same weights: every hidden
+    state (causal mask), clip_skip in {None, 1, 2} through the final LayerNorm, and the projected image embedding (head_dim 80,
+    class token, pre / post LayerNorm).  The same comparison runs on the real kernels in the -m gpu suite."""
+    transformers = pytest.importorskip("transformers")
+    from anyv2v_amd.clip import CLIPTextTower, CLIPTowerConfig, CLIPVisionTower
+    tm, vm, tcfg, vcfg = _tiny_clip_pair(transformers)
+    ids = torch.randint(3, 100, (3, 16))
+    ids[:, -3:] = 2
+    text = CLIPTextTower(CLIPTowerConfig.from_hf(tcfg.to_dict()), tm.state_dict()).to("cpu")
+    with torch.no_grad():
+        want = tm(ids, output_hidden_states=True)
+    got = text.hidden_states(ids)
+    assert len(got) == len(want.hidden_states) == 4
+    for g_, w_ in zip(got, want.hidden_states):
+        assert (g_.float() - w_).abs().max() <= 6e-3 * max(1.0, float(w_.abs().max()))
+    ln = getattr(tm, "text_model", tm).final_layer_norm
+    for skip in (None, 1, 2):
+        ref = (want.last_hidden_state if skip is None else ln(want.hidden_states[-(skip + 1)])).detach()
+        assert (text.encode_ids(ids, skip).float() - ref).abs().max() <= 8e-3 * float(ref.abs().max())
+    vis = CLIPVisionTower(CLIPTowerConfig.from_hf(vcfg.to_dict()), vm.state_dict()).to("cpu")
+    px = torch.randn(2, 3, 224, 224)
+    with torch.no_grad():
+        ref = vm(pixel_values=px).image_embeds
+    got = vis.image_embeds(px)
+    assert got.shape == (2, 24) and (got.float() - ref).abs().max() <= 8e-3 * float(ref.abs().max())
+
+
+def test_native_clip_encoders_follow_the_reference_encode_paths(cpu_ops, tmp_path):
+    """``attach_native_clip_encoders`` on a checkpoint-shaped folder (text_encoder / tokenizer / image_encoder with config.json +
+    model.safetensors): the encoders it builds agree with the transformers-module adapters on the reference's encode paths."""
+    transformers = pytest.importorskip("transformers")
+    from PIL import Image
+    from safetensors.torch import save_file
+
+    from anyv2v_amd.encoders import HFImageEncoder, HFTextEncoder, NativeImageEncoder, NativeTextEncoder, _load_tower_files
+    from anyv2v_amd.clip import CLIPTextTower, CLIPTowerConfig, CLIPVisionTower
+    tm, vm, tcfg, vcfg = _tiny_clip_pair(transformers)
+    for name, m, c in (("text_encoder", tm, tcfg), ("image_encoder", vm, vcfg)):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "config.json").write_text(c.to_json_string())
+        save_file({k: v.contiguous() for k, v in m.state_dict().items()}, str(d / "model.safetensors"))
+
+    class Tok:
+        model_max_length = 16
+
+        def __call__(self, prompts, padding, max_length, truncation, return_tensors):
+            ids = torch.zeros(len(prompts), max_length, dtype=torch.long)
+            for i, p in enumerate(prompts):
+                t = [(ord(c) % 90) + 3 for c in p][: max_length - 1]
+                ids[i, : len(t)] = torch.tensor(t, dtype=torch.long)
+                ids[i, len(t)] = 2
+            return type("O", (), {"input_ids": ids})
+
+    tc, tsd = _load_tower_files(str(tmp_path / "text_encoder"))
+    vc, vsd = _load_tower_files(str(tmp_path / "image_encoder"))
+    nat_t = NativeTextEncoder(CLIPTextTower(CLIPTowerConfig.from_hf(tc, "text"), tsd), Tok())
+    nat_v = NativeImageEncoder(CLIPVisionTower(CLIPTowerConfig.from_hf(vc, "vision"), vsd))
+    dev = torch.device("cpu")
+    for skip in (None, 1):
+        a = nat_t.encode(["a robot", ""], dev, clip_skip=skip)
+        b = HFTextEncoder(tm, Tok()).encode(["a robot", ""], dev, clip_skip=skip)
+        assert a.shape == b.shape == (2, 16, 128) and (a.float() - b.float()).abs().max() <= 8e-3 * float(b.float().abs().max())
+    img = Image.fromarray((np.random.RandomState(0).rand(300, 500, 3) * 255).astype("uint8"))
+    a, b = nat_v.encode(img, 512, dev), HFImageEncoder(vm).encode(img, 512, dev)
+    assert a.shape == b.shape == (1, 1, 24) and (a.float() - b.float()).abs().max() <= 8e-3 * float(b.float().abs().max())
+
+
 def test_pnp_without_cfg_is_refused(cpu_ops):
     """Reference quirk B.1: with guidance_scale <= 1 the hooks would slice a 2-way batch in thirds; we raise instead."""
     from anyv2v_amd import pnp_utils
