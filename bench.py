@@ -178,8 +178,9 @@ def cpu_baseline():
 def whole_clip(pipe, device, seed):
     """ONE whole BASELINE config-3 clip through the product pipeline, end to end on the GPU, next to the steady-state number:
     native AutoencoderKL encode of 16 synthetic 512x512 frames (+ first-frame latent) -> pipe.invert (50 steps, trajectory
-    written to ddim_latents_{t}.pt files) -> pipe.sample_with_pnp (50 steps, the reference's default schedules 0.2 / 0.2 / 0.5
-    of configs/group_pnp_edit/template.yaml:38-40, cfg 9.0) -> native VAE decode to 16 PIL frames.  CLIP text / image embeddings
+    written to ddim_latents_{t}.pt files) -> pipe.sample_with_pnp (50 steps, all three injections on every step and
+    ddim_init_latents_t_idx 0: the active demo entry, configs/group_pnp_edit/group_config.json:2-13 -- the same schedule as the
+    steady-state number; cfg 9.0) -> native VAE decode to 16 PIL frames.  CLIP text / image embeddings
     are synthetic tensors (the towers are not part of this timing).  Run twice: the first clip pays HIP-graph capture."""
     import shutil
     import tempfile
@@ -215,9 +216,9 @@ def whole_clip(pipe, device, seed):
         sched.set_timesteps(STEPS_PER_STAGE)
         pipe.register_modules(scheduler=sched)
         k = lambda ratio: sched.timesteps[: int(STEPS_PER_STAGE * ratio)]
-        pnp_utils.register_conv_injection(pipe, k(0.2))
-        pnp_utils.register_spatial_attention_pnp(pipe, k(0.2))
-        pnp_utils.register_temp_attention_pnp(pipe, k(0.5))
+        pnp_utils.register_conv_injection(pipe, k(1.0))
+        pnp_utils.register_spatial_attention_pnp(pipe, k(1.0))
+        pnp_utils.register_temp_attention_pnp(pipe, k(1.0))
         T = max(traj.keys())
         video = pipe.sample_with_pnp(prompt_embeds=ehs[2:3], negative_prompt_embeds=ehs[1:2], image_embeddings=ie[2:3],
                                      image_latents=il, height=512, width=512, num_frames=FRAMES,
@@ -236,7 +237,7 @@ def whole_clip(pipe, device, seed):
                     "invert_50_steps_s": round(t2 - t1, 3), "pnp_edit_50_steps_plus_vae_decode_s": round(t3 - t2, 3),
                     "trajectory_files_flush_s": round(t4 - t3, 3), "trajectory_files": nfiles, "frames_out": len(video)}
     out["what"] = ("one config-3 clip end to end: native VAE encode (16 x 512x512) + pipe.invert 50 steps (+ddim_latents_t.pt files) + "
-                   "pipe.sample_with_pnp 50 steps (schedules 0.2/0.2/0.5, cfg 9) + native VAE decode; synthetic CLIP embeddings; "
+                   "pipe.sample_with_pnp 50 steps (injection schedules 1.0/1.0/1.0 as the active demo entry, cfg 9) + native VAE decode; synthetic CLIP embeddings; "
                    "'first' includes HIP-graph capture")
     return out
 
