@@ -24,7 +24,7 @@ def say(s):
 
 for flag, name in FORMS:
     ops.GEMM_FLAGS = flag
-    res = gc.check_gemm_big()
+    res = gc.check_gemm_big() + gc.check_conv(("glds",)) + gc.check_gemm_splitk() + gc.check_vae_kernels()
     bad = [r for r in res if not r["ok"]]
     say(f"[{name}] parity: {len(res) - len(bad)}/{len(res)} ok, worst {max(r['err'] for r in res):.2e}")
     for r in bad:
@@ -42,9 +42,9 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-def case(tag, M, N, K, mode=0, act=0, conv=None, temporal=None, res=False, rv=0, rounds=5, iters=10):
+def case(tag, M, N, K, mode=0, act=0, conv=None, temporal=None, res=False, rv=0, rounds=5, iters=10, a_rows=None):
     taps = {0: 1, 1: 9, 2: 3}[mode]
-    a = torch.randn(M, K // taps, device=dev).half()
+    a = torch.randn(a_rows or M, K // taps, device=dev).half()
     w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
     b = torch.zeros(N, dtype=torch.float16, device=dev)
     n_out = N // 2 if act == 3 else N
@@ -66,6 +66,24 @@ def case(tag, M, N, K, mode=0, act=0, conv=None, temporal=None, res=False, rv=0,
         f"{n}: med {sorted(v)[len(v) // 2]:7.1f} min {min(v):7.1f} us ({fl / min(v) / 1e6:5.0f} TF, {by / min(v) / 1e3:5.0f} GB/s)" for n, v in ts.items()))
 
 
+if os.environ.get("GEMM_CASES") == "conv":
+    for B, tagB in ((3, "B3"), (1, "B1")):
+        N0 = 16 * B
+        case(f"{tagB} conv 320->320 @64", N0 * 4096, 320, 2880, mode=1, conv=(64, 64, 64, 64, 1, 0), res=True)
+        case(f"{tagB} conv 320->320 @64 +temb", N0 * 4096, 320, 2880, mode=1, conv=(64, 64, 64, 64, 1, 0), rv=65536)
+        case(f"{tagB} conv 640->320 @64", N0 * 4096, 320, 5760, mode=1, conv=(64, 64, 64, 64, 1, 0), rv=65536)
+        case(f"{tagB} conv 960->320 @64", N0 * 4096, 320, 8640, mode=1, conv=(64, 64, 64, 64, 1, 0), rv=65536)
+        case(f"{tagB} conv 320->320 s2 64->32", N0 * 1024, 320, 2880, mode=1, conv=(64, 64, 32, 32, 2, 0), a_rows=N0 * 4096)
+        case(f"{tagB} conv 640->640 @32", N0 * 1024, 640, 5760, mode=1, conv=(32, 32, 32, 32, 1, 0), res=True)
+        case(f"{tagB} conv 1280->640 @32", N0 * 1024, 640, 11520, mode=1, conv=(32, 32, 32, 32, 1, 0), rv=16384)
+        case(f"{tagB} conv 1280->1280 @16", N0 * 256, 1280, 11520, mode=1, conv=(16, 16, 16, 16, 1, 0), res=True)
+        case(f"{tagB} conv 2560->1280 @16", N0 * 256, 1280, 23040, mode=1, conv=(16, 16, 16, 16, 1, 0), rv=4096)
+        case(f"{tagB} conv 1280->1280 @8", N0 * 64, 1280, 11520, mode=1, conv=(8, 8, 8, 8, 1, 0), res=True)
+        case(f"{tagB} conv 2560->1280 @8", N0 * 64, 1280, 23040, mode=1, conv=(8, 8, 8, 8, 1, 0), rv=1024)
+    ops.GEMM_FLAGS = 0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", os.environ.get("GEMM_AB_OUT", "gemm_epi_ab.txt")), "w").write("\n".join(lines) + "\n")
+    sys.exit(0)
 for B, tagB in ((3, "B3"), (1, "B1")):
     T0, T1, T2 = B * 65536, B * 16384, B * 4096
     case(f"{tagB} L0 out-proj +res", T0, 320, 320, res=True)

@@ -25,7 +25,10 @@ x = torch.randn(N * H * H, C, device="cuda").half()
 w = (torch.randn(C, 9 * C, device="cuda") / (9 * C) ** 0.5).half()
 b = torch.zeros(C, dtype=torch.float16, device="cuda")
 out = torch.empty(N * H * H, C, dtype=torch.float16, device="cuda")
-for _ in range(reps):
-    ops.gemm(x, w, bias=b, mode=ops.MODE_CONV2D, conv=(H, H, H, H, 1, 0), out=out)
+for flags in [int(f) for f in os.environ.get("PMC_GEMM_FLAGS", "0").split(",")]:  # e.g. "0,512": both K orders of the conv gather
+    ops.GEMM_FLAGS = flags
+    for _ in range(reps):
+        ops.gemm(x, w, bias=b, mode=ops.MODE_CONV2D, conv=(H, H, H, H, 1, 0), out=out)
+ops.GEMM_FLAGS = 0
 torch.cuda.synchronize()
 print("done")
