@@ -64,10 +64,21 @@ def measured_traffic(kernel_key):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None, None
+    def readable(name):
+        """rocprofv3 leaves some kernel names mangled: _Z24flash_attn_d64_v2_kernelILi3ELi1ELi8EEv... -> flash_attn_d64_v2_kernel<3, 1, 8>"""
+        import re
+        m = re.match(r"_Z(\d+)", name)
+        if not m:
+            return name
+        n = int(m.group(1))
+        base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+        args = re.findall(r"L([ib])(\d+)E", rest.split("Ev")[0]) if rest.startswith("I") else []
+        return base + ("<" + ", ".join(("true" if v == "1" else "false") if t == "b" else v for t, v in args) + ">" if args else "")
+
     try:
         rec = json.load(open(files[-1]))
         for k, v in rec.get("kernels", {}).items():
-            if kernel_key in k:
+            if kernel_key in readable(k):
                 return int(v["hbm_bytes_per_launch"]), {"file": os.path.relpath(files[-1], ROOT), "commit": rec.get("commit"),
                                                         "kernel": k}
     except Exception:

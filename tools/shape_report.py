@@ -68,7 +68,7 @@ def main():
         return ((f"mode{mode}", f"act{act}", M, N, K, "2src" if a1 is not None else "", "res" if residual is not None else "",
                  "rv" if rowvec is not None else "", str(conv or temporal or "")), 2.0 * M * N * K, nb)
 
-    def gn_key(x0, gamma, beta, stats, rpg, *, x1=None, groups=32, eps=1e-5, silu=False, out=None):
+    def gn_key(x0, gamma, beta, stats, rpg, *, x1=None, groups=32, eps=1e-5, silu=False, out=None, **_kw):
         C = x0.shape[1] + (x1.shape[1] if x1 is not None else 0)
         return ((x0.shape[0], C, rpg, "silu" if silu else "", "2src" if x1 is not None else ""), 0.0, 2 * x0.shape[0] * C * 3)
 
