@@ -53,20 +53,24 @@ def ddim_sampling(config, first_frame, ddim_latents_at_T, pipe: I2VGenXLPipeline
                 generator=g, return_dict=True, ddim_init_latents_t_idx=ddim_init_latents_t_idx).frames[0]
 
 
-def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False):
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False,
+         pipe=None, trajectories=None):
+    """``pipe``: reuse a pipeline that is already built (``run_group_anyv2v``: both stages in one process); ``trajectories``: dict
+    filled with {absolute latents directory: LatentTrajectory} of every inversion run here (the in-HBM hand-off to stage 2)."""
     rank, local_rank, world = init_distributed()
     # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
     # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
     fp_mode = bool(frame_parallel) and world > 1
     writer = rank == 0 or not fp_mode
     e_rank, e_world = (0, 1) if fp_mode else (rank, world)
-    pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
-                                            variant="fp16", random_init_seed=random_init_seed)
-    pipe.to(device)
-    if synthetic_encoders:
-        attach_synthetic_encoders(pipe)
-    if fp_mode:
-        pipe.unet.set_frame_parallel(FrameParallel())
+    if pipe is None:
+        pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
+                                                variant="fp16", random_init_seed=random_init_seed)
+        pipe.to(device)
+        if synthetic_encoders:
+            attach_synthetic_encoders(pipe)
+        if fp_mode:
+            pipe.unet.set_frame_parallel(FrameParallel())
     inverse_scheduler = DDIMInverseScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
     ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
     video_dir = template_config.video_dir
@@ -111,6 +115,8 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         seed_everything(seed_for_entry(template_config.seed, entry_idx) if e_world > 1 else template_config.seed)
         g = torch.Generator().manual_seed(template_config.seed)
         ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, inverse_scheduler, g, write=writer)
+        if trajectories is not None:
+            trajectories[os.path.abspath(str(config.inverse_config.output_dir))] = pipe._last_trajectory
         recon_config = config.recon_config
         if recon_config.enable_recon:
             t_idx = recon_config.ddim_init_latents_t_idx

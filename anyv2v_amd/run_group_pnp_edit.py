@@ -53,20 +53,24 @@ def output_suffix(config, ddim_init_latents_t_idx) -> str:
             + str(config.pnp_temp_attn_t))
 
 
-def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False):
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False,
+         pipe=None, trajectories=None):
+    """``pipe`` / ``trajectories``: see ``run_group_ddim_inversion.main`` -- an entry whose ``ddim_latents_path`` is a key of
+    ``trajectories`` takes the source trajectory from HBM instead of reading the ``ddim_latents_{t}.pt`` files."""
     rank, local_rank, world = init_distributed()
     # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
     # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
     fp_mode = bool(frame_parallel) and world > 1
     writer = rank == 0 or not fp_mode
     e_rank, e_world = (0, 1) if fp_mode else (rank, world)
-    pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
-                                            variant="fp16", random_init_seed=random_init_seed)
-    pipe.to(device)
-    if synthetic_encoders:
-        attach_synthetic_encoders(pipe)
-    if fp_mode:
-        pipe.unet.set_frame_parallel(FrameParallel())
+    if pipe is None:
+        pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
+                                                variant="fp16", random_init_seed=random_init_seed)
+        pipe.to(device)
+        if synthetic_encoders:
+            attach_synthetic_encoders(pipe)
+        if fp_mode:
+            pipe.unet.set_frame_parallel(FrameParallel())
     ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
     all_active = [e for e in configs_list if e["active"] is not False]
     for config_entry in configs_list:
@@ -99,8 +103,9 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         ddim_scheduler.set_timesteps(config.n_steps)
         logger.info(f"ddim_scheduler.timesteps: {ddim_scheduler.timesteps}")
         # read the whole source trajectory once into HBM (the reference re-reads one file per step, :1134)
-        traj = LatentTrajectory.load(config.ddim_latents_path, device=device,
-                                     timesteps=[int(t) for t in ddim_scheduler.timesteps[t_idx:]])
+        handed = (trajectories or {}).get(os.path.abspath(str(config.ddim_latents_path)))
+        traj = handed if handed is not None else LatentTrajectory.load(
+            config.ddim_latents_path, device=device, timesteps=[int(t) for t in ddim_scheduler.timesteps[t_idx:]])
         ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
         seed_everything(seed_for_entry(template_config.seed, entry_idx) if e_world > 1 else template_config.seed)
         random_latents = torch.randn(ddim_latents_at_t.shape, dtype=torch.float32).to(ddim_latents_at_t)  # drawn even if unused (:124)

@@ -196,3 +196,35 @@ def test_sharded_runners_world2_gather_every_entry(tmp_path):
         per_entry.append(lat)
     # the entries really are different jobs (different prompt / schedule / per-entry seed)
     assert all(not torch.equal(per_entry[0], x) for x in per_entry[1:])
+
+
+def test_fused_runner_matches_the_two_stage_run(tmp_path):
+    """``run_group_anyv2v``: stage 1 -> stage 2 in one process (one pipeline, trajectory handed over in HBM)
+    writes the same files with the same contents as the two separate stages, and never reads the ``ddim_latents_{t}.pt`` files
+    back (they are removed before stage 2 could: the hand-off is the in-memory trajectory)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_emulation as emu
+    emu.install()
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    base = _make_workspace(tmp_path)
+    _run_both_stages(base, "two")
+    from anyv2v_amd import run_group_anyv2v as fused, run_group_pnp_edit as s2
+    from anyv2v_amd.utils import LatentTrajectory
+    inv, inv_list, ed, ed_list = _configs(base, "fused")
+    loads = []
+    orig = LatentTrajectory.load
+    LatentTrajectory.load = classmethod(lambda cls, *a, **k: loads.append(a) or orig(*a, **k))
+    try:
+        trajs = fused.main(inv, inv_list, ed, ed_list, torch.device("cpu"), logging.getLogger("e2e"), synthetic_encoders=True)
+    finally:
+        LatentTrajectory.load = orig
+    assert len(trajs) == 1 and not loads          # the edit took the trajectory from memory
+    (inv_a, out_a), (inv_b, out_b) = _outputs(base, "two"), _outputs(base, "fused")
+    fa, fb = sorted(os.listdir(os.path.join(inv_a, "ddim_latents"))), sorted(os.listdir(os.path.join(inv_b, "ddim_latents")))
+    assert fa == fb and len(fa) == N_STEPS
+    for f in fa:
+        assert torch.equal(torch.load(os.path.join(inv_a, "ddim_latents", f)), torch.load(os.path.join(inv_b, "ddim_latents", f))), f
+    assert torch.equal(torch.load(os.path.join(out_a, "edited_latents.pt")), torch.load(os.path.join(out_b, "edited_latents.pt")))
+    assert sorted(os.listdir(out_a)) == sorted(os.listdir(out_b))
