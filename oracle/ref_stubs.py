@@ -192,3 +192,12 @@ def load_reference_consisti2v_models():
             if k.split(".")[0] in ("torchvision", "diffusers", "beartype"):
                 del sys.modules[k]
     return att, blocks, ublocks
+
+
+def load_reference_seine_blocks():
+    """``seine/models/resnet.py`` (``ResnetBlock3D`` / ``Upsample3D`` / ``Downsample3D``: diffusers' ResNet block and samplers with
+    per-frame 2-D convolutions on [b, c, f, h, w]; at f = 1 they ARE ``ResnetBlock2D`` / ``Upsample2D`` / ``Downsample2D``) and
+    ``seine/models/utils.py`` (``timestep_embedding``), verbatim.  Both files import only torch / numpy / einops."""
+    res = _load(os.path.join(REFERENCE_ROOT, "seine", "models", "resnet.py"), "_ref_seine_resnet")
+    utl = _load(os.path.join(REFERENCE_ROOT, "seine", "models", "utils.py"), "_ref_seine_utils")
+    return res, utl

@@ -603,7 +603,8 @@ def check_attention(naive_too=True):
     ref = _sdpa(q, k, v).reshape(B_, HW, h, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B_ * Fr * HW, C)
     out.append(_res("attn[flash] temporal F128 (frame stride)", o, ref, KTOL))
     # every KV-loop length 1 .. 7 tiles with ragged last tiles, shared K/V (kv_div), Q/K aliasing on the plain kernel
-    for (b, h, S, Sk, kv_div, qk_mod) in [(2, 1, 128, 64, 1, 0), (2, 2, 128, 128, 1, 0), (4, 1, 256, 145, 2, 0),
+    for (b, h, S, Sk, kv_div, qk_mod) in [(2, 1, 20, 3, 1, 0), (2, 2, 130, 17, 1, 0), (1, 1, 33, 63, 1, 0),  # tiny ragged KV: whole steps masked
+                                           (2, 1, 128, 64, 1, 0), (2, 2, 128, 128, 1, 0), (4, 1, 256, 145, 2, 0),
                                            (1, 2, 128, 200, 1, 0), (2, 1, 128, 320, 1, 0), (1, 1, 256, 384, 1, 0),
                                            (4, 2, 128, 448, 1, 2), (1, 5, 4096, 4096, 1, 0)]:
         C = 64 * h

@@ -279,3 +279,37 @@ def test_oracle_temporal_conv_layout_vs_reference_conv3dlayer():
     for r in refs:
         want = r(want)
     torch.testing.assert_close(mine(x, Fr), x + want, rtol=1e-5, atol=1e-5)
+
+
+@_needs_ref
+def test_oracle_resnet_samplers_and_timestep_embedding_vs_reference_seine_blocks():
+    """``seine/models/resnet.py:113-206`` (``ResnetBlock3D`` -- "adapted from diffusers resnet.py": norm1 -> SiLU -> conv1 ->
+    + time_emb_proj(SiLU(temb)) -> norm2 -> SiLU -> dropout -> conv2 -> 1x1 shortcut when the width changes -> (x + h) / scale),
+    ``:24-110`` (``Upsample3D``: nearest x2 + 3x3 conv; ``Downsample3D``: 3x3 stride-2 pad-1 conv) at ONE frame, where the per-frame
+    convolutions and the 5-D GroupNorm coincide with the 2-D blocks, vs the oracle's ResnetBlock2D / Upsample2D / Downsample2D on
+    shared weights; ``seine/models/utils.py:74-94`` (``timestep_embedding``: [cos | sin], exp(-ln(10000) i / half)) vs the oracle's."""
+    from oracle import unet_oracle as uo
+    res, utl = ref_stubs.load_reference_seine_blocks()
+    torch.manual_seed(3)
+    for cin, cout in ((64, 64), (64, 128)):
+        ref = res.ResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=96, groups=32, eps=1e-5)
+        mine = uo.ResnetBlock2D(cin, cout, 96, 32, eps=1e-5)
+        with torch.no_grad():
+            for p_ in ref.parameters():
+                p_.normal_(0, 0.1)
+        _copy_params(mine, ref)
+        x, temb = torch.randn(3, cin, 9, 7), torch.randn(3, 96)
+        torch.testing.assert_close(mine(x, temb), ref(x[:, :, None], temb)[:, :, 0], rtol=1e-5, atol=2e-5)
+    up_r, up_m = res.Upsample3D(64, use_conv=True), uo.Upsample2D(64)
+    dn_r, dn_m = res.Downsample3D(64, use_conv=True), uo.Downsample2D(64)
+    with torch.no_grad():
+        for p_ in list(up_r.parameters()) + list(dn_r.parameters()):
+            p_.normal_(0, 0.1)
+    up_m.conv.load_state_dict(up_r.conv.state_dict())
+    dn_m.conv.load_state_dict(dn_r.conv.state_dict())
+    x = torch.randn(2, 64, 6, 10)
+    torch.testing.assert_close(up_m(x), up_r(x[:, :, None])[:, :, 0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dn_m(x), dn_r(x[:, :, None])[:, :, 0], rtol=1e-5, atol=1e-5)
+    t = torch.tensor([1.0, 21.0, 501.0, 981.0])
+    for dim in (320, 1280):
+        torch.testing.assert_close(uo.timestep_embedding(t, dim), utl.timestep_embedding(t, dim), rtol=1e-6, atol=1e-6)
