@@ -135,7 +135,7 @@ def load_reference_pipeline_module():
 
 # ----------------------------------------------------------------------------------------------- toy components
 class ToyTokenizer:
-    model_max_length = 16
+    model_max_length = 77  # CLIP's: the UNet context is 77 text + 64 image-latent + 4 image-embedding tokens = 145
 
     def __call__(self, prompts, padding=None, max_length=None, truncation=None, return_tensors=None):
         prompts = [prompts] if isinstance(prompts, str) else list(prompts)
@@ -160,7 +160,7 @@ class ToyTextEncoder(nn.Module):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
         self.emb = nn.Embedding(100, dim)
-        self.pos = nn.Parameter(torch.randn(16, dim, generator=g) * 0.1)
+        self.pos = nn.Parameter(torch.randn(77, dim, generator=g) * 0.1)
         self.l1, self.l2 = nn.Linear(dim, dim), nn.Linear(dim, dim)
         self.text_model = types.SimpleNamespace(final_layer_norm=nn.LayerNorm(dim))
         self._ln = self.text_model.final_layer_norm
@@ -256,3 +256,73 @@ def build_reference_pipeline(unet_oracle, dim, vae_noise_std=0.0):
                                image_encoder=ToyImageEncoder(dim), feature_extractor=ToyFeatureExtractor(), unet=unet_oracle,
                                scheduler=ForwardDDIM())
     return pipe, pm, pnp
+
+
+INV_CFG = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="squaredcos_cap_v2", clip_sample=False,
+               set_alpha_to_one=True, steps_offset=1, prediction_type="v_prediction", timestep_spacing="leading",
+               rescale_betas_zero_snr=True)  # i2vgen-xl/demo.ipynb:1208-1226
+
+
+@torch.no_grad()
+def run_reference_job(oracle_unet, dim, frames, edited, size, n_steps, ratios, work_dir, neg="blurry", edit_prompt="a robot",
+                      with_reconstruction=True):
+    """Stage 1 and stage 2 of the reference on ONE clip, driven exactly as its two runners drive the pipeline
+    (``run_group_ddim_inversion.py:29-77``, ``run_group_pnp_edit.py:35-47,107-140``): ``encode_vae_video`` -> ``invert`` (cfg 1,
+    empty prompt, fps 8, files written to ``work_dir``) -> [``__call__`` CFG reconstruction from the noisiest latent] -> the
+    reference's ``register_*`` hooks with ``int(n_steps * ratio)``-long schedule prefixes -> ``sample_with_pnp`` (cfg 9, t_idx 0).
+    Returns everything a comparison needs: the conditioning tensors the reference's glue code built, the trajectory it wrote, the
+    edited / reconstructed latents.  ``oracle_unet`` is left with the reference hooks installed (pass a copy)."""
+    import copy
+    import warnings
+    Fr = len(frames)
+    dev = torch.device("cpu")
+    plain = copy.deepcopy(oracle_unet) if with_reconstruction else None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, pm, ref_pnp = build_reference_pipeline(oracle_unet, dim)
+        inv_mod = ref_stubs.load_reference_inverse_scheduler()
+    ref.scheduler = inv_mod.DDIMInverseScheduler(**INV_CFG)
+    lat0 = ref.encode_vae_video(frames, device=dev, height=size, width=size)
+    out_dir = os.path.join(str(work_dir), "ddim_latents")
+    inverted = ref.invert(prompt="", image=frames[0], height=size, width=size, num_frames=Fr, num_inference_steps=n_steps,
+                          guidance_scale=1.0, negative_prompt=neg, target_fps=8, latents=lat0,
+                          generator=torch.Generator().manual_seed(8888), return_dict=False, output_dir=out_dir)
+    inv_ts = [int(t) for t in ref.scheduler.timesteps]
+    files = {t: torch.load(os.path.join(out_dir, f"ddim_latents_{t}.pt")) for t in inv_ts}
+    ref._guidance_scale = 1.0
+    src_pe, _ = ref.encode_prompt("", dev, 1, None, clip_skip=1)
+    crop = lambda im: pm._resize_bilinear(pm._center_crop_wide(im, (size, size)), (224, 224))
+    prep = lambda im: ref.image_processor.preprocess(pm._center_crop_wide(im, (size, size)))
+    src_ie = ref._encode_image(crop(frames[0]), dev, 1)
+    src_il = ref.prepare_image_latents(prep(frames[0]), device=dev, num_frames=Fr, num_videos_per_prompt=1)
+    fwd = ForwardDDIM()
+    fwd.set_timesteps(n_steps)
+    ts = fwd.timesteps
+    T = int(ts[0])
+    out = dict(lat0=lat0, inv_ts=inv_ts, files=files, inverted=inverted, src_pe=src_pe, src_ie=src_ie, src_il=src_il, T=T,
+               out_dir=out_dir, ratios=tuple(ratios), n_steps=n_steps, neg=neg)
+    if with_reconstruction:  # the reference reconstructs before any hook exists (stage 1): a hook-free pipeline
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref2, _, _ = build_reference_pipeline(plain, dim)
+        ref2.scheduler = ForwardDDIM()
+        out["rec_ref"] = ref2(prompt="", image=frames[0], height=size, width=size, num_frames=Fr, num_inference_steps=n_steps,
+                              guidance_scale=9.0, negative_prompt=neg, target_fps=8, latents=files[T].clone(),
+                              generator=torch.Generator().manual_seed(8888), return_dict=True, ddim_init_latents_t_idx=0,
+                              output_type="latent").frames
+        ref2._guidance_scale = 9.0
+        out["rec_pe"], out["rec_npe"] = ref2.encode_prompt("", dev, 1, neg, clip_skip=1)
+    ref.scheduler = fwd
+    ref_pnp.register_conv_injection(ref, ts[: int(n_steps * ratios[0])])
+    ref_pnp.register_spatial_attention_pnp(ref, ts[: int(n_steps * ratios[1])])
+    ref_pnp.register_temp_attention_pnp(ref, ts[: int(n_steps * ratios[2])])
+    out["edit_ref"] = ref.sample_with_pnp(
+        prompt=edit_prompt, image=edited, height=size, width=size, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=9.0,
+        negative_prompt=neg, target_fps=8, latents=files[T].clone(), generator=torch.Generator().manual_seed(8888), return_dict=True,
+        ddim_init_latents_t_idx=0, ddim_inv_latents_path=out_dir, ddim_inv_prompt="", ddim_inv_1st_frame=frames[0],
+        output_type="latent").frames
+    ref._guidance_scale = 9.0
+    out["pe"], out["npe"] = ref.encode_prompt(edit_prompt, dev, 1, neg, clip_skip=1)
+    out["ie2"] = ref._encode_image(crop(edited), dev, 1)                                                # [zeros, positive]
+    out["il2"] = ref.prepare_image_latents(prep(edited), device=dev, num_frames=Fr, num_videos_per_prompt=1)  # [edited, edited]
+    return out

@@ -11,6 +11,11 @@
 2. ``inverse_scheduler.pt``: the reference's vendored ``consisti2v/ddim_inverse_scheduler.py``
    constructed with the config logged at ``i2vgen-xl/demo.ipynb:1208-1226``: alphas_cumprod table,
    timesteps for n=50/500, and inverse steps on seeded tensors.
+3. ``ref_pipeline_mini.pt`` (``--pipeline``) / ``ref_pipeline_full_config1.pt`` (``--pipeline-full``, ~3 min of CPU): the
+   reference's OWN PIPELINE CLASS (``i2vgen-xl/pipelines/pipeline_i2vgen_xl.py`` verbatim via ``oracle.ref_pipeline``) runs
+   inversion -> CFG reconstruction -> PnP edit of one synthetic clip around the oracle UNet (fp32, CPU), the reference's
+   vendored inverse scheduler and toy VAE / CLIP components: the conditioning tensors its glue code built, the trajectory it
+   wrote, the reconstructed and the edited latents.  The -m gpu suite runs the HIP pipeline on the same inputs against it.
 """
 import os
 import sys
@@ -116,9 +121,64 @@ def gen_scheduler():
     print("timesteps_50[:5] =", out["timesteps_50"][:5].tolist(), " timesteps_500[-3:] =", out["timesteps_500"][-3:].tolist())
 
 
+# one synthetic clip per job: mini UNet (4 f x 64^2, 4 steps, schedules 0.25 / 0.5 / 0.75) and the full-width UNet at BASELINE
+# config 1's size (8 f x 256^2; 3 steps, schedules 0.34 / 0.67 / 1.0 -> 1 / 2 / 3 steps)
+REF_PIPELINE_JOBS = {
+    "mini": dict(cfg="mini", seed=4321, frames=4, size=64, n_steps=4, ratios=(0.25, 0.5, 0.75), file="ref_pipeline_mini.pt"),
+    "full": dict(cfg="full", seed=1234, frames=8, size=256, n_steps=3, ratios=(0.34, 0.67, 1.0), file="ref_pipeline_full_config1.pt"),
+}
+
+
+def ref_pipeline_frames(spec):
+    """Smooth synthetic frames (a drifting gradient + texture) and an 'edited' first frame, as PIL images."""
+    import numpy as np
+    from PIL import Image
+    n, size = spec["frames"], spec["size"]
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    rng = np.random.RandomState(spec["seed"])
+    tex = rng.rand(size, size, 3).astype(np.float32)
+    frames = []
+    for i in range(n):
+        ph = i / max(n - 1, 1)
+        img = np.stack([0.5 + 0.5 * np.sin(6.3 * (xx + ph)), yy, 0.5 + 0.5 * np.cos(6.3 * (xx * yy + ph))], -1)
+        frames.append(Image.fromarray((255 * (0.8 * img + 0.2 * tex)).clip(0, 255).astype("uint8")))
+    ed = np.stack([yy, 0.5 + 0.5 * np.sin(9.0 * xx), xx], -1)
+    edited = Image.fromarray((255 * (0.8 * ed + 0.2 * tex[::-1])).clip(0, 255).astype("uint8"))
+    return frames, edited
+
+
+def pack_ref_pipeline_job(spec, job):
+    """What the GPU box needs of a reference-pipeline job (fp16 tensors; the trajectory stacked in inversion order)."""
+    h = lambda x: x.detach().to(torch.float16).contiguous()
+    return dict(spec={k: v for k, v in spec.items()}, inv_ts=list(job["inv_ts"]), T=job["T"], lat0=h(job["lat0"]),
+                trajectory=h(torch.stack([job["files"][t] for t in job["inv_ts"]])), src_pe=h(job["src_pe"]), src_ie=h(job["src_ie"]),
+                src_il=h(job["src_il"]), pe=h(job["pe"]), npe=h(job["npe"]), ie_pos=h(job["ie2"][1:]), il_edit=h(job["il2"][1:]),
+                rec_pe=h(job["rec_pe"]), rec_npe=h(job["rec_npe"]), edit_ref=h(job["edit_ref"]), rec_ref=h(job["rec_ref"]))
+
+
+def gen_ref_pipeline(name):
+    import tempfile
+    from oracle import ref_pipeline
+    spec = REF_PIPELINE_JOBS[name]
+    cfg = UNetConfig.mini() if spec["cfg"] == "mini" else UNetConfig.i2vgen_xl()
+    unet = build_oracle(cfg, random_state_dict(cfg, spec["seed"]), dtype=torch.float32)
+    frames, edited = ref_pipeline_frames(spec)
+    with tempfile.TemporaryDirectory() as tmp:
+        job = ref_pipeline.run_reference_job(unet, cfg.cross_attention_dim, frames, edited, spec["size"], spec["n_steps"],
+                                             spec["ratios"], tmp)
+    fx = pack_ref_pipeline_job(spec, job)
+    torch.save(fx, os.path.join(HERE, spec["file"]))
+    print(spec["file"], {k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in fx.items() if k != "spec"})
+    print("  |edit_ref| max", float(fx["edit_ref"].float().abs().max()), " inv_ts", fx["inv_ts"])
+
+
 if __name__ == "__main__":
     assert ref_stubs.reference_available(), "needs /root/reference"
-    if "--full" in sys.argv:
+    if "--pipeline" in sys.argv:
+        gen_ref_pipeline("mini")
+    elif "--pipeline-full" in sys.argv:
+        gen_ref_pipeline("full")
+    elif "--full" in sys.argv:
         gen_hooks_full()
     else:
         gen_hooks()

@@ -1364,6 +1364,77 @@ def check_n1_drift(cfg_name="full", Fr=16, hw=64, n_steps=50, every=10, report=N
     return out
 
 
+def check_pipeline_vs_reference_fixture(name="mini"):
+    """The product pipeline (HIP kernels + HIP graphs on the GPU; op emulation in the CPU suite) vs a fixture produced by the
+    REFERENCE'S OWN PIPELINE CLASS on the CPU in fp32 (``tests/golden/make_golden.py --pipeline[-full]``: pipeline_i2vgen_xl.py
+    verbatim around the oracle UNet): n-step inversion (every trajectory latent), CFG reconstruction and PnP edit from the
+    reference's noisiest latent, on the conditioning tensors the reference's glue code built.  On the GPU every bound is 2 x the
+    error of the same oracle model run through the oracle loops in eager fp16 on this GPU; on the CPU emulation a fixed bound."""
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    from oracle import pnp_oracle
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "ref_pipeline_mini.pt" if name == "mini" else "ref_pipeline_full_config1.pt"))
+    sp = fx["spec"]
+    calibrate = DEV != "cpu"
+    m = full_models(sp["cfg"], sp["seed"], want=("native",) + (("o16",) if calibrate else ()))
+    native, o16 = m["native"], m.get("o16")
+    n_steps, size, Fr, ratios = sp["n_steps"], sp["size"], sp["frames"], sp["ratios"]
+    g = lambda x: x.to(DEV)
+    inv_ts, T = fx["inv_ts"], fx["T"]
+    traj_ref = {t: fx["trajectory"][i] for i, t in enumerate(inv_ts)}
+    pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+    pipe._device = torch.device(DEV)
+    traj = pipe.invert(prompt_embeds=g(fx["src_pe"]), image_embeddings=g(fx["src_ie"]), image_latents=g(fx["src_il"]), height=size,
+                       width=size, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0, target_fps=8, latents=g(fx["lat0"]),
+                       return_trajectory=True)
+    sched = DDIMScheduler()
+    sched.set_timesteps(n_steps)
+    pipe.register_modules(scheduler=sched)
+    start = g(traj_ref[T])  # both sampling runs start from the REFERENCE's noisiest latent, as its own stage 2 does
+    rec = pipe(prompt_embeds=g(fx["rec_pe"]), negative_prompt_embeds=g(fx["rec_npe"]), image_embeddings=g(fx["src_ie"]),
+               image_latents=g(fx["src_il"]), height=size, width=size, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=9.0,
+               target_fps=8, latents=start.clone(), output_type="latent", ddim_init_latents_t_idx=0).frames
+    k = lambda r: sched.timesteps[: int(n_steps * r)]
+    pnp_utils.register_conv_injection(pipe, k(ratios[0]))
+    pnp_utils.register_spatial_attention_pnp(pipe, k(ratios[1]))
+    pnp_utils.register_temp_attention_pnp(pipe, k(ratios[2]))
+    from anyv2v_amd.utils import LatentTrajectory
+    src = LatentTrajectory()
+    for t in inv_ts:
+        src[t] = g(traj_ref[t])
+    ed = pipe.sample_with_pnp(prompt_embeds=g(fx["pe"]), negative_prompt_embeds=g(fx["npe"]), image_embeddings=g(fx["ie_pos"]),
+                              image_latents=g(fx["il_edit"]), height=size, width=size, num_frames=Fr, num_inference_steps=n_steps,
+                              guidance_scale=9.0, target_fps=8, latents=start.clone(), output_type="latent",
+                              ddim_init_latents_t_idx=0, ddim_inv_latents_path=src, ddim_inv_prompt_embeds=g(fx["src_pe"]),
+                              ddim_inv_image_embeddings=g(fx["src_ie"]), ddim_inv_image_latents=g(fx["src_il"])).frames
+    pnp_utils.clear_time(pipe)
+    tag = f"{name} [{Fr}f x {size}^2, {n_steps} steps]"
+    rows = [(f"{tag} pipe.invert vs the reference pipeline's trajectory, t={t}", traj[t], traj_ref[t]) for t in inv_ts]
+    rows += [(f"{tag} pipe.__call__ (CFG reconstruction) vs the reference pipeline", rec, fx["rec_ref"]),
+             (f"{tag} pipe.sample_with_pnp vs the reference pipeline", ed, fx["edit_ref"])]
+    if not calibrate:
+        return [_res(n_, a, b.float(), 5e-2) for n_, a, b in rows]
+    # eager-fp16 calibration: the same oracle model through the oracle loops on this GPU, same inputs
+    d = lambda x: x.to(DEV, torch.float16)
+    with torch.no_grad():
+        c1 = dict(fps=torch.tensor([8], device=DEV), image_latents=d(fx["src_il"]), image_embeddings=d(fx["src_ie"]),
+                  encoder_hidden_states=d(fx["src_pe"]))
+        t16 = pnp_oracle.invert_loop(o16, d(fx["lat0"]), c1, n_steps)
+        c2 = dict(fps=torch.tensor([8, 8], device=DEV), image_latents=d(torch.cat([fx["src_il"]] * 2)),
+                  image_embeddings=d(torch.cat([torch.zeros_like(fx["src_ie"]), fx["src_ie"]])),
+                  encoder_hidden_states=d(torch.cat([fx["rec_npe"], fx["rec_pe"]])))
+        r16 = pnp_oracle.sample_loop(o16, d(traj_ref[T]).clone(), c2, n_steps, 9.0, t_idx=0)
+        c3 = dict(fps=torch.tensor([8, 8, 8], device=DEV), image_latents=d(torch.cat([fx["src_il"], fx["il_edit"], fx["il_edit"]])),
+                  image_embeddings=d(torch.cat([fx["src_ie"], torch.zeros_like(fx["ie_pos"]), fx["ie_pos"]])),
+                  encoder_hidden_states=d(torch.cat([fx["src_pe"], fx["npe"], fx["pe"]])))
+        pnp_oracle.init_pnp(o16, n_steps, *ratios)
+        e16 = pnp_oracle.pnp_loop(o16, d(traj_ref[T]).clone(), {t: d(v) for t, v in traj_ref.items()}, c3, n_steps, 9.0, t_idx=0)
+        pnp_oracle.clear_hooks(o16)
+    eager = [t16[t] for t in inv_ts] + [r16, e16]
+    return [_calibrated(n_, a, b, e_, floor=1e-3) for (n_, a, b), e_ in zip(rows, eager)]
+
+
 def check_full_size_properties():
     """BASELINE config 3 sizes (T = 196608 tokens, N = 48 images, S = 4096), where the CPU oracle is far too slow:
     size-independent identities of each kernel family."""

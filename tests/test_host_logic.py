@@ -426,128 +426,58 @@ def test_pnp_without_cfg_is_refused(cpu_ops):
 
 
 # ---- the REFERENCE's own pipeline class, imported verbatim, runs stage 1 and stage 2 on the CPU ------------------------------
-INV_CFG = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="squaredcos_cap_v2", clip_sample=False,
-               set_alpha_to_one=True, steps_offset=1, prediction_type="v_prediction", timestep_spacing="leading",
-               rescale_betas_zero_snr=True)  # i2vgen-xl/demo.ipynb:1208-1226
-
-
 def test_reference_pipeline_code_vs_loop_oracle_vs_native_pipeline(cpu_ops, tmp_path):
     """A1 / A2 / A3 / A12 pinned to the reference's code: ``/root/reference/i2vgen-xl/pipelines/pipeline_i2vgen_xl.py`` (verbatim,
     via ``oracle.ref_pipeline``; its ``invert`` :1197-1451, ``sample_with_pnp`` :892-1193 and ``__call__`` :652-888 loops, its
     ``encode_prompt`` / ``_encode_image`` / ``prepare_image_latents`` / ``encode_vae_video`` glue, its ``pnp_utils.py`` hooks and
-    ``utils.load_ddim_latents_at_t``) runs 4-step inversion -> PnP edit -> CFG reconstruction of a 4-frame 64x64 clip around the
+    ``utils.load_ddim_latents_at_t``) runs 4-step inversion -> CFG reconstruction -> PnP edit of a 4-frame 64x64 clip around the
     oracle UNet, the reference's vendored inverse scheduler and toy VAE / CLIP components.  Compared with (a) ``oracle.pnp_oracle``'s
     loops on the same conditioning tensors -- the loop oracle the GPU tests use -- and (b) the native pipeline on the same weights
-    (op emulation, fp16): trajectory files, edited latents, reconstructed latents."""
+    (op emulation, fp16): trajectory files, edited latents, reconstructed latents.  (c) The committed fixture
+    ``tests/golden/ref_pipeline_mini.pt`` is what this produces (the -m gpu suite compares the HIP path with it)."""
     from oracle import ref_stubs
     if not ref_stubs.reference_available():
         pytest.skip("needs /root/reference")
     import copy
-    import warnings
-    from PIL import Image
-
-    from anyv2v_amd import pnp_utils
-    from anyv2v_amd.pipeline import I2VGenXLPipeline
-    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    import sys
     from oracle import pnp_oracle, ref_pipeline
-    n_steps, Fr, size = 4, 4, 64
-    native, oracle, ocfg = gc.build_pair("mini", 4321)
-    oracle_plain = copy.deepcopy(oracle)  # for the loop oracle: the reference hooks below replace forwards / processors in place
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        ref, pm, ref_pnp = ref_pipeline.build_reference_pipeline(oracle, ocfg.cross_attention_dim)
-        inv_mod = ref_stubs.load_reference_inverse_scheduler()
-    rng = np.random.RandomState(3)
-    frames = [Image.fromarray((rng.rand(size, size, 3) * 255).astype("uint8")) for _ in range(Fr)]
-    edited = Image.fromarray((rng.rand(size, size, 3) * 255).astype("uint8"))
-    dev = torch.device("cpu")
-    neg = "blurry"
+    sys.path.insert(0, os.path.join(gc.ROOT, "tests", "golden"))
+    import make_golden
+    spec = make_golden.REF_PIPELINE_JOBS["mini"]
+    _, oracle, ocfg = gc.build_pair("mini", spec["seed"])
+    oracle_plain = copy.deepcopy(oracle)  # for the loop oracle: the reference hooks replace forwards / processors in place
+    frames, edited = make_golden.ref_pipeline_frames(spec)
+    n_steps, size, ratios = spec["n_steps"], spec["size"], spec["ratios"]
+    job = ref_pipeline.run_reference_job(oracle, ocfg.cross_attention_dim, frames, edited, size, n_steps, ratios, tmp_path)
+    files, inv_ts, T = job["files"], job["inv_ts"], job["T"]
+    assert torch.equal(job["inverted"][0, 0], files[inv_ts[-1]][0])  # reversed stack: index 0 = the noisiest latent (:1436)
     with torch.no_grad():
-        # ---- stage 1 exactly as run_group_ddim_inversion.py:29-55 drives it
-        ref.scheduler = inv_mod.DDIMInverseScheduler(**INV_CFG)
-        lat0 = ref.encode_vae_video(frames, device=dev, height=size, width=size)
-        out_dir = str(tmp_path / "ddim_latents")
-        inverted = ref.invert(prompt="", image=frames[0], height=size, width=size, num_frames=Fr, num_inference_steps=n_steps,
-                              guidance_scale=1.0, negative_prompt=neg, target_fps=8, latents=lat0,
-                              generator=torch.Generator().manual_seed(8888), return_dict=False, output_dir=out_dir)
-        inv_ts = [int(t) for t in ref.scheduler.timesteps]
-        files = {t: torch.load(os.path.join(out_dir, f"ddim_latents_{t}.pt")) for t in inv_ts}
-        assert torch.equal(inverted[0, 0], files[inv_ts[-1]][0])  # reversed stack: index 0 = the noisiest latent (:1436)
-        # the conditioning tensors the reference built (its own glue code), for the loop oracle and the native pipeline
-        ref._guidance_scale = 1.0
-        src_pe, _ = ref.encode_prompt("", dev, 1, None, clip_skip=1)
-        crop = pm._resize_bilinear(pm._center_crop_wide(frames[0], (size, size)), (224, 224))
-        src_ie = ref._encode_image(crop, dev, 1)
-        src_il = ref.prepare_image_latents(ref.image_processor.preprocess(pm._center_crop_wide(frames[0], (size, size))), device=dev,
-                                           num_frames=Fr, num_videos_per_prompt=1)
-        cond_src = dict(fps=torch.tensor([8]), image_latents=src_il, image_embeddings=src_ie, encoder_hidden_states=src_pe)
-        traj_o = pnp_oracle.invert_loop(oracle_plain, lat0.clone(), cond_src, n_steps)
+        cond_src = dict(fps=torch.tensor([8]), image_latents=job["src_il"], image_embeddings=job["src_ie"],
+                        encoder_hidden_states=job["src_pe"])
+        traj_o = pnp_oracle.invert_loop(oracle_plain, job["lat0"].clone(), cond_src, n_steps)
         for t in inv_ts:
             assert (traj_o[t] - files[t]).abs().max() <= 2e-4 * files[t].abs().max(), f"loop oracle vs reference invert at t={t}"
-        # ---- stage 2 as run_group_pnp_edit.py:35-47,107-140 drives it (schedules 0.25 / 0.5 / 0.75 of the full list, t_idx 0)
-        fwd = ref_pipeline.ForwardDDIM()
-        fwd.set_timesteps(n_steps)
-        ts = fwd.timesteps
-        ref.scheduler = fwd
-        ref_pnp.register_conv_injection(ref, ts[:1])
-        ref_pnp.register_spatial_attention_pnp(ref, ts[:2])
-        ref_pnp.register_temp_attention_pnp(ref, ts[:3])
-        T = int(ts[0])
-        edit_ref = ref.sample_with_pnp(prompt="a robot", image=edited, height=size, width=size, num_frames=Fr,
-                                       num_inference_steps=n_steps, guidance_scale=9.0, negative_prompt=neg, target_fps=8,
-                                       latents=files[T].clone(), generator=torch.Generator().manual_seed(8888), return_dict=True,
-                                       ddim_init_latents_t_idx=0, ddim_inv_latents_path=out_dir, ddim_inv_prompt="",
-                                       ddim_inv_1st_frame=frames[0], output_type="latent").frames
-        # edit-branch conditioning from the reference's glue (CFG on: [negative, positive] pairs)
-        ref._guidance_scale = 9.0
-        pe, npe = ref.encode_prompt("a robot", dev, 1, neg, clip_skip=1)
-        crop = pm._resize_bilinear(pm._center_crop_wide(edited, (size, size)), (224, 224))
-        ie2 = ref._encode_image(crop, dev, 1)                                    # [zeros, positive]
-        il2 = ref.prepare_image_latents(ref.image_processor.preprocess(pm._center_crop_wide(edited, (size, size))), device=dev,
-                                        num_frames=Fr, num_videos_per_prompt=1)  # [edited, edited]
-        cond_all = dict(fps=torch.tensor([8, 8, 8]), image_latents=torch.cat([src_il, il2]),
-                        image_embeddings=torch.cat([src_ie, ie2]), encoder_hidden_states=torch.cat([src_pe, npe, pe]))
-        pnp_oracle.init_pnp(oracle_plain, n_steps, 0.25, 0.5, 0.75)
+        cond2 = dict(fps=torch.tensor([8, 8]), image_latents=torch.cat([job["src_il"], job["src_il"]]),
+                     image_embeddings=torch.cat([torch.zeros_like(job["src_ie"]), job["src_ie"]]),
+                     encoder_hidden_states=torch.cat([job["rec_npe"], job["rec_pe"]]))
+        rec_o = pnp_oracle.sample_loop(oracle_plain, files[T].clone(), cond2, n_steps, 9.0, t_idx=0)
+        assert (rec_o - job["rec_ref"]).abs().max() <= 5e-4 * job["rec_ref"].abs().max(), "loop oracle vs reference __call__"
+        cond_all = dict(fps=torch.tensor([8, 8, 8]), image_latents=torch.cat([job["src_il"], job["il2"]]),
+                        image_embeddings=torch.cat([job["src_ie"], job["ie2"]]),
+                        encoder_hidden_states=torch.cat([job["src_pe"], job["npe"], job["pe"]]))
+        plain_o = pnp_oracle.pnp_loop(oracle_plain, files[T].clone(), files, cond_all, n_steps, 9.0, t_idx=0)  # no hooks yet
+        pnp_oracle.init_pnp(oracle_plain, n_steps, *ratios)
         edit_o = pnp_oracle.pnp_loop(oracle_plain, files[T].clone(), files, cond_all, n_steps, 9.0, t_idx=0)
         pnp_oracle.clear_hooks(oracle_plain)
+        edit_ref = job["edit_ref"]
         assert (edit_o - edit_ref).abs().max() <= 5e-4 * edit_ref.abs().max(), "loop oracle vs reference sample_with_pnp"
-        # not vacuous: the edit moved away from its start, and the hooks mattered (same loop without injection differs)
+        # not vacuous: the edit moved away from its start, and the hooks mattered
         assert (edit_ref - files[T]).abs().max() > 0.5 * files[T].abs().max()
-        plain_o = pnp_oracle.pnp_loop(oracle_plain, files[T].clone(), files, cond_all, n_steps, 9.0, t_idx=0)
         assert (plain_o - edit_ref).abs().max() > 20 * (edit_o - edit_ref).abs().max()
-        # ---- plain CFG reconstruction through the reference's __call__ (hooks registered but t outside: register_time never ran
-        #      with these t's schedules cleared) -- reference stage 1 does this before any hook exists: use a fresh pipeline
-        ref2, _, _ = ref_pipeline.build_reference_pipeline(copy.deepcopy(oracle_plain), ocfg.cross_attention_dim)
-        ref2.scheduler = ref_pipeline.ForwardDDIM()
-        rec_ref = ref2(prompt="", image=frames[0], height=size, width=size, num_frames=Fr, num_inference_steps=n_steps,
-                       guidance_scale=9.0, negative_prompt=neg, target_fps=8, latents=files[T].clone(),
-                       generator=torch.Generator().manual_seed(8888), return_dict=True, ddim_init_latents_t_idx=0,
-                       output_type="latent").frames
-        ref2._guidance_scale = 9.0
-        pe0, npe0 = ref2.encode_prompt("", dev, 1, neg, clip_skip=1)
-        cond2 = dict(fps=torch.tensor([8, 8]), image_latents=torch.cat([src_il, src_il]),
-                     image_embeddings=torch.cat([torch.zeros_like(src_ie), src_ie]), encoder_hidden_states=torch.cat([npe0, pe0]))
-        rec_o = pnp_oracle.sample_loop(oracle_plain, files[T].clone(), cond2, n_steps, 9.0, t_idx=0)
-        assert (rec_o - rec_ref).abs().max() <= 5e-4 * rec_ref.abs().max(), "loop oracle vs reference __call__"
-    # ---- (b) the native pipeline (fp16, emulated ops) on the same weights and the reference-built conditioning
-    h = lambda x: x.half()
-    pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
-    pipe._device = dev
-    traj_n = pipe.invert(prompt_embeds=h(src_pe), image_embeddings=h(src_ie), image_latents=h(src_il), height=size, width=size,
-                         num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0, target_fps=8, latents=h(lat0),
-                         return_trajectory=True)
-    for t in inv_ts:
-        assert (traj_n[t].float() - files[t]).abs().max() <= 2e-2 * files[t].abs().max(), f"native invert vs reference at t={t}"
-    sched = DDIMScheduler()
-    sched.set_timesteps(n_steps)
-    pipe.register_modules(scheduler=sched)
-    pnp_utils.register_conv_injection(pipe, sched.timesteps[:1])
-    pnp_utils.register_spatial_attention_pnp(pipe, sched.timesteps[:2])
-    pnp_utils.register_temp_attention_pnp(pipe, sched.timesteps[:3])
-    edit_n = pipe.sample_with_pnp(prompt_embeds=h(pe), negative_prompt_embeds=h(npe), image_embeddings=h(ie2[1:]),
-                                  image_latents=h(il2[1:]), height=size, width=size, num_frames=Fr, num_inference_steps=n_steps,
-                                  guidance_scale=9.0, target_fps=8, latents=h(files[T]), output_type="latent",
-                                  ddim_init_latents_t_idx=0, ddim_inv_latents_path=out_dir, ddim_inv_prompt_embeds=h(src_pe),
-                                  ddim_inv_image_embeddings=h(src_ie), ddim_inv_image_latents=h(src_il)).frames
-    pnp_utils.clear_time(pipe)
-    assert (edit_n.float() - edit_ref).abs().max() <= 5e-2 * edit_ref.abs().max(), "native sample_with_pnp vs reference"
+    # (c) the committed fixture is this job
+    fx = make_golden.pack_ref_pipeline_job(spec, job)
+    gold = torch.load(os.path.join(gc.ROOT, "tests", "golden", "ref_pipeline_mini.pt"))
+    for k in ("trajectory", "edit_ref", "rec_ref", "src_pe", "il_edit"):
+        assert (fx[k].float() - gold[k].float()).abs().max() <= 2e-3 * gold[k].float().abs().max().clamp_min(1e-6), k
+    # (b) the native pipeline (fp16, emulated ops) against the reference-generated fixture -- the same check the GPU suite runs
+    _ok(gc.check_pipeline_vs_reference_fixture("mini"))
