@@ -152,6 +152,18 @@ class ToyTokenizer:
         return ["?"] * len(ids)
 
 
+class _TextOut(tuple):
+    """tuple-style AND attribute-style access, like a transformers ModelOutput (the reference indexes, adapters use attributes)."""
+
+    @property
+    def hidden_states(self):
+        return self[-1]
+
+    @property
+    def last_hidden_state(self):
+        return self[0]
+
+
 class ToyTextEncoder(nn.Module):
     """``CLIPTextModel``'s calling convention: ``enc(ids)[0]`` = final-LayerNorm'ed last hidden state; with
     ``output_hidden_states=True`` ``enc(ids)[-1]`` = tuple of hidden states; ``enc.text_model.final_layer_norm``; ``enc.config``."""
@@ -178,7 +190,7 @@ class ToyTextEncoder(nn.Module):
         h1 = h0 + torch.tanh(self.l1(h0))
         h2 = h1 + torch.tanh(self.l2(h1))
         last = self._ln(h2)
-        return (last, None, (h0, h1, h2)) if output_hidden_states else (last,)
+        return _TextOut((last, None, (h0, h1, h2))) if output_hidden_states else _TextOut((last,))
 
 
 class ToyImageEncoder(nn.Module):
@@ -190,7 +202,8 @@ class ToyImageEncoder(nn.Module):
             for p in self.parameters():
                 p.copy_(torch.randn(p.shape, generator=g) * 0.2)
 
-    def forward(self, image):
+    def forward(self, image=None, pixel_values=None):
+        image = image if image is not None else pixel_values
         x = torch.nn.functional.adaptive_avg_pool2d(image.float(), 8).flatten(1)
         return types.SimpleNamespace(image_embeds=self.proj(x).to(image.dtype))
 

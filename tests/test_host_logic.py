@@ -481,3 +481,82 @@ def test_reference_pipeline_code_vs_loop_oracle_vs_native_pipeline(cpu_ops, tmp_
         assert (fx[k].float() - gold[k].float()).abs().max() <= 2e-3 * gold[k].float().abs().max().clamp_min(1e-6), k
     # (b) the native pipeline (fp16, emulated ops) against the reference-generated fixture -- the same check the GPU suite runs
     _ok(gc.check_pipeline_vs_reference_fixture("mini"))
+
+
+def test_native_pipeline_from_raw_inputs_vs_reference_pipeline(cpu_ops, tmp_path):
+    """A13 (once-per-clip pre / post) pinned to the reference's glue: BOTH pipelines start from the same PIL frames and prompt
+    strings with the same toy VAE / CLIP weights -- the reference's ``encode_vae_video``, ``encode_prompt`` (clip_skip = 1,
+    negative prompt), ``_encode_image`` (centre crop, 224 bilinear, CLIP normalisation, zero negative embedding),
+    ``prepare_image_latents`` (scaling factor, frame-position planes) vs ``anyv2v_amd.pipeline`` + ``anyv2v_amd.encoders``'
+    interfaces around the same components -- and must agree on every conditioning tensor and on the final latents."""
+    from oracle import ref_stubs
+    if not ref_stubs.reference_available():
+        pytest.skip("needs /root/reference")
+    import sys
+    from PIL import Image
+
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.encoders import HFImageEncoder, HFTextEncoder, _center_crop_wide, _pil_to_tensor
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    from oracle import ref_pipeline
+    sys.path.insert(0, os.path.join(gc.ROOT, "tests", "golden"))
+    import make_golden
+    spec = dict(make_golden.REF_PIPELINE_JOBS["mini"], size=128)  # 128 x 128: not the size the fixtures use
+    frames, edited = make_golden.ref_pipeline_frames(spec)
+    frames = [f.resize((200, 128)) for f in frames]                # wide source frames: the centre crop matters
+    edited = edited.resize((160, 128))
+    native, oracle, ocfg = gc.build_pair("mini", spec["seed"])
+    n_steps, size, ratios = spec["n_steps"], spec["size"], spec["ratios"]
+    job = ref_pipeline.run_reference_job(oracle, ocfg.cross_attention_dim, frames, edited, size, n_steps, ratios, tmp_path,
+                                         with_reconstruction=False)
+
+    class VaeAdapter:  # the toy VAE behind anyv2v_amd.encoders' VAE interface (what NativeVAE does around the real AutoencoderKL)
+        def __init__(self):
+            self.toy = ref_pipeline.ToyVAE()
+            self.config = self.toy.config
+
+        def to(self, device):
+            return self
+
+        def _enc(self, x):
+            return (self.toy.encode(x).latent_dist.sample() * self.config.scaling_factor).detach()
+
+        def encode_image(self, image, device, height, width):
+            return self._enc(_pil_to_tensor(_center_crop_wide(image, (width, height)))).half()
+
+        def encode_video(self, video, device, height, width):
+            x = torch.cat([_pil_to_tensor(_center_crop_wide(f, (width, height))) for f in video])
+            return self._enc(x).permute(1, 0, 2, 3)[None].half()
+
+    dim, dev = ocfg.cross_attention_dim, torch.device("cpu")
+    tok = ref_pipeline.ToyTokenizer()
+    pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler(), vae=VaeAdapter(),
+                            text_encoder=HFTextEncoder(ref_pipeline.ToyTextEncoder(dim), tok), tokenizer=tok,
+                            image_encoder=HFImageEncoder(ref_pipeline.ToyImageEncoder(dim)), feature_extractor=object())
+    pipe._device = dev
+    close = lambda a, b, tol: float((a.float() - b.float()).abs().max()) <= tol * float(b.float().abs().max())
+    lat0 = pipe.encode_vae_video(frames, dev, height=size, width=size)
+    assert close(lat0, job["lat0"], 2e-3), "encode_vae_video"
+    assert close(pipe.text_encoder.encode("", dev, 1), job["src_pe"], 2e-3) and close(pipe.text_encoder.encode(job["neg"], dev, 1), job["npe"], 2e-3)
+    assert close(pipe.image_encoder.encode(frames[0], size, dev), job["src_ie"], 2e-3), "_encode_image (crop + 224 bilinear + CLIP norm)"
+    first = pipe.vae.encode_image(edited, dev, size, size)
+    assert close(pipe.prepare_image_latents_from_first_frame_latent(first, len(frames)), job["il2"][1:], 2e-3), "prepare_image_latents"
+    traj = pipe.invert(prompt="", image=frames[0], height=size, width=size, num_frames=len(frames), num_inference_steps=n_steps,
+                       guidance_scale=1.0, negative_prompt=job["neg"], target_fps=8, latents=lat0, return_trajectory=True)
+    for t in job["inv_ts"]:
+        assert close(traj[t], job["files"][t], 1e-2), f"invert from raw inputs at t={t}"
+    sched = DDIMScheduler()
+    sched.set_timesteps(n_steps)
+    pipe.register_modules(scheduler=sched)
+    k = lambda r: sched.timesteps[: int(n_steps * r)]
+    pnp_utils.register_conv_injection(pipe, k(ratios[0]))
+    pnp_utils.register_spatial_attention_pnp(pipe, k(ratios[1]))
+    pnp_utils.register_temp_attention_pnp(pipe, k(ratios[2]))
+    T = job["T"]
+    ed = pipe.sample_with_pnp(prompt="a robot", image=edited, height=size, width=size, num_frames=len(frames),
+                              num_inference_steps=n_steps, guidance_scale=9.0, negative_prompt=job["neg"], target_fps=8,
+                              latents=job["files"][T].half(), output_type="latent", ddim_init_latents_t_idx=0,
+                              ddim_inv_latents_path=job["out_dir"], ddim_inv_prompt="", ddim_inv_1st_frame=frames[0]).frames
+    pnp_utils.clear_time(pipe)
+    assert close(ed, job["edit_ref"], 3e-2), "sample_with_pnp from raw inputs (reads the reference's ddim_latents_{t}.pt files)"
