@@ -518,6 +518,29 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK p) {
 //    live next to the 160 accumulators, instead of 112 when hipcc hoists all 28 reads of the tile to the top);
 //  * the next tile's LDS-DMA pieces are threaded through the first half of the MFMA stream, one per fragment group
 //    (they have to sit here textually: an LDS-DMA load writes LDS, so hipcc never moves it across a ds_read).
+#ifndef AV_FRAG_ASM
+#define AV_FRAG_ASM 1
+#endif
+// Fragment reads of the K-tile below are issued as inline asm with hand-counted `s_waitcnt lgkmcnt(n)`: with an LDS-DMA load
+// (global_load_lds) in flight hipcc treats the LGKM counter as out of order and waits lgkmcnt(0) before every fragment use,
+// i.e. also for the fragment it has just requested two groups ahead -- the roll degenerates into issue -> full LDS latency ->
+// use (tools/wait_probe.hip reproduces it in 30 lines).  LDS reads return in order among themselves, and the DMA completes on
+// vmcnt, so the wait a use needs is "all but the reads issued after mine".
+__device__ __forceinline__ h8 lds_frag(unsigned base, int off) {  // off: a constant after unrolling (16-bit immediate)
+    h8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(off) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lgkm_wait(int n) {  // n is a constant after unrolling; the switch folds to one s_waitcnt
+    switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+    }
+}
+
 template <int MF, typename PieceFn>
 __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, const char* bs, int wr, int wc, int lane,
                                              PieceFn&& piece) {
@@ -526,8 +549,17 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
     const char* b0 = bs + (wc * 160 + l15) * 128;
     const int c0 = ((0 * 4 + lq) ^ (l15 & 7)) * 16, c1 = ((1 * 4 + lq) ^ (l15 & 7)) * 16;
     h8 af[2][MF], bf[2][10];
+#if AV_FRAG_ASM
+    // issue order of the reads (seq = running count) and, per fragment, its position in that order
+    int seq = 0, a_seq[2] = {0, 0}, b_seq[2][10] = {};
+    const unsigned abase[2] = {(unsigned)(size_t)(a0 + c0), (unsigned)(size_t)(a0 + c1)};
+    const unsigned bbase[2] = {(unsigned)(size_t)(b0 + c0), (unsigned)(size_t)(b0 + c1)};
+#define AV_RA(ks, mf) (af[ks][mf] = lds_frag(abase[ks], (mf) * 2048), a_seq[ks] = ++seq)
+#define AV_RB(ks, nf) (bf[ks][nf] = lds_frag(bbase[ks], (nf) * 2048), b_seq[ks][nf] = ++seq)
+#else
 #define AV_RA(ks, mf) af[ks][mf] = *(const h8*)(a0 + (mf) * 2048 + ((ks) ? c1 : c0))
 #define AV_RB(ks, nf) bf[ks][nf] = *(const h8*)(b0 + (nf) * 2048 + ((ks) ? c1 : c0))
+#endif
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) AV_RA(0, mf);
     AV_RB(0, 0);
@@ -538,17 +570,25 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int nf = 0; nf < 10; ++nf) {
+#if AV_FRAG_ASM
+            {   // everything up to the later of (this group's weight fragment, this K-step's last activation fragment)
+                const int need = b_seq[ks][nf] > a_seq[ks] ? b_seq[ks][nf] : a_seq[ks];
+                lgkm_wait(seq - need);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], acc[mf][nf], 0, 0, 0);
             q += MF;
             __builtin_amdgcn_sched_barrier(0);
+            // (activation fragment of the next K-step first: group (1, 0) then waits for all but the weight read behind it)
+            if (ks == 0 && nf >= 10 - MF) AV_RA(1, nf - (10 - MF));
             if (nf + 2 < 10) {
                 AV_RB(ks, nf + 2);
             } else if (ks == 0) {
                 AV_RB(1, nf + 2 - 10);
             }
-            if (ks == 0 && nf >= 10 - MF) AV_RA(1, nf - (10 - MF));
             if (npiece < MF + 5) piece(npiece++);
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -1,4 +1,5 @@
-"""A/B of two forms of the persistent GEMM kernel selected by AnyV2VGemmDesc.flags (GEMM_FORMS="flag:name,..."): parity of each
+"""A/B of forms of the GEMM kernels selected by AnyV2VGemmDesc.flags and / or by build (GEMM_FORMS="flag:name[:path/to/lib.so],...";
+a third field loads another build of the library with the same ABI next to the product one, in the same process): parity of each
 on the big-tile check, then interleaved timing (rounds in one process) on the bench workload's large shapes.
 Writes gpurun_out/gemm_epi_ab.txt.   python tools/gemm_epi_ab.py"""
 import os
@@ -14,7 +15,25 @@ from anyv2v_amd import ops  # noqa: E402
 
 dev = "cuda"
 lines = []
-FORMS = [(int(f), n) for f, n in (a.split(":") for a in os.environ.get("GEMM_FORMS", "512:wave-private,0:cooperative").split(","))]
+from anyv2v_amd import _lib  # noqa: E402
+
+_product = _lib.load()
+_handles = {}
+FORMS = []
+for spec in os.environ.get("GEMM_FORMS", "0:product").split(","):
+    f = spec.split(":")
+    if len(f) > 2:  # another build
+        _lib._lib, _lib.LIB_PATH = None, os.path.join(ROOT, f[2])
+        _handles[f[1]] = _lib.load()
+        _lib._lib = _product
+    else:
+        _handles[f[1]] = _product
+    FORMS.append((int(f[0]), f[1]))
+
+
+def select(flag, name):
+    ops.GEMM_FLAGS = flag
+    _lib._lib = _handles[name]
 
 
 def say(s):
@@ -23,7 +42,7 @@ def say(s):
 
 
 for flag, name in FORMS:
-    ops.GEMM_FLAGS = flag
+    select(flag, name)
     res = gc.check_gemm_big() + gc.check_conv(("glds",)) + gc.check_gemm_splitk() + gc.check_vae_kernels()
     bad = [r for r in res if not r["ok"]]
     say(f"[{name}] parity: {len(res) - len(bad)}/{len(res)} ok, worst {max(r['err'] for r in res):.2e}")
@@ -58,7 +77,7 @@ def case(tag, M, N, K, mode=0, act=0, conv=None, temporal=None, res=False, rv=0,
     ts = {n: [] for _, n in FORMS}
     for _ in range(rounds):
         for flag, name in FORMS:
-            ops.GEMM_FLAGS = flag
+            select(flag, name)
             ts[name].append(timeit(fn, iters))
     fl = 2.0 * M * N * K
     by = (M * (K // taps) + N * K + M * n_out * (2 if res else 1)) * 2.0
@@ -80,7 +99,7 @@ if os.environ.get("GEMM_CASES") == "conv":
         case(f"{tagB} conv 2560->1280 @16", N0 * 256, 1280, 23040, mode=1, conv=(16, 16, 16, 16, 1, 0), rv=4096)
         case(f"{tagB} conv 1280->1280 @8", N0 * 64, 1280, 11520, mode=1, conv=(8, 8, 8, 8, 1, 0), res=True)
         case(f"{tagB} conv 2560->1280 @8", N0 * 64, 1280, 23040, mode=1, conv=(8, 8, 8, 8, 1, 0), rv=1024)
-    ops.GEMM_FLAGS = 0
+    select(*FORMS[0])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", os.environ.get("GEMM_AB_OUT", "gemm_epi_ab.txt")), "w").write("\n".join(lines) + "\n")
     sys.exit(0)
@@ -106,6 +125,6 @@ for B, tagB in ((3, "B3"), (1, "B1")):
         case(f"{tagB} L2 GEGLU", T2, 10240, 1280, act=3)
         case(f"{tagB} L2 FF down +res", T2, 1280, 5120, res=True)
         case(f"{tagB} L2 conv3x3 +res", T2, 1280, 11520, mode=1, conv=(16, 16, 16, 16, 1, 0), res=True)
-ops.GEMM_FLAGS = 0
+select(*FORMS[0])
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", os.environ.get("GEMM_AB_OUT", "gemm_epi_ab.txt")), "w").write("\n".join(lines) + "\n")
