@@ -809,383 +809,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// gemm_pp_kernel -- the short-K linear layers (attention projections, feed-forward) of the 64x64 / 32x32 levels.
-// On these a 192 x 320 tile spends as long storing its 123 KB of results as in its 5-10 K-tiles, and gemm_big_kernel runs the
-// two phases back to back.  Here a block works on 192 x 160 sub-tiles with TWO accumulator sets (2 x 60 registers, the same 120
-// as one 192 x 320 tile): while the MFMAs of sub-tile i+1 fill one set, the epilogue of sub-tile i drains the other -- its
-// converts, LDS turn, residual loads and global stores are threaded through the first three K-tiles of the next sub-tile, one
-// 16-row slab per K-tile, one small piece per MFMA group.  Consequences of running both in one instruction stream:
-//   * operand stages (192 + 160 rows x 128 B = 44 KB) form a 3-deep ring filled two K-tiles ahead by LDS-DMA; a K-tile waits
-//     for "everything except what was requested during the previous K-tile" (counted vmcnt, no drain), then one barrier;
-//   * every VMEM / LDS operation inside the K loop is inline asm with a hand-counted s_waitcnt: with an LDS-DMA load in
-//     flight hipcc waits vmcnt(0) / lgkmcnt(0) before any use of a load result (see lds_frag above), which would drain the ring.
-//     The counts are derived from running counters in the unrolled code (vq / lds below), never written by hand, and every
-//     operation is issued unconditionally (rows beyond M read a clamped row and store to a dump line) so that they hold;
-//   * the bias is the initial value of the accumulators; it travels like the operands (a 4-byte-per-lane LDS-DMA piece requested
-//     during the previous sub-tile's first K-tile, read back from LDS in its last): a register load would have to be waited
-//     for within one K-tile, and a global load takes several K-tiles under this store traffic.
-// Sub-tiles are handed out in contiguous ranges per block, N fastest, so consecutive sub-tiles re-read the same A rows from L2.
-__device__ __attribute__((aligned(256))) half_t g_dump_line[512];  // 1 KB sink for the stores of rows beyond M
-
-__device__ __forceinline__ void vm_wait_n(int n) {  // n: a constant after unrolling
-    switch (n) {
-#define AV_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        AV_VMW(0) AV_VMW(1) AV_VMW(2) AV_VMW(3) AV_VMW(4) AV_VMW(5) AV_VMW(6) AV_VMW(7) AV_VMW(8) AV_VMW(9) AV_VMW(10)
-        AV_VMW(11) AV_VMW(12) AV_VMW(13) AV_VMW(14) AV_VMW(15) AV_VMW(16) AV_VMW(17) AV_VMW(18) AV_VMW(19) AV_VMW(20)
-#undef AV_VMW
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-__device__ __forceinline__ void lgkm_wait_n(int n) {
-    switch (n) {
-#define AV_LGW(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" ::: "memory"); break;
-        AV_LGW(0) AV_LGW(1) AV_LGW(2) AV_LGW(3) AV_LGW(4) AV_LGW(5) AV_LGW(6) AV_LGW(7) AV_LGW(8) AV_LGW(9) AV_LGW(10)
-        AV_LGW(11) AV_LGW(12) AV_LGW(13) AV_LGW(14) AV_LGW(15)
-#undef AV_LGW
-        default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
-    }
-}
-__device__ __forceinline__ h8 gload16(const half_t* g) {
-    h8 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(g) : "memory");
-    return v;
-}
-__device__ __forceinline__ h4 gload8(const half_t* g) {
-    h4 v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(g) : "memory");
-    return v;
-}
-__device__ __forceinline__ void gstore16(half_t* g, h8 v) {
-    // (s_nop: a store of more than 8 bytes must not be followed at once by a VALU write of its data registers; hipcc's hazard
-    //  recognizer cannot see into the asm)
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(g), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_write8(unsigned addr, h4 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-__device__ __forceinline__ h8 lds_read16(unsigned addr) {
-    h8 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-
-template <bool RES>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmK p, half_t* const dump) {
-    constexpr int BM = 192, BN = 160, A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int SLAB_LD = 88, SLAB_BYTES = 16 * SLAB_LD * 2;  // 16 rows x 80 columns (+8 pad) fp16 per wave
-    constexpr int BIAS_OFF = 3 * STAGE + 8 * SLAB_BYTES;        // 256 B per wave: the next sub-tile's 80 bias values
-    __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 8 * 256];
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wu = __builtin_amdgcn_readfirstlane(w);  // wave-uniform copy for scalar branches
-    const bool hi = wu >= 4;                           // waves 4-7 request five pieces per K-tile, waves 0-3 six
-    const int wr = w >> 1, wc = w & 1, l15 = lane & 15, lq = lane >> 4;
-    const int G = gridDim.x;
-    const int b0 = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous
-    const int tilesM = (p.M + BM - 1) / BM, nsub = p.N / BN, nitems = tilesM * nsub;
-    const int ipb = (nitems + G - 1) / G;
-    const int it0 = b0 * ipb, it1 = it0 + ipb < nitems ? it0 + ipb : nitems;
-    if (it0 >= it1) return;
-    const int nk = p.Ktot >> 6;
-
-    // ---- producer: two K-tiles ahead of the consumer over the flattened (sub-tile, K-tile) sequence of this block ----
-    const int srow0 = tid >> 3, pc = tid & 7, kc = pc ^ (srow0 & 7);
-    const size_t brow = (size_t)64 * p.Ktot;
-    const half_t* ap[3];
-    const half_t* bp;
-    int p_item = it0, p_kt = 0;
-    auto p_start = [&]() {
-        const int item = p_item < it1 ? p_item : it1 - 1;
-        const int mt = item / nsub, ns = item - mt * nsub;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            int row = mt * BM + srow0 + 64 * i;
-            row = row < p.M ? row : p.M - 1;  // rows beyond M: any valid row (their results go to the dump line)
-            ap[i] = p.A0 + (size_t)row * p.lda0 + kc * 8;
-        }
-        bp = p.W + (size_t)(ns * BN + srow0) * p.Ktot + kc * 8;
-    };
-    auto p_advance = [&]() {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ap[i] += 64;
-        bp += 64;
-        if (++p_kt == nk) {
-            p_kt = 0;
-            ++p_item;
-            p_start();
-        }
-    };
-    // piece g (0..5) of the K-tile the producer stands on, into ring stage `pst`; returns 1 if a VMEM op was issued
-    auto p_piece = [&](int g, char* pst) -> int {
-        const bool fetch = p_item < it1;
-        if (g < 3) {
-            glds16(fetch ? ap[g] : p.zeros, pst + (g * 512 + w * 64) * 16);
-            return 1;
-        }
-        const int j = g - 3;
-        if (j < 2 || !hi) glds16(fetch ? bp + j * brow : p.zeros, pst + A_BYTES + (j * 512 + w * 64) * 16);
-        return 1;  // (waves 4-7 skip piece 5: the waits below subtract it, see vm_wait_k)
-    };
-
-    // lane geometry of the epilogue: fragment -> slab position; three 16-byte chunks of the 16 x 80 slab per lane
-    const unsigned slab = (unsigned)(size_t)(smem + 3 * STAGE + w * SLAB_BYTES);
-    const unsigned slab_w = slab + (l15 * SLAB_LD + 4 * lq) * 2;
-    int c_row[3], c_col[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int id = c * 64 + lane;
-        const int row = id / 10;
-        c_row[c] = id < 160 ? row : 16;  // 16 = "no chunk": fails every row < M test through the +16 below? no: handled by ok_c
-        c_col[c] = (id - row * 10) * 8;
-    }
-
-    f4 accA[3][5], accB[3][5];
-    auto bias_init = [&](f4 (&acc)[3][5], const h4 (&bv)[5]) {
-#pragma unroll
-        for (int mf = 0; mf < 3; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < 5; ++nf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mf][nf][r] = (float)bv[nf][r];
-    };
-    auto bias_ptr = [&](int item, int nf) -> const half_t* {
-        const int it = item < it1 ? item : it1 - 1;
-        const int ns = it % nsub;
-        return p.bias != nullptr ? p.bias + ns * BN + wc * 80 + nf * 16 + 4 * lq : p.zeros;
-    };
-
-    // ---- one K-tile: MFMAs into `cur`; EPI = 0..2: slab EPI of `prev` (sub-tile `e_item`) drains alongside; LAST: the bias of
-    //      sub-tile `n_item` is loaded and becomes the initial value of `prev` (free by then).  Returns the number of VMEM
-    //      operations issued (as for waves 0-3), i.e. what the next K-tile's entry wait may leave outstanding. ----
-    int st_c = 0;  // ring stage the consumer reads
-    auto ktile = [&](auto epi_tag, auto last_tag, f4 (&cur)[3][5], f4 (&prev)[3][5], int e_item, int n_item) -> int {
-        constexpr int EPI = decltype(epi_tag)::value;
-        constexpr bool LAST = decltype(last_tag)::value;
-        const char* as = smem + st_c * STAGE;
-        char* pst = smem + (st_c == 0 ? 2 : st_c - 1) * STAGE;
-        const char* a0 = as + (wr * 48 + l15) * 128;
-        const char* b0p = as + A_BYTES + (wc * 80 + l15) * 128;
-        const int c0 = ((0 * 4 + lq) ^ (l15 & 7)) * 16, c1 = ((1 * 4 + lq) ^ (l15 & 7)) * 16;
-        const unsigned abase[2] = {(unsigned)(size_t)(a0 + c0), (unsigned)(size_t)(a0 + c1)};
-        const unsigned bbase[2] = {(unsigned)(size_t)(b0p + c0), (unsigned)(size_t)(b0p + c1)};
-        h8 af[2][3], bf[2][5];
-        int lds = 0, a_seq[2] = {0, 0}, b_seq[2][5] = {};  // LDS operations issued / position of each fragment read
-        int vq = 0;                                        // VMEM operations issued in this K-tile (waves 0-3)
-        bool b2_issued = false;                            // piece 5 (skipped by waves 4-7) is among them
-        auto vm_wait_k = [&](int k) {  // everything up to the k-th VMEM operation of this K-tile has completed
-            const int n = vq - k;
-            if (b2_issued) {
-                if (hi) vm_wait_n(n - 1); else vm_wait_n(n);
-            } else {
-                vm_wait_n(n);
-            }
-        };
-#define AV_RA(ks, mf) (af[ks][mf] = lds_frag(abase[ks], (mf) * 2048), a_seq[ks] = ++lds)
-#define AV_RB(ks, nf) (bf[ks][nf] = lds_frag(bbase[ks], (nf) * 2048), b_seq[ks][nf] = ++lds)
-        // epilogue state of this K-tile
-        h8 rr[3], sv[3];
-        h4 bnext[5];
-        int rr_k[3] = {0, 0, 0}, sv_seq[3] = {0, 0, 0}, bias_seq = 0;
-        const unsigned bias_lds = (unsigned)(size_t)(smem + BIAS_OFF + w * 256);
-        int e_m = 0, e_n = 0;
-        if constexpr (EPI >= 0) {
-            const int it = e_item >= it0 ? e_item : it0;
-            const int mt = it / nsub, ns = it - mt * nsub;
-            e_m = e_item >= it0 ? mt * BM + wr * 48 + EPI * 16 : (1 << 28);  // no previous sub-tile: every row is "beyond M"
-            e_n = ns * BN + wc * 80;
-        }
-        auto epi_piece = [&](int g) {
-            if constexpr (LAST) {
-                if (g == 8) {
-#pragma unroll
-                    for (int nf = 0; nf < 5; ++nf) {
-                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bnext[nf]) : "v"(bias_lds + 8 * lq), "n"(nf * 32) : "memory");
-                        bias_seq = ++lds;
-                    }
-                }
-            }
-            if constexpr (EPI == 0) {
-                if (g == 0) {  // the bias of sub-tile n_item, 2 values per lane, into this wave's 256 bytes (lanes >= 40: zeros)
-                    const int it = n_item < it1 ? n_item : it1 - 1;
-                    const half_t* src = (p.bias != nullptr && lane < 40) ? p.bias + (it % nsub) * BN + wc * 80 + 2 * lane : p.zeros;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(smem + BIAS_OFF + w * 256), 4, 0, 0);
-                    ++vq;
-                }
-            }
-            if constexpr (EPI >= 0) {
-                if (g == 0) {
-                    if constexpr (RES) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const bool ok = c_row[c] < 16 && e_m + c_row[c] < p.M;
-                            rr[c] = gload16(ok ? p.R + (size_t)(e_m + c_row[c]) * p.ldr + e_n + c_col[c] : p.zeros);
-                            rr_k[c] = ++vq;
-                        }
-                    }
-                } else if (g <= 5) {
-                    const int nf = g - 1;
-                    h4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)prev[EPI][nf][r];
-                    lds_write8(slab_w + nf * 32, o);
-                    ++lds;
-                } else if (g == 6) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        sv[c] = lds_read16(slab + (c_row[c] < 16 ? c_row[c] * SLAB_LD * 2 + c_col[c] * 2 : 0));
-                        sv_seq[c] = ++lds;
-                    }
-                } else {
-                    const int c = g - 7;
-                    lgkm_wait_n(lds - sv_seq[c]);
-                    h8 v = sv[c];
-                    if constexpr (RES) {
-                        vm_wait_k(rr_k[c]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[c][e]);
-                    }
-                    const bool ok = c_row[c] < 16 && e_m + c_row[c] < p.M;
-                    gstore16(ok ? p.C + (size_t)(e_m + c_row[c]) * p.ldc + e_n + c_col[c] : dump + lane * 8, v);
-                    ++vq;
-                }
-            }
-        };
-
-#pragma unroll
-        for (int mf = 0; mf < 3; ++mf) AV_RA(0, mf);
-        AV_RB(0, 0);
-        AV_RB(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int nf = 0; nf < 5; ++nf) {
-                const int g = ks * 5 + nf;
-                {
-                    const int need = b_seq[ks][nf] > a_seq[ks] ? b_seq[ks][nf] : a_seq[ks];
-                    lgkm_wait_n(lds - need);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int mf = 0; mf < 3; ++mf)
-                    cur[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], cur[mf][nf], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks == 0 && nf >= 2) AV_RA(1, nf - 2);
-                if (nf + 2 < 5) {
-                    AV_RB(ks, nf + 2);
-                } else if (ks == 0) {
-                    AV_RB(1, nf + 2 - 5);
-                }
-                epi_piece(g);  // (before this group's DMA piece: loads issued here are older than the piece)
-                if (g < 6) {
-                    vq += p_piece(g, pst);
-                    if (g == 5) b2_issued = true;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#undef AV_RA
-#undef AV_RB
-        if constexpr (LAST) {  // the next sub-tile starts from its bias; `prev` has been stored by now (K-tiles 0..2)
-            lgkm_wait_n(lds - bias_seq);
-            __builtin_amdgcn_sched_barrier(0);
-            bias_init(prev, bnext);
-        }
-        p_advance();
-        st_c = st_c == 2 ? 0 : st_c + 1;
-        return vq;
-    };
-    auto enter = [&](int n_prev) {  // n_prev: VMEM operations of the previous K-tile (waves 0-3; piece 5 among them)
-        if (hi) vm_wait_n(n_prev - 1); else vm_wait_n(n_prev);
-        __builtin_amdgcn_s_barrier();
-    };
-    using I = std::integral_constant<int, 0>;
-    (void)sizeof(I);
-    auto item = [&](f4 (&cur)[3][5], f4 (&prev)[3][5], int it, int n_in) -> int {
-        // K-tiles 0..2 drain the previous sub-tile's slabs 0..2; K-tile nk-1 prepares the next sub-tile's bias
-        enter(n_in);
-        int n = ktile(std::integral_constant<int, 0>{}, std::false_type{}, cur, prev, it - 1, it + 1);
-        enter(n);
-        n = ktile(std::integral_constant<int, 1>{}, std::false_type{}, cur, prev, it - 1, 0);
-        enter(n);
-        n = ktile(std::integral_constant<int, 2>{}, std::false_type{}, cur, prev, it - 1, 0);
-        for (int kt = 3; kt < nk - 1; ++kt) {
-            enter(n);
-            n = ktile(std::integral_constant<int, -1>{}, std::false_type{}, cur, prev, 0, 0);
-        }
-        enter(n);
-        return ktile(std::integral_constant<int, -1>{}, std::true_type{}, cur, prev, 0, it + 1);
-    };
-
-    // ---- prologue: bias of the first sub-tile, K-tiles 0 and 1 into stages 0 and 1 ----
-    {
-        h4 bv[5];
-#pragma unroll
-        for (int nf = 0; nf < 5; ++nf) bv[nf] = *(const h4*)bias_ptr(it0, nf);
-        bias_init(accA, bv);
-#pragma unroll
-        for (int mf = 0; mf < 3; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < 5; ++nf) accB[mf][nf] = (f4){0.f, 0.f, 0.f, 0.f};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    p_start();
-#pragma unroll
-    for (int g = 0; g < 6; ++g) p_piece(g, smem + 0 * STAGE);
-    p_advance();
-#pragma unroll
-    for (int g = 0; g < 6; ++g) p_piece(g, smem + 1 * STAGE);
-    p_advance();
-
-    int n_in = 6;  // stage 1's pieces may be in flight when K-tile 0 starts
-    int it = it0;
-    bool last_in_A = true;
-    while (true) {
-        n_in = item(accA, accB, it, n_in);
-        last_in_A = true;
-        if (++it >= it1) break;
-        n_in = item(accB, accA, it, n_in);
-        last_in_A = false;
-        if (++it >= it1) break;
-    }
-
-    // ---- the last sub-tile's epilogue has nothing to hide behind: plain form ----
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    {
-        const int li = it1 - 1;
-        const int mt = li / nsub, ns = li - mt * nsub;
-        const int m_wave = mt * BM + wr * 48, n_wave = ns * BN + wc * 80;
-        half_t* const sl = (half_t*)(smem + 3 * STAGE + w * SLAB_BYTES);
-        auto tail = [&](f4 (&acc)[3][5]) {
-#pragma unroll
-            for (int mf = 0; mf < 3; ++mf) {
-#pragma unroll
-                for (int nf = 0; nf < 5; ++nf) {
-                    h4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)acc[mf][nf][r];
-                    *(h4*)(sl + l15 * SLAB_LD + nf * 16 + 4 * lq) = o;
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int row = m_wave + mf * 16 + c_row[c];
-                    if (c_row[c] < 16 && row < p.M) {
-                        h8 v = *(const h8*)(sl + c_row[c] * SLAB_LD + c_col[c]);
-                        if constexpr (RES) {
-                            const h8 r8 = *(const h8*)(p.R + (size_t)row * p.ldr + n_wave + c_col[c]);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
-                        }
-                        *(h8*)(p.C + (size_t)row * p.ldc + n_wave + c_col[c]) = v;
-                    }
-                }
-            }
-        };
-        if (last_in_A) tail(accA); else tail(accB);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Reference-grade kernel: one thread per output element, any shape.  Used for the tiny once-per-clip
 // conditioning layers (Cin = 4/16/32 ...) and as the on-device cross-check of the MFMA kernels in the tests.
 template <int MODE>
@@ -1295,15 +918,6 @@ static const half_t* zero_line() {
     return z;
 }
 
-static half_t* dump_line() {
-    static half_t* z = nullptr;
-    if (z == nullptr) {
-        void* ptr = nullptr;
-        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_dump_line)) == hipSuccess) z = (half_t*)ptr;
-    }
-    return z;
-}
-
 template <int MODE>
 static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s) {
     const bool geglu = d->act == ACT_GEGLU;
@@ -1316,19 +930,6 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     const bool glds = (d->flags & 2) != 0;
     const int nf = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
     k.tilesN = (d->N + nf * 32 - 1) / (nf * 32);
-    if constexpr (MODE == MODE_LINEAR) {
-        // short-K linear layers: 192 x 160 sub-tiles with the epilogue of one hidden behind the K loop of the next
-        if (glds && (d->flags & 1024) && d->C1 == 0 && d->act == ACT_NONE && d->rowvec == nullptr && d->N % 160 == 0 &&
-            k.nt0 >= 4 && dump_line() != nullptr) {
-            const int items = ((d->M + 191) / 192) * (d->N / 160);
-            const dim3 grid(items < 256 ? items : 256);
-            if (d->R != nullptr)
-                hipLaunchKernelGGL((gemm_pp_kernel<true>), grid, dim3(512), 0, s, k, dump_line());
-            else
-                hipLaunchKernelGGL((gemm_pp_kernel<false>), grid, dim3(512), 0, s, k, dump_line());
-            return av_launch_status("gemm_pp");
-        }
-    }
     if (glds && !(d->flags & 4) && d->N % 320 == 0 && (!geglu || MODE == MODE_LINEAR) && (geglu || d->act == ACT_NONE)) {
         // large launches: persistent 192 x 320 tiles, one block per CU (see gemm_big_kernel); taken when the tiles fill
         // the 256 CUs for a whole number of rounds well enough (>= 75 %), or when forced (flags bit3)

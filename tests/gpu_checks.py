@@ -162,32 +162,6 @@ def check_gemm(variants=("reg", "glds", "naive")):
     return out
 
 
-def check_gemm_pp(flag=1024):
-    """Ping-pong kernel of the short-K linear layers (gemm_pp_kernel; flag bit10 routes eligible shapes to it): one / several
-    sub-tiles per block, odd and even counts, ragged M (clamped rows + dump line), with and without bias / residual, the K loop
-    at its minimum of four K-tiles and longer; each against the fp32 reference and the one-thread-per-output kernel."""
-    out = []
-    saved = ops.GEMM_FLAGS
-    ops.GEMM_FLAGS = saved | flag
-    try:
-        for (M, N, K, res, has_bias) in [(192, 160, 256, False, True), (192 * 3, 320, 320, True, True), (1000, 160, 256, True, False),
-                                         (192 * 256 + 77, 320, 320, True, True), (65536, 960, 320, False, True),
-                                         (16384, 640, 640, True, True), (4096 * 3, 1280, 1280, True, True),
-                                         (192 * 512, 160, 448, False, False), (37, 480, 512, True, True)]:
-            a, w = rnd(M, K), rnd(N, K, scale=1 / math.sqrt(K))
-            bias = rnd(N) if has_bias else None
-            r = rnd(M, N) if res else None
-            y = ops.gemm(a, w, bias=bias, residual=r)
-            out.append(_res(f"gemm[pp] M{M} N{N} K{K} res={res} bias={has_bias}", y, _gemm_ref(a, w, bias, None, 0, r), KTOL))
-            yn = ops.gemm(a, w, bias=bias, residual=r, naive=True)
-            out.append(_res(f"gemm[pp] == naive kernel M{M} N{N} K{K}", y, yn.float(), 2e-3))
-            y2 = ops.gemm(a, w, bias=bias, residual=r)
-            out.append(_res(f"gemm[pp] run-to-run M{M} N{N} K{K}", y2, y.float(), 0.0))
-    finally:
-        ops.GEMM_FLAGS = saved
-    return out
-
-
 def check_gemm_big():
     """Persistent 256x320 kernel (gemm_big_kernel), forced with flag bit3 on shapes small enough for the references:
     single / multiple rounds per block, every mode, two-source K loop, bias / temb / residual / GEGLU epilogues."""
