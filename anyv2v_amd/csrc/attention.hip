@@ -231,34 +231,53 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
             const char* Ks = smem + stage * STAGE_BYTES;
             const unsigned ks_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ks;
             // ---- S^T = K Q^T for this wave's 32 queries x 64 keys
+            // K fragments as inline asm with counted lgkmcnt waits: the first block's four reads, then its MFMAs with the second
+            // block's reads slotted in, each MFMA waiting only for its own fragment (hipcc would wait lgkmcnt(0) in front of every
+            // MFMA while an LDS-DMA load is in flight -- see gemm.hip / tools/wait_probe.hip -- i.e. also for the read just issued)
             h8 kf[2][4];
+            unsigned kaddr[2];
+            int kfk[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int key = 32 * kb + l31;
-                const char* krow = Ks + key * 128;
-                const int fk = (key >> 1) & 7;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *(const h8*)(krow + (((2 * ks + hi) ^ fk) << 4));
+                kaddr[kb] = ks_lds + key * 128;
+                kfk[kb] = (key >> 1) & 7;
             }
+            auto kread = [&](int kb, int ks) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[kb][ks]) : "v"(kaddr[kb] + (((2 * ks + hi) ^ kfk[kb]) << 4)) : "memory");
+            };
+            auto kwait = [&](int n) {
+                switch (n) {
+                    case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+                }
+            };
             f16v sacc[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
-            }
-            // issue order: the first block's four K fragments, then its MFMAs with the second block's reads slotted in, then the
-            // rest (left alone, hipcc sinks every read next to its MFMA behind a full lgkmcnt(0): eight exposed LDS round trips)
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            for (int ks = 0; ks < 4; ++ks) kread(0, ks);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kwait(3);  // reads issued behind fragment (0, ks): three
+                __builtin_amdgcn_sched_barrier(0);
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][ks], qf[ks], sacc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                kread(1, ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kwait(3 - ks);
+                __builtin_amdgcn_sched_barrier(0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][ks], qf[ks], sacc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (j == ntiles - 1 && (p.Sk & 63) != 0) {  // key tail: only the last tile can hold masked keys
                 const int key_base = j * 64 + 4 * hi;
 #pragma unroll

@@ -1,5 +1,5 @@
 """A/B of flash-kernel variants selected by AnyV2VAttnDesc.flags (SM_FORMS="flag:name,..."; default: 8-wave dispatch vs 4-wave
-blocks only) or of two builds (ANYV2V_LIB): parity of each on the full attention check, then interleaved timing at the UNet's shapes.
+blocks only) and / or by build (a third field in a form names another .so): parity of each on the full attention check, then interleaved timing at the UNet's shapes.
 (Round 2 used it with development flags for the softmax forms: profiles/r02_attn_softmax_forms_ab*.txt.)
 Writes gpurun_out/attn_sm_ab.txt.   python tools/attn_sm_ab.py"""
 import os
@@ -10,15 +10,29 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
-if os.environ.get("ANYV2V_LIB"):  # A/B of builds: load another shared object (same ABI) instead of the product library
-    from anyv2v_amd import _lib
-    _lib.LIB_PATH = os.path.join(ROOT, os.environ["ANYV2V_LIB"])
 import gpu_checks as gc  # noqa: E402
-from anyv2v_amd import ops  # noqa: E402
+from anyv2v_amd import _lib, ops  # noqa: E402
 
 dev = "cuda"
 lines = []
-FORMS = [(int(f), n) for f, n in (a.split(":") for a in os.environ.get("SM_FORMS", "0:default,4:4-wave-blocks").split(","))]
+# SM_FORMS entries: "flag:name" or "flag:name:path/to/other/build.so" (same ABI, loaded next to the product library)
+_product = _lib.load()
+_handles, FORMS = {}, []
+for spec in os.environ.get("SM_FORMS", "0:default,4:4-wave-blocks").split(","):
+    f = spec.split(":")
+    if len(f) > 2:
+        _lib._lib, _lib.LIB_PATH = None, os.path.join(ROOT, f[2])
+        _handles[f[1]] = _lib.load()
+        _lib._lib = _product
+    else:
+        _handles[f[1]] = _product
+    FORMS.append((int(f[0]), f[1]))
+
+
+def select(flag, name):
+    ops.ATTN_FLAGS = flag
+    _lib._lib = _handles[name]
+
 
 
 def say(s):
@@ -27,7 +41,7 @@ def say(s):
 
 
 for flag, name in FORMS:
-    ops.ATTN_FLAGS = flag
+    select(flag, name)
     res = gc.check_attention(naive_too=False)
     bad = [r for r in res if not r["ok"]]
     worst = max(res, key=lambda r: r["err"] if r["err"] == r["err"] else 1e9)
@@ -67,7 +81,7 @@ def case(tag, N, h, S, iters, qk_mod=0, Sk=None, kv_div=1, rounds=5):
     ts = {n: [] for _, n in FORMS}
     for _ in range(rounds):          # interleaved rounds in one process (guide rule 24)
         for flag, name in FORMS:
-            ops.ATTN_FLAGS = flag
+            select(flag, name)
             ts[name].append(timeit(fn, iters))
     fl = 4.0 * N * h * S * Sk * 64
     say(f"{tag:<34s} " + "  ".join(f"{n}: med {sorted(v)[len(v) // 2]:.3f} min {min(v):.3f} ms ({fl / (min(v) * 1e-3) / 1e12:6.1f} TF)"
@@ -81,6 +95,6 @@ case("spatial 16x16 B=3", 48, 20, 256, 20)
 case("cross 64x64 Sk=145 B=3", 48, 5, 4096, 20, Sk=145, kv_div=16)
 case("PnP shared softmax 64x64", 48, 5, 4096, 10, qk_mod=16)
 case("PnP shared softmax 32x32", 48, 10, 1024, 20, qk_mod=16)
-ops.ATTN_FLAGS = 0
+select(*FORMS[0])
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", os.environ.get("SM_AB_OUT", "attn_sm_ab.txt")), "w").write("\n".join(lines) + "\n")
