@@ -25,7 +25,7 @@ from .parallel import FrameParallel, gather_latents, init_distributed, seed_for_
 from .pipeline import I2VGenXLPipeline
 from .pnp_utils import register_conv_injection, register_spatial_attention_pnp, register_temp_attention_pnp
 from .schedulers import DDIMScheduler
-from .utils import (LatentTrajectory, convert_video_to_frames, export_to_gif, load_ddim_latents_at_t, load_image,
+from .utils import (LatentTrajectory, convert_video_to_frames, export_to_gif, export_to_video, load_ddim_latents_at_t, load_image,
                     load_video_frames, seed_everything)
 
 MODEL_ID = "ali-vilab/i2vgen-xl"
@@ -132,8 +132,10 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         os.makedirs(output_dir, exist_ok=True)
         edited_video = [frame.resize(tuple(config.image_size), resample=Image.LANCZOS) for frame in edited_video]
         name = "video"
+        export_to_video(edited_video, os.path.join(output_dir, f"{name}.mp4"), fps=config.target_fps)
         export_to_gif(edited_video, os.path.join(output_dir, f"{name}.gif"), fps=config.target_fps)
-        logger.info(f"Saved gif to: {os.path.join(output_dir, f'{name}.gif')} (mp4 export needs ffmpeg, absent here)")
+        logger.info(f"Saved video to: {os.path.join(output_dir, f'{name}.mp4')}")
+        logger.info(f"Saved gif to: {os.path.join(output_dir, f'{name}.gif')}")
         for i, frame in enumerate(edited_video):
             frame.save(os.path.join(output_dir, f"{name}_{i:05d}.png"))
         torch.save(edited_latents.cpu(), os.path.join(output_dir, "edited_latents.pt"))

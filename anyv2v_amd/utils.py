@@ -179,9 +179,34 @@ def load_video_frames(frames_path, n_frames, image_size=(512, 512)):
 
 
 def convert_video_to_frames(video_path, img_size=(512, 512), save_frames=True):
-    """``i2vgen-xl/utils.py:43-67`` needs an mp4 decoder (torchvision/ffmpeg), which this image does not ship."""
-    raise RuntimeError(f"cannot decode {video_path}: no video decoder available here (no torchvision/ffmpeg/cv2); "
-                       "provide the frames as a directory of %05d.png files")
+    """``i2vgen-xl/utils.py:43-67``: decode the clip, LANCZOS-resize every frame to ``img_size``, optionally save them as
+    ``<video dir>/<video name>/%05d.png``.  The reference decodes with torchvision / ffmpeg; this image has no codec library,
+    so only mp4 files whose H.264 pictures are raw (I_PCM) macroblocks -- what ``export_to_video`` below writes -- can be read
+    (``anyv2v_amd.mp4``); anything else raises with the reason and the frame-directory alternative."""
+    from .mp4 import Mp4Unsupported, read_mp4
+    try:
+        video, _fps = read_mp4(video_path)
+    except Mp4Unsupported as e:
+        raise RuntimeError(f"cannot decode {video_path}: {e}; no video decoder library is available here (no torchvision / "
+                           "ffmpeg / cv2) -- provide the frames as a directory of %05d.png files") from e
+    if save_frames:
+        out_dir = os.path.join(os.path.dirname(video_path), os.path.splitext(os.path.basename(video_path))[0])
+        os.makedirs(out_dir, exist_ok=True)
+    frames = []
+    for i, image in enumerate(video):
+        if image.size != tuple(img_size):
+            image = image.resize(tuple(img_size), resample=Image.Resampling.LANCZOS)
+        if save_frames:
+            image.save(os.path.join(out_dir, f"{i:05d}.png"))
+        frames.append(image)
+    return frames
+
+
+def export_to_video(frames: List[Image.Image], path: str, fps: int = 8):
+    """``diffusers.utils.export_to_video`` as called at ``i2vgen-xl/run_group_pnp_edit.py:178``: an H.264 mp4 any player opens
+    (raw I_PCM macroblocks: there is no encoder library here; see ``anyv2v_amd.mp4``)."""
+    from .mp4 import write_mp4
+    return write_mp4(frames, path, fps=fps)
 
 
 def export_to_gif(frames: List[Image.Image], path: str, fps: int = 8):

@@ -99,6 +99,32 @@ def test_stage1_stage2_file_formats(tmp_path):
     _check_file_formats(tmp_path, "cpu")
 
 
+def test_stage1_from_an_mp4_clip(tmp_path):
+    """The reference's fallback when ``<video_dir>/<name>/%05d.png`` is missing (``run_group_ddim_inversion.py:97-105``):
+    decode ``<video_dir>/<name>.mp4`` into that directory, then go on as usual."""
+    base = _make_workspace(tmp_path)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_emulation as emu
+    emu.install()
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    from anyv2v_amd import run_group_ddim_inversion as s1
+    from anyv2v_amd.utils import export_to_video, seed_everything
+    clip = os.path.join(base, "demo", "clip")
+    pngs = [os.path.join(clip, f"{i:05d}.png") for i in range(N_FRAMES)]
+    export_to_video([Image.open(p).convert("RGB") for p in pngs], os.path.join(base, "demo", "clip.mp4"), fps=8)
+    for p in pngs:
+        os.remove(p)
+    inv, inv_list, _, _ = _configs(base, "mp4")
+    inv_list[0]["recon_config"] = {"enable_recon": False}
+    seed_everything(inv.seed)
+    s1.main(inv, inv_list, torch.device("cpu"), logging.getLogger("e2e"), synthetic_encoders=True)
+    assert all(os.path.isfile(p) for p in pngs) and os.path.isfile(os.path.join(clip, "clip.gif"))
+    lat_dir = os.path.join(base, "inversions", "mini-mp4", "clip", "ddim_latents")
+    assert len(os.listdir(lat_dir)) == N_STEPS
+
+
 @pytest.mark.gpu
 def test_stage1_stage2_on_gpu(tmp_path):
     """The same two CLI stages on cuda:0 through the HIP library (HIP-graph step engines, real kernels)."""
@@ -123,6 +149,13 @@ def _check_file_formats(tmp_path, device):
     assert tuple(lat.shape) == (1, 4, N_FRAMES, SIZE // 8, SIZE // 8) and torch.isfinite(lat.float()).all()
     with Image.open(os.path.join(out_dir, "video.gif")) as g:
         assert g.n_frames == N_FRAMES and g.size == (SIZE, SIZE)
+    # the reference's export_to_video(..., "video.mp4", fps=target_fps) (run_group_pnp_edit.py:178): an H.264 mp4 with the frames
+    from anyv2v_amd.mp4 import read_mp4
+    import numpy as np
+    vid, fps = read_mp4(os.path.join(out_dir, "video.mp4"))
+    assert len(vid) == N_FRAMES and vid[0].size == (SIZE, SIZE) and fps > 0
+    png0 = np.asarray(Image.open(os.path.join(out_dir, "video_00000.png")).convert("RGB"), dtype=np.int16)
+    assert np.abs(np.asarray(vid[0], dtype=np.int16) - png0).mean() < 6.0  # 4:2:0 chroma subsampling + limited-range rounding
     # stage 1 is skipped when its output exists (reference behaviour, run_group_ddim_inversion.py:118-120)
     mtime = os.path.getmtime(os.path.join(inv_dir, "ddim_latents", lat_files[0]))
     _run_both_stages(base, "single", device=device)
