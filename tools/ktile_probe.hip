@@ -137,6 +137,84 @@ static void run(const char* what, const _Float16* src, long long* out, long long
     fflush(stdout);
 }
 
+
+// ---- operand-data sweep: back-to-back MFMAs only (no LDS, no DMA, no barrier), 8 waves per CU on all 256 CUs -------------------
+// OPS: 0 = all-zero operands, 1 = small integers, 2 = random fp16 in [-2, 2).  SHAPE: 0 = 16x16x32, 1 = 32x32x16.
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int SHAPE>
+__global__ __launch_bounds__(512) void mfma_only(const _Float16* src, long long* out, int iters, int ops) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    h8 a[3], b[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[0][e] = ops == 1 ? (_Float16)(float)(lane + e) : (_Float16)0.f;
+        a[1][e] = ops == 1 ? (_Float16)(float)(lane - e) : (_Float16)0.f;
+        a[2][e] = ops == 1 ? (_Float16)(float)(e) : (_Float16)0.f;
+        b[0][e] = ops == 1 ? (_Float16)(float)(lane * e) : (_Float16)0.f;
+        b[1][e] = ops == 1 ? (_Float16)(float)(1 + e) : (_Float16)0.f;
+    }
+    if (ops == 2) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] = *(const h8*)(src + (size_t)(j * 64 + lane) * 8 + 4096 * w);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *(const h8*)(src + (size_t)((3 + j) * 64 + lane) * 8 + 4096 * w);
+    }
+    float sum = 0.f;
+    if constexpr (SHAPE == 0) {
+        f4 acc[10][3];
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int g = 0; g < 20; ++g)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[g % 10][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[g & 1], a[j], acc[g % 10][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sum += acc[i][j][0] + acc[i][j][3];
+    } else {
+        f16v acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int g = 0; g < 30; ++g) acc[g % 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[g & 1], a[g % 3], acc[g % 6], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sum += acc[i][0] + acc[i][15];
+    }
+    if (sum == 12345.678f) out[0] = 1;
+}
+
+template <int SHAPE>
+static void run_ops(const _Float16* src, long long* out, int ops) {
+    const int iters = 2000, blocks = 256;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((mfma_only<SHAPE>), dim3(blocks), dim3(512), 0, 0, src, out, iters, ops);
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    // per SIMD: 2 waves x 60 MFMAs (16 cycles each) or 2 x 30 (32 cycles each) per iteration = 1920 matrix-pipe cycles
+    const double flops = (SHAPE == 0 ? 2.0 * 16 * 16 * 32 * 60 : 2.0 * 32 * 32 * 16 * 30) * 8.0 * blocks * iters;
+    const double ghz = 1920.0 * iters / (ms * 1e-3) / 1e9;
+    printf("MFMA only %-9s operands %-14s : %7.1f TF/s  (matrix pipe busy 100 %% => clock %.2f GHz)\n", SHAPE == 0 ? "16x16x32" : "32x32x16",
+           ops == 0 ? "all zero" : (ops == 1 ? "small integers" : "random fp16"), flops / (ms * 1e-3) / 1e12, ghz);
+    fflush(stdout);
+}
+
 int main() {
     _Float16* src;
     long long* out;
@@ -154,6 +232,11 @@ int main() {
     }
     CK(hipMalloc(&out, sizeof(long long) * (1 + 256 * 8)));
     long long* host = (long long*)malloc(sizeof(long long) * (1 + 256 * 8));
+    for (int rep = 0; rep < 2; ++rep)
+        for (int ops = 0; ops < 3; ++ops) {
+            run_ops<0>(src, out, ops);
+            run_ops<1>(src, out, ops);
+        }
     run<0, 60, 0, 0>("MFMA only, free", src, out, host);
     run<0, 60, 0, 0>("MFMA only, free, random operands", src, out, host, 1);
     run<8, 60, 26, 1>("192x320 mix, drain, random ops", src, out, host, 1);
