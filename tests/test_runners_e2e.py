@@ -99,6 +99,66 @@ def test_stage1_stage2_file_formats(tmp_path):
     _check_file_formats(tmp_path, "cpu")
 
 
+def test_front_end_callable_perform_anyv2v(tmp_path):
+    """``anyv2v_amd.api.AnyV2V_I2VGenXL.perform_anyv2v`` -- the function behind ``gradio_demo.py:80-222`` / ``predict.py``: an
+    mp4 clip + an edited first frame in, ``edited_video.mp4`` out, the trajectory files on disk, deterministic in the seed, and
+    the same edited frames as assembling the steps by hand the way the reference's demo does (files read back from disk)."""
+    base = _make_workspace(tmp_path)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_emulation as emu
+    emu.install()
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    from anyv2v_amd.api import AnyV2V_I2VGenXL
+    from anyv2v_amd.mp4 import read_mp4
+    from anyv2v_amd.utils import export_to_video
+    clip = os.path.join(base, "demo", "clip")
+    frames = [Image.open(os.path.join(clip, f"{i:05d}.png")).convert("RGB") for i in range(N_FRAMES)]
+    src = export_to_video(frames, os.path.join(base, "clip.mp4"), fps=8)
+    ed = AnyV2V_I2VGenXL(model_path=os.path.join(base, "model"), device="cpu", tmp_dir=os.path.join(base, "tmp"),
+                         synthetic_encoders=True)
+    args = dict(video_path=src, video_prompt="a robot", video_negative_prompt="blurry",
+                edited_first_frame_path=os.path.join(clip, "edited_first_frame", "e.png"), conv_inj=0.25, spatial_inj=0.5,
+                temp_inj=0.75, num_inference_steps=N_STEPS, guidance_scale=9.0, ddim_init_latents_t_idx=0,
+                ddim_inversion_steps=N_STEPS, seed=7)
+    out = ed.perform_anyv2v(**args)
+    assert out.endswith(os.path.join("AnyV2V", "edited_video.mp4"))
+    vid, fps = read_mp4(out)
+    assert len(vid) == N_FRAMES and vid[0].size == (SIZE, SIZE) and fps == 8.0
+    lat_dir = os.path.join(base, "tmp", "AnyV2V", "ddim_latents")
+    assert len([f for f in os.listdir(lat_dir) if f.startswith("ddim_latents_")]) == N_STEPS
+    first = [np.asarray(f).copy() for f in vid]
+    # by hand, as gradio_demo.py does: start latent and source trajectory read back from the files
+    from anyv2v_amd.run_group_pnp_edit import init_pnp
+    from anyv2v_amd.utils import load_ddim_latents_at_t, load_image
+    pipe, sched = ed.pipe, ed.ddim_scheduler
+    sched.set_timesteps(N_STEPS)
+    lat_t = load_ddim_latents_at_t(sched.timesteps[0], ddim_latents_path=lat_dir)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    # the generator state after the inversion of the first call: replay its draws (encode_vae_video samples the posterior)
+    from anyv2v_amd.run_group_ddim_inversion import ddim_inversion
+    cfg = ed.config.inverse_config
+    cfg.output_dir = os.path.join(base, "tmp", "by_hand")
+    src_frames = read_mp4(src)[0]
+    ddim_inversion(cfg, src_frames[0], src_frames, pipe, ed.inverse_scheduler, g)
+    pipe._last_trajectory.wait()
+    torch.randn_like(lat_t)  # (random_ratio = 0: the blend draws and discards, gradio_demo.py:160)
+    init_pnp(pipe, sched, ed.config.pnp_config)
+    pipe.register_modules(scheduler=sched)
+    e1 = load_image(args["edited_first_frame_path"]).resize((SIZE, SIZE), resample=Image.Resampling.LANCZOS)
+    by_hand = pipe.sample_with_pnp(prompt="a robot", image=e1, height=SIZE, width=SIZE, num_frames=N_FRAMES,
+                                   num_inference_steps=N_STEPS, guidance_scale=9.0, negative_prompt="blurry", target_fps=8,
+                                   latents=lat_t, generator=g, return_dict=True, ddim_init_latents_t_idx=0,
+                                   ddim_inv_latents_path=cfg.output_dir, ddim_inv_prompt="", ddim_inv_1st_frame=src_frames[0]).frames[0]
+    export_to_video(by_hand, os.path.join(base, "by_hand.mp4"), fps=8)
+    hand = [np.asarray(f) for f in read_mp4(os.path.join(base, "by_hand.mp4"))[0]]
+    assert all(np.array_equal(a, b) for a, b in zip(first, hand)), "HBM trajectory hand-over != files read back"
+    # same seed -> same video
+    out2 = ed.perform_anyv2v(**args)
+    assert all(np.array_equal(a, np.asarray(b)) for a, b in zip(first, read_mp4(out2)[0]))
+
+
 def test_stage1_from_an_mp4_clip(tmp_path):
     """The reference's fallback when ``<video_dir>/<name>/%05d.png`` is missing (``run_group_ddim_inversion.py:97-105``):
     decode ``<video_dir>/<name>.mp4`` into that directory, then go on as usual."""
