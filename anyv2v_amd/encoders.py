@@ -10,7 +10,7 @@ exercised end to end without any checkpoint:
 
   vae.encode_image(pil, device, height, width) -> [1,4,h,w]      (posterior mean x scaling_factor)
   vae.encode_video(list[pil], device, height, width) -> [1,4,F,h,w]
-  vae.decode_video(latents[1,4,F,h,w], decode_chunk_size) -> float32 [1,3,F,H,W] in [-1,1];  vae.to_pil(video)
+  vae.decode_video(latents[1,4,F,h,w], decode_chunk_size) -> float32 [1,3,F,H,W] in [-1,1] (host or device);  vae.to_pil(video)
   text_encoder.encode(list[str], device, clip_skip) -> [n,77,1024]
   image_encoder.encode(pil, width, device) -> [1,1,1024]
 """
@@ -40,6 +40,20 @@ def _center_crop_wide(image: Image.Image, resolution):
 def _pil_to_tensor(img: Image.Image) -> torch.Tensor:
     a = np.asarray(img.convert("RGB"), dtype=np.float32) / 255.0
     return torch.from_numpy(a).permute(2, 0, 1)[None] * 2.0 - 1.0  # [1,3,H,W] in [-1,1]
+
+
+_U8_LUT = None
+
+
+def _pil_batch_to_device(frames: List[Image.Image], device) -> torch.Tensor:
+    """``torch.cat([_pil_to_tensor(f) for f in frames])`` with the float conversion done on ``device``: the frames cross the
+    bus as uint8 (a quarter of the bytes) and are mapped through a 256-entry table that holds exactly the values
+    ``_pil_to_tensor`` computes on the host, so the result is bit-identical to the host path."""
+    global _U8_LUT
+    if _U8_LUT is None:
+        _U8_LUT = torch.from_numpy(np.arange(256, dtype=np.float32) / 255.0) * 2.0 - 1.0
+    u8 = torch.from_numpy(np.stack([np.asarray(f.convert("RGB"), dtype=np.uint8) for f in frames]))  # [F,H,W,3]
+    return _U8_LUT.to(device)[u8.to(device).long()].permute(0, 3, 1, 2).contiguous()
 
 
 class SyntheticVAE:
@@ -75,8 +89,9 @@ class SyntheticVAE:
         return x.clamp(-1, 1)
 
     def to_pil(self, video):
-        """``tensor2vid`` (``pipeline_i2vgen_xl.py:79-97``) for one clip: [1,3,F,H,W] in [-1,1] -> list of PIL."""
-        x = ((video[0].permute(1, 2, 3, 0) + 1.0) * 127.5).round().clamp(0, 255).to(torch.uint8).numpy()
+        """``tensor2vid`` (``pipeline_i2vgen_xl.py:79-97``) for one clip: [1,3,F,H,W] in [-1,1] -> list of PIL.  The
+        quantisation runs where the tensor lives (same fp32 arithmetic either way); a device tensor crosses the bus as uint8."""
+        x = ((video[0].permute(1, 2, 3, 0) + 1.0) * 127.5).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
         return [Image.fromarray(fr) for fr in x]
 
 
@@ -109,19 +124,20 @@ class NativeVAE:
         return z * self.config.scaling_factor
 
     def encode_image(self, image, device, height, width):
-        x = _pil_to_tensor(_center_crop_wide(image, (width, height)))
+        x = _pil_batch_to_device([_center_crop_wide(image, (width, height))], device)
         return self._encode(x, device).to(torch.float16)
 
     def encode_video(self, video: List[Image.Image], device, height, width):
-        x = torch.cat([_pil_to_tensor(_center_crop_wide(f, (width, height))) for f in video])  # [F,3,H,W]
+        x = _pil_batch_to_device([_center_crop_wide(f, (width, height)) for f in video], device)  # [F,3,H,W]
         return self._encode(x, device).permute(1, 0, 2, 3)[None].to(torch.float16)
 
     def decode_video(self, latents, decode_chunk_size=None):
+        """-> float32 [1,3,F,H,W] in [-1,1] on the latents' device (as the reference's ``decode_latents`` leaves it)."""
         z = latents[0].permute(1, 0, 2, 3).float() / self.config.scaling_factor  # [F,4,h,w]
         n = z.shape[0]
         chunk = n if not decode_chunk_size else int(decode_chunk_size)
         frames = [self.model.decode(z[i:i + chunk]) for i in range(0, n, chunk)]
-        return torch.cat(frames).permute(1, 0, 2, 3)[None].float().cpu().clamp(-1, 1)  # [1,3,F,H,W]
+        return torch.cat(frames).permute(1, 0, 2, 3)[None].float().clamp(-1, 1)  # [1,3,F,H,W]
 
     to_pil = SyntheticVAE.to_pil
 

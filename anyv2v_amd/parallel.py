@@ -152,7 +152,9 @@ class FrameParallel:
         return full.reshape(B * N * Fl * HW, C)
 
     def gather_video(self, video: torch.Tensor) -> torch.Tensor:
-        """Decoded frames [1,3,F/world,H,W] (host fp32, as ``decode_video`` returns them) -> the whole clip on every rank."""
+        """Decoded frames [1,3,F/world,H,W] (fp32, host or device, as ``decode_video`` returns them) -> the whole clip on every rank."""
+        if self.host_staged and video.is_cuda:  # gloo bring-up: stage device frames through the host
+            return self.gather_video(video.cpu()).to(video.device)
         parts = [torch.empty_like(video) for _ in range(self.world)]
         if self.host_staged or not video.is_cuda:
             if self.host_staged:
