@@ -316,6 +316,32 @@ struct AGen {
     }
 };
 
+#ifndef AV_FRAG_ASM
+#define AV_FRAG_ASM 1
+#endif
+#ifndef AV_FRAG_ASM_128  // the 128-row kernel's K-tile (A/B builds)
+#define AV_FRAG_ASM_128 AV_FRAG_ASM
+#endif
+// Fragment reads of the K-tile below are issued as inline asm with hand-counted `s_waitcnt lgkmcnt(n)`: with an LDS-DMA load
+// (global_load_lds) in flight hipcc treats the LGKM counter as out of order and waits lgkmcnt(0) before every fragment use,
+// i.e. also for the fragment it has just requested two groups ahead -- the roll degenerates into issue -> full LDS latency ->
+// use (tools/wait_probe.hip reproduces it in 30 lines).  LDS reads return in order among themselves, and the DMA completes on
+// vmcnt, so the wait a use needs is "all but the reads issued after mine".
+__device__ __forceinline__ h8 lds_frag(unsigned base, int off) {  // off: a constant after unrolling (16-bit immediate)
+    h8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(off) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lgkm_wait(int n) {  // n is a constant after unrolling; the switch folds to one s_waitcnt
+    switch (n) {
+#define AV_LGW(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" ::: "memory"); break;
+        AV_LGW(0) AV_LGW(1) AV_LGW(2) AV_LGW(3) AV_LGW(4) AV_LGW(5) AV_LGW(6) AV_LGW(7) AV_LGW(8) AV_LGW(9) AV_LGW(10)
+        AV_LGW(11) AV_LGW(12) AV_LGW(13) AV_LGW(14) AV_LGW(15)
+#undef AV_LGW
+        default: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;  // (more than 15 younger reads: the counter saturates there)
+    }
+}
+
 // one K-tile (64) of MFMA work for a 64 x NF*16 wave tile: all 2*(4+NF) fragment reads are issued first, so the
 // compiler can retire them with counted lgkmcnt waits while the MFMAs of the first K-step already run (loading per
 // K-step made it emit a full lgkmcnt(0) in front of every MFMA batch).
@@ -375,6 +401,58 @@ __device__ __forceinline__ void mma_tile(f4 (&acc)[4][NF], const char* as, const
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 8 * NF - 2 * (4 + NF), 0);
     // keep the MFMAs above the caller's end-of-tile s_waitcnt (an asm "memory" clobber does not order register-only MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The same K-tile with the fragment reads as inline asm and counted waits (LDS-DMA kernel: the next tile's pieces are already in
+// flight here, so hipcc would wait lgkmcnt(0) in front of both MFMA batches, see lds_frag): K-step 0's reads, then its MFMAs
+// each waiting only for its own two fragments, K-step 1's reads slotted in one per two MFMAs.
+template <int NF>
+__device__ __forceinline__ void mma_tile_asm(f4 (&acc)[4][NF], const char* as, const char* bs, int wr, int wc, int lane) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int c0 = ((0 * 4 + lq) ^ (l15 & 7)) * 16, c1 = ((1 * 4 + lq) ^ (l15 & 7)) * 16;
+    const char* a0 = as + (wr * 64 + l15) * 128;
+    const char* b0 = bs + (wc * NF * 16 + l15) * 128;
+    const unsigned abase[2] = {(unsigned)(size_t)(a0 + c0), (unsigned)(size_t)(a0 + c1)};
+    const unsigned bbase[2] = {(unsigned)(size_t)(b0 + c0), (unsigned)(size_t)(b0 + c1)};
+    h8 af[2][4], bf[2][NF];
+    int seq = 0, done = 0, a_seq[2][4] = {}, b_seq[2][NF] = {};
+#define AV_RA(ks, mf) (af[ks][mf] = lds_frag(abase[ks], (mf) * 2048), a_seq[ks][mf] = ++seq)
+#define AV_RB(ks, nf) (bf[ks][nf] = lds_frag(bbase[ks], (nf) * 2048), b_seq[ks][nf] = ++seq)
+    AV_RA(0, 0);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) AV_RB(0, nf);
+#pragma unroll
+    for (int mf = 1; mf < 4; ++mf) AV_RA(0, mf);
+    __builtin_amdgcn_sched_barrier(0);
+    int slot = 0;  // K-step 1 reads issued so far, in the order a(1,0), b(1,0..NF-1), a(1,1..3)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int need = a_seq[ks][mf] > b_seq[ks][nf] ? a_seq[ks][mf] : b_seq[ks][nf];
+                if (need > done) {
+                    lgkm_wait(seq - need);
+                    done = need;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], acc[mf][nf], 0, 0, 0);
+                if (ks == 0 && ((mf * NF + nf) & 1) && slot < 4 + NF) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (slot == 0)
+                        AV_RA(1, 0);
+                    else if (slot <= NF)
+                        AV_RB(1, slot - 1);
+                    else
+                        AV_RA(1, slot - NF);
+                    ++slot;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#undef AV_RA
+#undef AV_RB
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -475,7 +553,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK p) {
         const int cur = kt & 1;
         const bool has_next = kt + 1 < nk;
         if (has_next && KO != 3) issue(cur ^ 1, KO != 2);
-        mma_tile<NF, KO>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
+        if constexpr (GLDS && KO == 0 && AV_FRAG_ASM_128)
+            mma_tile_asm<NF>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
+        else
+            mma_tile<NF, KO>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
         if constexpr (TRACE) if (tid == 0 && kt < 8) tr[4 + kt] = (long long)__builtin_amdgcn_s_memtime();
         if constexpr (!GLDS) {
             if (has_next) commit(cur ^ 1);
@@ -518,29 +599,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK p) {
 //    live next to the 160 accumulators, instead of 112 when hipcc hoists all 28 reads of the tile to the top);
 //  * the next tile's LDS-DMA pieces are threaded through the first half of the MFMA stream, one per fragment group
 //    (they have to sit here textually: an LDS-DMA load writes LDS, so hipcc never moves it across a ds_read).
-#ifndef AV_FRAG_ASM
-#define AV_FRAG_ASM 1
-#endif
-// Fragment reads of the K-tile below are issued as inline asm with hand-counted `s_waitcnt lgkmcnt(n)`: with an LDS-DMA load
-// (global_load_lds) in flight hipcc treats the LGKM counter as out of order and waits lgkmcnt(0) before every fragment use,
-// i.e. also for the fragment it has just requested two groups ahead -- the roll degenerates into issue -> full LDS latency ->
-// use (tools/wait_probe.hip reproduces it in 30 lines).  LDS reads return in order among themselves, and the DMA completes on
-// vmcnt, so the wait a use needs is "all but the reads issued after mine".
-__device__ __forceinline__ h8 lds_frag(unsigned base, int off) {  // off: a constant after unrolling (16-bit immediate)
-    h8 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(off) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lgkm_wait(int n) {  // n is a constant after unrolling; the switch folds to one s_waitcnt
-    switch (n) {
-        case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
-    }
-}
-
 template <int MF, typename PieceFn>
 __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, const char* bs, int wr, int wc, int lane,
                                              PieceFn&& piece) {
