@@ -215,6 +215,101 @@ static void run_ops(const _Float16* src, long long* out, int ops) {
     fflush(stdout);
 }
 
+// ---- one wave per SIMD (4 waves, 512 registers each: accumulators can live in AGPRs), 32x32x16 MFMAs: the 192 x 320 tile as a
+//      2 x 2 grid of 96 x 160 wave tiles = 15 accumulator tiles; per K-tile and wave 60 MFMAs (32 cycles each), 32 fragment reads,
+//      16 LDS-DMA pieces.  SYNC as above.
+template <int NDMA, int NREAD, int SYNC>
+__global__ __launch_bounds__(256) void probe4(const _Float16* src, long long* out, int iters, int rnd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned frag_off = l15 * 128 + ((lq ^ (l15 & 7)) * 16);
+    const _Float16* base = src + ((size_t)(blockIdx.x & 63) * 512 * 1024) + (size_t)(w * 64 + lane) * 8;
+    f16v acc[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    h8 a[3], b[5];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[j][e] = (_Float16)(float)(lane + e + j);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[j][e] = (_Float16)(float)(lane - e * j);
+    if (rnd) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] = *(const h8*)(src + (size_t)(j * 64 + lane) * 8 + 4096 * w);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) b[j] = *(const h8*)(src + (size_t)((3 + j) * 64 + lane) * 8 + 4096 * w);
+    }
+    __syncthreads();
+    int st_r = 1;
+    for (int it = 0; it < iters; ++it) {
+        const _Float16* s = base + (size_t)(it & 31) * 8192;
+        char* wst = smem + (it & 1) * 65536 + w * 1024;
+        const unsigned rbase = (unsigned)(size_t)(smem + st_r * 32768) + frag_off;
+        int ndma = 0, nread = 0;
+#pragma unroll
+        for (int g = 0; g < 20; ++g) {  // 4 k-steps x 5 column tiles: 3 MFMAs (the row tiles) per group
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[(g % 5) * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[g % 5], a[j], acc[(g % 5) * 3 + j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            while (nread * 20 < (g + 1) * NREAD) {
+                h8 v;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(rbase), "n"((nread % 23) * 2048) : "memory");
+                asm volatile("" ::"v"(v));
+                ++nread;
+            }
+            if (ndma < NDMA) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + ndma * 2048),
+                                                 (__attribute__((address_space(3))) void*)(wst + ndma * 4096), 16, 0, 0);
+                ++ndma;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (SYNC == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else if constexpr (SYNC == 2) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        st_r = st_r == 2 ? 0 : st_r + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) sum += acc[i][0] + acc[i][15];
+    if (sum == 12345.678f) out[0] = (long long)smem[lane];
+}
+
+template <int NDMA, int NREAD, int SYNC>
+static void run4(const char* what, const _Float16* src, long long* out, int rnd) {
+    const int iters = 400, blocks = 256;
+    const size_t lds = 2 * 65536;
+    CK(hipFuncSetAttribute((const void*)probe4<NDMA, NREAD, SYNC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((probe4<NDMA, NREAD, SYNC>), dim3(blocks), dim3(256), lds, 0, src, out, iters, rnd);
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    const double tf = 2.0 * 32 * 32 * 16 * 60 * 4.0 * blocks * iters / (ms * 1e-3) / 1e12;
+    printf("%-44s dma=%2d mfma=60 (32x32x16) reads=%2d sync=%d %s : %7.1f ns/K-tile  %6.0f TF/s\n", what, NDMA, NREAD, SYNC,
+           rnd ? "random ops" : "small ints", ms * 1e6 / iters, tf);
+    fflush(stdout);
+}
+
 int main() {
     _Float16* src;
     long long* out;
@@ -237,6 +332,14 @@ int main() {
             run_ops<0>(src, out, ops);
             run_ops<1>(src, out, ops);
         }
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        run4<0, 0, 0>("1 wave/SIMD, MFMA only, free", src, out, rnd);
+        run4<0, 32, 0>("1 wave/SIMD, MFMA + reads, free", src, out, rnd);
+        run4<16, 32, 0>("1 wave/SIMD, 192x320 mix, free", src, out, rnd);
+        run4<16, 32, 1>("1 wave/SIMD, 192x320 mix, drain", src, out, rnd);
+        run4<16, 32, 2>("1 wave/SIMD, 192x320 mix, ring", src, out, rnd);
+        run<8, 60, 26, 1>("2 waves/SIMD 192x320 mix, drain (today)", src, out, host, rnd);
+    }
     run<0, 60, 0, 0>("MFMA only, free", src, out, host);
     run<0, 60, 0, 0>("MFMA only, free, random operands", src, out, host, 1);
     run<8, 60, 26, 1>("192x320 mix, drain, random ops", src, out, host, 1);
