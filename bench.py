@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 STEPS_PER_STAGE = 50          # BASELINE config 2/3: 50 inversion steps, 50 edit steps
 FRAMES, LAT = 16, 64          # 16 frames, 512/8 = 64
 PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+# context only (frac is always quoted against the nominal peak above): what a stream of nothing but MFMAs sustains on this part with
+# random fp16 operands, all 1024 SIMDs busy -- the matrix pipe is power limited (tools/ktile_probe.hip, profiles/r02_ktile_probe.txt)
+SUSTAINED_NOTE_32 = {"mfma_only_random_fp16_operands_tflops": 1720, "mfma_shape": "32x32x16", "source": "profiles/r02_ktile_probe.txt"}
+SUSTAINED_NOTE_16 = {"mfma_only_random_fp16_operands_tflops": 1920, "mfma_shape": "16x16x32", "source": "profiles/r02_ktile_probe.txt"}
 
 
 def synthetic_clip(device, seed):
@@ -113,6 +117,7 @@ def roofline_spatial_attention(device, pnp=False):
          "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src}
     if pnp:
         r["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
+    r["context"] = SUSTAINED_NOTE_32
     return r
 
 
@@ -131,7 +136,8 @@ def roofline_conv(device):
     traffic, src = measured_traffic("gemm_big_kernel<3, false, 1")
     return {"bound": "mfma", "kernel": "gemm_big_kernel<3,false,conv2d> (conv3x3 320->320 @64x64, N=48; persistent 192x320 tiles)", "achieved": round(ach, 2),
             "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src}
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src,
+            "context": SUSTAINED_NOTE_16}
 
 
 def effective_cpus() -> int:
