@@ -72,9 +72,40 @@ class _StepEngine:
                                       cond["image_embeddings"])
         # CFG batches [.., negative, positive]: the last two slots hold the same latent (dup_slots) and -- checked here,
         # once -- the same image latents and fps, so the UNet may share their stem (exact; unet._forward_core)
+        self._shared_stem_requested = bool(shared_stem)
+        self.nosrc = None  # the [negative, editing]-only engine of a PnP edit (shares `sample[1:]`), built on demand
         self.ctx.shared_stem = bool(shared_stem and B >= 2 and os.environ.get("ANYV2V_SHARED_STEM", "1") == "1"
                                     and torch.equal(cond["image_latents"][B - 2], cond["image_latents"][B - 1])
                                     and torch.equal(cond["fps"][B - 2], cond["fps"][B - 1]))
+
+    def rebind(self, sample_init, cond) -> bool:
+        """Point this engine (its static buffers and captured graphs) at another clip of the same geometry: the new latents go
+        into ``self.sample``, the new clip's step-invariant tensors are computed by ``_prepare_clip`` and copied INTO the
+        context tensors the graphs were captured on.  False if the clip cannot run on this engine (different shared-stem
+        decision): the caller then builds a fresh one."""
+        B, _, F, H, W = self.sample.shape
+        shared = bool(self._shared_stem_requested and B >= 2 and os.environ.get("ANYV2V_SHARED_STEM", "1") == "1"
+                      and torch.equal(cond["image_latents"][B - 2], cond["image_latents"][B - 1])
+                      and torch.equal(cond["fps"][B - 2], cond["fps"][B - 1]))
+        if shared != self.ctx.shared_stem:
+            return False
+        if sample_init.data_ptr() != self.sample.data_ptr():
+            self.sample.copy_(sample_init)
+        fresh = self.unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
+                                        cond["image_embeddings"])
+        if fresh is not self.ctx:
+            if (fresh.Sk, fresh.F) != (self.ctx.Sk, self.ctx.F):
+                return False
+            for name, new in vars(fresh).items():
+                old = getattr(self.ctx, name, None)
+                if torch.is_tensor(new) and name not in ("stats", "t_buf"):
+                    if not torch.is_tensor(old) or old.shape != new.shape or old.dtype != new.dtype:
+                        return False
+                    old.copy_(new)
+            self.ctx.key, self.ctx._keepalive = fresh.key, fresh._keepalive
+            self.unet._ctx = self.ctx
+        self.cond = cond
+        return True
 
     def _body(self):
         vtok = self.unet._forward_core(self.ctx, self.sample)
@@ -112,6 +143,7 @@ class I2VGenXLPipeline:
         self.vae_scale_factor = 8
         self._guidance_scale = 1.0
         self._device = torch.device("cpu")
+        self._engines: Dict[tuple, _StepEngine] = {}  # step engines (static buffers + HIP graphs) kept across clips, LRU
 
     # ------------------------------------------------------------------ construction / plumbing
     @classmethod
@@ -306,6 +338,24 @@ class I2VGenXLPipeline:
                 negative_prompt_embeds.to(device, torch.float16), image_embeddings.to(device, torch.float16),
                 image_latents.to(device, torch.float16))
 
+    def _engine(self, tag, sample, cond, **kw) -> _StepEngine:
+        """A step engine for this loop: a new one, or -- for the next clip of the same geometry in a multi-clip job -- the one
+        captured for the previous clip, re-pointed at the new clip (``_StepEngine.rebind``): graph capture and its warm-up
+        forward (~0.25 s per 16 x 512^2 clip) are paid once per process instead of once per clip.  ANYV2V_ENGINE_CACHE=0
+        switches it off."""
+        if os.environ.get("ANYV2V_ENGINE_CACHE", "1") != "1" or getattr(self.unet, "frame_parallel", None) is not None:
+            return _StepEngine(self, sample, cond, **kw)
+        key = (tag, tuple(sample.shape), str(sample.device), tuple(cond["encoder_hidden_states"].shape), kw.get("b_unc"),
+               kw.get("b_cond"), float(kw.get("guidance")), tuple(kw.get("dup_slots")), bool(kw.get("shared_stem", False)),
+               _use_graphs(), pnp_utils.has_foreign_hooks(self.unet), id(self.unet))
+        eng = self._engines.pop(key, None)
+        if eng is None or not eng.rebind(sample, cond):
+            eng = _StepEngine(self, sample, cond, **kw)
+        self._engines[key] = eng  # most recently used last
+        while len(self._engines) > 4:
+            self._engines.pop(next(iter(self._engines)))
+        return eng
+
     # ------------------------------------------------------------------ A1: DDIM inversion (:1197-1451)
     @torch.no_grad()
     def invert(self, prompt=None, image=None, height: Optional[int] = 704, width: Optional[int] = 1280,
@@ -341,8 +391,9 @@ class I2VGenXLPipeline:
         sample = latents.repeat(nb, 1, 1, 1, 1).contiguous()
         cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
                     image_embeddings=ie_all.contiguous())
-        eng = _StepEngine(self, sample, cond, b_unc=0 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
-                          dup_slots=range(nb - 1))
+        eng = self._engine("inv", sample, cond, b_unc=0 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
+                           dup_slots=range(nb - 1))
+        sample = eng.sample  # (a cached engine keeps its own static buffer; the latents were copied into it)
         ts = [int(t) for t in timesteps.tolist()]
         t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, nb).contiguous()
         coef_table = self.scheduler.coefficient_table(ts, device)
@@ -400,8 +451,9 @@ class I2VGenXLPipeline:
         sample = latents.repeat(nb, 1, 1, 1, 1).contiguous()
         cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
                     image_embeddings=ie_all.contiguous())
-        eng = _StepEngine(self, sample, cond, b_unc=0 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
-                          dup_slots=range(nb - 1), shared_stem=cfg_on)
+        eng = self._engine("cfg", sample, cond, b_unc=0 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
+                           dup_slots=range(nb - 1), shared_stem=cfg_on)
+        sample = eng.sample
         t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, nb).contiguous()
         coef_table = self.scheduler.coefficient_table(ts, device)
         for i, t in enumerate(ts):
@@ -463,8 +515,9 @@ class I2VGenXLPipeline:
         sample = latents.repeat(nb, 1, 1, 1, 1).contiguous()
         cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
                     image_embeddings=ie_all.contiguous())
-        eng = _StepEngine(self, sample, cond, b_unc=1 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
-                          dup_slots=range(1, nb - 1), shared_stem=cfg_on)
+        eng = self._engine("pnp", sample, cond, b_unc=1 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
+                           dup_slots=range(1, nb - 1), shared_stem=cfg_on)
+        sample = eng.sample
         # source trajectory resident in HBM (in-memory hand-off from invert(), or read once from the reference's files)
         if isinstance(ddim_inv_latents_path, LatentTrajectory):
             traj = ddim_inv_latents_path
@@ -477,6 +530,7 @@ class I2VGenXLPipeline:
         # slots only.  Both engines share the `sample` storage, so they can alternate freely.
         skip_src = cfg_on and nb == 3 and os.environ.get("ANYV2V_SRC_SKIP", "1") == "1"
         eng_nosrc = None
+        nosrc_bound = False
         for i, t in enumerate(ts):
             pnp_utils.register_time(self, t)  # host-side only: python int, no device sync (:1143)
             state = pnp_utils.injection_state(self)
@@ -486,10 +540,12 @@ class I2VGenXLPipeline:
                 raise ValueError("PnP feature injection needs classifier-free guidance (guidance_scale > 1): the hooks "
                                  "assume the 3-way batch [source, negative, editing]")
             if skip_src and not any(state):
-                if eng_nosrc is None:
+                if not nosrc_bound:  # built once per engine (it lives on `sample[1:]`), re-pointed at this clip once per call
                     cond2 = {k: v[1:].contiguous() for k, v in cond.items()}
-                    eng_nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale, dup_slots=[0],
-                                            shared_stem=True)
+                    if eng.nosrc is None or not eng.nosrc.rebind(sample[1:], cond2):
+                        eng.nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale,
+                                                dup_slots=[0], shared_stem=True)
+                    eng_nosrc, nosrc_bound = eng.nosrc, True
                 eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-nosrc",))
             else:
                 sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)

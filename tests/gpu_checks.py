@@ -966,6 +966,82 @@ def check_unet_vs_oracle(cfg_name="mini", B=3, Fr=4, hw=8, with_pnp=True, tol=3e
     return out
 
 
+def check_engine_reuse_across_clips():
+    """Multi-clip jobs keep the step engines (static buffers + HIP graphs) and re-point them at the next clip
+    (``pipeline._engine`` / ``_StepEngine.rebind``): clip B through engines captured for clip A must be BIT-equal to clip B on a
+    fresh pipeline -- any step-invariant tensor left over from clip A would show here.  Covers inversion, the PnP edit with its
+    [negative, editing]-only engine (schedules ending early) and the plain CFG loop."""
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    out = []
+    native, _, ocfg = build_pair("mini", 1234)
+    Fr, hw, n_steps = 4, 8, 6
+    h = lambda x: x.half().to(DEV)
+
+    def clip(seed):
+        torch.manual_seed(seed)
+        inp = config1_inputs(ocfg, 3, Fr, hw)
+        return h(inp["sample"][:1]) * (1.0 + 0.1 * seed), h(inp["encoder_hidden_states"]) + 0.05 * seed, h(inp["image_embeddings"]) * (1 + 0.2 * seed), \
+            h(inp["image_latents"]) - 0.1 * seed
+
+    def run(pipe, c):
+        lat0, ehs, ie, il = c
+        pnp_utils.clear_time(pipe)
+        pipe.register_modules(scheduler=DDIMInverseScheduler())
+        traj = pipe.invert(prompt_embeds=ehs[:1], image_embeddings=ie[:1], image_latents=il[:1], height=hw * 8, width=hw * 8,
+                           num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0, target_fps=8, latents=lat0,
+                           return_trajectory=True)
+        T = max(traj.keys())
+        sched = DDIMScheduler()
+        sched.set_timesteps(n_steps)
+        k = lambda r: sched.timesteps[: int(n_steps * r)]
+        pnp_utils.register_conv_injection(pipe, k(0.2))
+        pnp_utils.register_spatial_attention_pnp(pipe, k(0.4))
+        pnp_utils.register_temp_attention_pnp(pipe, k(0.5))
+        pipe.register_modules(scheduler=sched)
+        ed = pipe.sample_with_pnp(prompt_embeds=ehs[2:3], negative_prompt_embeds=ehs[1:2], image_embeddings=ie[2:3],
+                                  image_latents=il[2:3], height=hw * 8, width=hw * 8, num_frames=Fr, num_inference_steps=n_steps,
+                                  guidance_scale=9.0, target_fps=8, latents=traj[T].clone(), output_type="latent",
+                                  ddim_init_latents_t_idx=0, ddim_inv_latents_path=traj, ddim_inv_prompt_embeds=ehs[:1],
+                                  ddim_inv_image_embeddings=ie[:1], ddim_inv_image_latents=il[:1]).frames
+        pnp_utils.clear_time(pipe)
+        rec = pipe(prompt_embeds=ehs[:1], negative_prompt_embeds=ehs[1:2], image_embeddings=ie[:1], image_latents=il[:1],
+                   height=hw * 8, width=hw * 8, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=9.0, target_fps=8,
+                   latents=traj[T].clone(), output_type="latent", ddim_init_latents_t_idx=0).frames
+        return traj[T].clone(), ed.clone(), rec.clone()
+
+    saved = os.environ.get("ANYV2V_ENGINE_CACHE")
+    try:
+        os.environ["ANYV2V_ENGINE_CACHE"] = "1"
+        pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+        pipe._device = torch.device(DEV)
+        a1 = run(pipe, clip(1))
+        engines = {k: id(v) for k, v in pipe._engines.items()}
+        b1 = run(pipe, clip(2))
+        reused = {k: id(v) for k, v in pipe._engines.items()} == engines and len(engines) == 3
+        a2 = run(pipe, clip(1))
+        os.environ["ANYV2V_ENGINE_CACHE"] = "0"
+        fresh = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+        fresh._device = torch.device(DEV)
+        b0 = run(fresh, clip(2))
+        a0 = run(fresh, clip(1))
+    finally:
+        if saved is None:
+            os.environ.pop("ANYV2V_ENGINE_CACHE", None)
+        else:
+            os.environ["ANYV2V_ENGINE_CACHE"] = saved
+    out.append(dict(name="engines of clip A are the ones clip B runs on (3 kept: inversion, PnP edit, CFG)", err=0.0 if reused else 1.0,
+                    l2=0.0, tol=0.0, ok=bool(reused)))
+    for tag, got, ref in (("clip B on clip A's engines", b1, b0), ("clip A again after clip B", a2, a0), ("clip A, first use", a1, a0)):
+        for name, g, r in zip(("inversion", "PnP edit", "CFG reconstruction"), got, ref):
+            out.append(_res(f"engine reuse: {tag}: {name} == fresh pipeline (bitwise)", g, r.float(), 0.0))
+    differs = float((b0[1].float() - a0[1].float()).abs().max()) > 1e-3
+    out.append(dict(name="engine reuse: the two clips do differ", err=0.0 if differs else 1.0, l2=0.0, tol=0.0, ok=bool(differs)))
+    return out
+
+
+
 def check_loops_mini():
     """Multi-step: inversion -> PnP edit with the pipeline (HIP graphs) vs the oracle loops; plus graph == eager."""
     from anyv2v_amd.pipeline import I2VGenXLPipeline

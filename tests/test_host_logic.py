@@ -71,6 +71,10 @@ def test_pipeline_loops_vs_oracle(cpu_ops):
     _ok(gc.check_loops_mini())
 
 
+def test_step_engines_are_reused_across_clips_without_stale_state(cpu_ops):
+    _ok(gc.check_engine_reuse_across_clips())
+
+
 def test_kernel_check_references_are_self_consistent(cpu_ops):
     """The references used by the gpu kernel tests agree with the op contracts (so a gpu failure is a kernel bug)."""
     for f in (gc.check_gemm, gc.check_conv, gc.check_norms, gc.check_attention, gc.check_elementwise):
