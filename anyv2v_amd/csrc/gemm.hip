@@ -316,6 +316,9 @@ struct AGen {
     }
 };
 
+#ifndef AV_TRACE_TILE  // experiments build: which tile of every block (0 = its first) the phase timestamps are taken from
+#define AV_TRACE_TILE 0
+#endif
 #ifndef AV_FRAG_ASM
 #define AV_FRAG_ASM 1
 #endif
@@ -735,11 +738,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
         }
 
         for (int kt = 0; kt < nk; ++kt) {
-            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 2 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
+            if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 2 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             if (kt > 0 || !landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt == 3) p.trace[(size_t)blockIdx.x * 32 + 29] = (long long)__builtin_amdgcn_s_memtime();
+            if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G && kt == 3) p.trace[(size_t)blockIdx.x * 32 + 29] = (long long)__builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();  // K-tile kt landed for everyone; everyone is done with the other stage
-            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 3 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
+            if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 3 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             const bool last = kt + 1 == nk;
             if (last && has_next) producer_start(next_tile);  // the pieces below then fetch K-tile 0 of the next tile
             const bool fetch = !last || has_next;
@@ -751,14 +754,16 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
                 else
                     glds16(fetch ? bptr + (i - MF) * brow : p.zeros, st + A_BYTES + ((i - MF) * 512 + w * 64) * 16);
             });
-            if constexpr (TRACE) if (tid == 0 && tile == b0 && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 4 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
+            if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 4 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             if (fetch) advance();
             stage ^= 1;
         }
-        if constexpr (TRACE) if (tid == 0 && tile == b0) p.trace[(size_t)blockIdx.x * 32 + 26] = (long long)__builtin_amdgcn_s_memtime();
+        if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G) p.trace[(size_t)blockIdx.x * 32 + 26] = (long long)__builtin_amdgcn_s_memtime();
         // `stage` now names the buffer holding the prefetched K-tile 0 of the next tile; stage ^ 1 was just consumed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // settle the prefetch BEFORE the stores below enter the queue
+        if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G) p.trace[(size_t)blockIdx.x * 32 + 30] = (long long)__builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();                     // every wave is done reading the consumed stage
+        if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G) p.trace[(size_t)blockIdx.x * 32 + 31] = (long long)__builtin_amdgcn_s_memtime();
         landed = true;
         rederive = true;
 
@@ -856,7 +861,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
         }
 
         if constexpr (TRACE) {
-            if (tid == 0 && tile == b0) {
+            if (tid == 0 && tile == b0 + AV_TRACE_TILE * G) {
                 p.trace[(size_t)blockIdx.x * 32 + 27] = (long long)__builtin_amdgcn_s_memtime();
                 p.trace[(size_t)blockIdx.x * 32 + 28] = nk;
             }

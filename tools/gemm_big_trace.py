@@ -46,15 +46,19 @@ def run(tag, M, N, K, mode=0, act=0, conv=None, temporal=None, res=False):
     nblk = min(256, ((M + 191) // 192) * (N // 320))
     t = ws.view(torch.int64)[: nblk * 32].cpu().numpy().reshape(nblk, 32)
     nk = int(t[0, 28])
+    if nk == 0:  # (the traced tile index does not exist for this launch: AV_TRACE_TILE rounds per block needed)
+        print(f'{tag}: no traced tile', flush=True)
+        return
     kk = min(nk, 8)
     wait = np.stack([t[:, 3 + 3 * k] - t[:, 2 + 3 * k] for k in range(kk)], 1)
     mma = np.stack([t[:, 4 + 3 * k] - t[:, 3 + 3 * k] for k in range(kk)], 1)
     epi = t[:, 27] - t[:, 26]
+    settle, bar, body = (t[:, 30] - t[:, 26]).mean(), (t[:, 31] - t[:, 30]).mean(), (t[:, 27] - t[:, 31]).mean()
     vm3 = (t[:, 29] - t[:, 2 + 9]).mean() if nk > 3 else -1
     tiles = ((M + 191) // 192) * (N // 320)
     s = (f"{tag}: M={M} N={N} K={K}: {us:.1f} us ({2.0 * M * N * K / us / 1e6:.0f} TF/s), {tiles} tiles / {nblk} blocks, {nk} K-tiles; "
          f"per K-tile (ticks): wait+barrier [" + " ".join(f"{x:.0f}" for x in wait.mean(0)) + "]  MFMA stream [" +
-         " ".join(f"{x:.0f}" for x in mma.mean(0)) + f"]  (MFMA floor 2 waves/SIMD: {120 * 12.4:.0f}); of K-tile 3's wait, vmcnt(0) took {vm3:.0f} (wave 0); epilogue {epi.mean():.0f} ticks")
+         " ".join(f"{x:.0f}" for x in mma.mean(0)) + f"]  (MFMA floor 2 waves/SIMD: {120 * 12.4:.0f}); of K-tile 3's wait, vmcnt(0) took {vm3:.0f} (wave 0); epilogue {epi.mean():.0f} ticks = prefetch settle {settle:.0f} + barrier {bar:.0f} + convert/turn/store {body:.0f}")
     lines.append(s)
     print(s, flush=True)
 

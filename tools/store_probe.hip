@@ -38,8 +38,8 @@ __global__ void probe(_Float16* dst, long long* out, int iters, size_t bytes_per
 }
 
 template <int PATTERN, bool NT>
-static void run(_Float16* dst, long long* out, long long* host, int waves, const char* tag) {
-    const int blocks = 256, iters = 600;
+static void run(_Float16* dst, long long* out, long long* host, int waves, const char* tag, int blocks = 256) {
+    const int iters = 600;
     const size_t bpb = (size_t)iters * waves * 1024 * 2;
     for (int rep = 0; rep < 2; ++rep) {
         hipLaunchKernelGGL((probe<PATTERN, NT>), dim3(blocks), dim3(waves * 64), 0, 0, dst, out, iters, bpb);
@@ -49,7 +49,7 @@ static void run(_Float16* dst, long long* out, long long* host, int waves, const
     double s = 0;
     for (int i = 0; i < blocks * waves; ++i) s += (double)host[i];
     const double ticks = s / (blocks * waves);
-    printf("%-36s waves/CU=%2d: %8.0f ticks for %d KiB per CU -> %5.1f B/tick/CU\n", tag, waves, ticks, iters * waves,
+    printf("%-36s CUs=%3d waves/CU=%2d: %8.0f ticks for %d KiB per CU -> %5.1f B/tick/CU\n", tag, blocks, waves, ticks, iters * waves,
            iters * waves * 1024.0 / ticks);
 }
 
@@ -65,6 +65,11 @@ int main() {
         run<1, false>(dst, out, host, waves, "320-byte segments, half rows only");
         run<2, false>(dst, out, host, waves, "320-byte halves by wave pairs");
         run<0, true>(dst, out, host, waves, "contiguous, non-temporal");
+    }
+    // how much of that is the CU's own write path and how much the HBM shared by all CUs: fewer CUs storing at once
+    for (int blocks = 8; blocks <= 256; blocks *= 2) {
+        run<0, false>(dst, out, host, 8, "contiguous 1 KiB pieces", blocks);
+        run<2, false>(dst, out, host, 8, "320-byte halves by wave pairs", blocks);
     }
     return 0;
 }
