@@ -99,16 +99,17 @@ def test_stage1_stage2_file_formats(tmp_path):
     _check_file_formats(tmp_path, "cpu")
 
 
-def test_front_end_callable_perform_anyv2v(tmp_path):
+def _check_front_end_callable(tmp_path, device):
     """``anyv2v_amd.api.AnyV2V_I2VGenXL.perform_anyv2v`` -- the function behind ``gradio_demo.py:80-222`` / ``predict.py``: an
     mp4 clip + an edited first frame in, ``edited_video.mp4`` out, the trajectory files on disk, deterministic in the seed, and
     the same edited frames as assembling the steps by hand the way the reference's demo does (files read back from disk)."""
     base = _make_workspace(tmp_path)
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import cpu_ops_emulation as emu
-    emu.install()
-    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    if device == "cpu":  # TEST-ONLY emulation of the C-ABI ops; on a GPU: the HIP library and HIP graphs
+        import cpu_ops_emulation as emu
+        emu.install()
+        os.environ["ANYV2V_NO_GRAPH"] = "1"
     torch.set_grad_enabled(False)
     from anyv2v_amd.api import AnyV2V_I2VGenXL
     from anyv2v_amd.mp4 import read_mp4
@@ -116,7 +117,7 @@ def test_front_end_callable_perform_anyv2v(tmp_path):
     clip = os.path.join(base, "demo", "clip")
     frames = [Image.open(os.path.join(clip, f"{i:05d}.png")).convert("RGB") for i in range(N_FRAMES)]
     src = export_to_video(frames, os.path.join(base, "clip.mp4"), fps=8)
-    ed = AnyV2V_I2VGenXL(model_path=os.path.join(base, "model"), device="cpu", tmp_dir=os.path.join(base, "tmp"),
+    ed = AnyV2V_I2VGenXL(model_path=os.path.join(base, "model"), device=device, tmp_dir=os.path.join(base, "tmp"),
                          synthetic_encoders=True)
     args = dict(video_path=src, video_prompt="a robot", video_negative_prompt="blurry",
                 edited_first_frame_path=os.path.join(clip, "edited_first_frame", "e.png"), conv_inj=0.25, spatial_inj=0.5,
@@ -135,7 +136,7 @@ def test_front_end_callable_perform_anyv2v(tmp_path):
     pipe, sched = ed.pipe, ed.ddim_scheduler
     sched.set_timesteps(N_STEPS)
     lat_t = load_ddim_latents_at_t(sched.timesteps[0], ddim_latents_path=lat_dir)
-    g = torch.Generator(device="cpu").manual_seed(7)
+    g = torch.Generator(device=device).manual_seed(7)
     # the generator state after the inversion of the first call: replay its draws (encode_vae_video samples the posterior)
     from anyv2v_amd.run_group_ddim_inversion import ddim_inversion
     cfg = ed.config.inverse_config
@@ -143,13 +144,13 @@ def test_front_end_callable_perform_anyv2v(tmp_path):
     src_frames = read_mp4(src)[0]
     ddim_inversion(cfg, src_frames[0], src_frames, pipe, ed.inverse_scheduler, g)
     pipe._last_trajectory.wait()
-    torch.randn_like(lat_t)  # (random_ratio = 0: the blend draws and discards, gradio_demo.py:160)
+    torch.randn_like(lat_t.to(device))  # (random_ratio = 0: the blend draws and discards, gradio_demo.py:160)
     init_pnp(pipe, sched, ed.config.pnp_config)
     pipe.register_modules(scheduler=sched)
     e1 = load_image(args["edited_first_frame_path"]).resize((SIZE, SIZE), resample=Image.Resampling.LANCZOS)
     by_hand = pipe.sample_with_pnp(prompt="a robot", image=e1, height=SIZE, width=SIZE, num_frames=N_FRAMES,
                                    num_inference_steps=N_STEPS, guidance_scale=9.0, negative_prompt="blurry", target_fps=8,
-                                   latents=lat_t, generator=g, return_dict=True, ddim_init_latents_t_idx=0,
+                                   latents=lat_t.to(device), generator=g, return_dict=True, ddim_init_latents_t_idx=0,
                                    ddim_inv_latents_path=cfg.output_dir, ddim_inv_prompt="", ddim_inv_1st_frame=src_frames[0]).frames[0]
     export_to_video(by_hand, os.path.join(base, "by_hand.mp4"), fps=8)
     hand = [np.asarray(f) for f in read_mp4(os.path.join(base, "by_hand.mp4"))[0]]
@@ -157,6 +158,16 @@ def test_front_end_callable_perform_anyv2v(tmp_path):
     # same seed -> same video
     out2 = ed.perform_anyv2v(**args)
     assert all(np.array_equal(a, np.asarray(b)) for a, b in zip(first, read_mp4(out2)[0]))
+
+
+def test_front_end_callable_perform_anyv2v(tmp_path):
+    _check_front_end_callable(tmp_path, "cpu")
+
+
+@pytest.mark.gpu
+def test_front_end_callable_on_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    _check_front_end_callable(tmp_path, "cuda")
 
 
 def test_stage1_from_an_mp4_clip(tmp_path):
