@@ -345,7 +345,9 @@ class I2VGenXLPipeline:
         switches it off."""
         if os.environ.get("ANYV2V_ENGINE_CACHE", "1") != "1" or getattr(self.unet, "frame_parallel", None) is not None:
             return _StepEngine(self, sample, cond, **kw)
-        key = (tag, tuple(sample.shape), str(sample.device), tuple(cond["encoder_hidden_states"].shape), kw.get("b_unc"),
+        if not self.unet._packed:
+            self.unet.pack()  # (weights loaded / moved since the last call: new packed tensors, engines of the old ones are stale)
+        key = (tag, self.unet._pack_gen, tuple(sample.shape), str(sample.device), tuple(cond["encoder_hidden_states"].shape), kw.get("b_unc"),
                kw.get("b_cond"), float(kw.get("guidance")), tuple(kw.get("dup_slots")), bool(kw.get("shared_stem", False)),
                _use_graphs(), pnp_utils.has_foreign_hooks(self.unet), id(self.unet))
         eng = self._engines.pop(key, None)

@@ -714,6 +714,7 @@ class I2VGenXLUNet(nn.Module):
         self.conv_act = SiLU()
         self.conv_out = Conv2d(boc[0], cfg.out_channels, 3, padding=1)
         self._packed = False
+        self._pack_gen = 0  # bumped by every pack(): captured graphs point at the packed tensors of one generation
         self._ctx = _Ctx()
         self.frame_parallel = None
 
@@ -763,6 +764,7 @@ class I2VGenXLUNet(nn.Module):
         self._w_kv_all = torch.cat([m._w_kv for m in cross], 0).contiguous()
         self._ctx = _Ctx()
         self._packed = True
+        self._pack_gen += 1
 
     # ----------------------------------------------------------------------------------- conditioning
     def _prepare_clip(self, B, F, H, W, ehs, fps, image_latents, image_embeddings):

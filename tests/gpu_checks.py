@@ -1036,6 +1036,25 @@ def check_engine_reuse_across_clips():
     for tag, got, ref in (("clip B on clip A's engines", b1, b0), ("clip A again after clip B", a2, a0), ("clip A, first use", a1, a0)):
         for name, g, r in zip(("inversion", "PnP edit", "CFG reconstruction"), got, ref):
             out.append(_res(f"engine reuse: {tag}: {name} == fresh pipeline (bitwise)", g, r.float(), 0.0))
+    # weights reloaded between clips: the kept engines (their graphs point at the old packed tensors) must not be reused
+    try:
+        os.environ["ANYV2V_ENGINE_CACHE"] = "1"
+        sd = {k: v.clone() for k, v in native.state_dict().items()}
+        sd2 = {k: (v * 1.01 if v.is_floating_point() and v.dim() >= 2 else v) for k, v in sd.items()}
+        native.load_state_dict(sd2)
+        c1 = run(pipe, clip(1))
+        os.environ["ANYV2V_ENGINE_CACHE"] = "0"
+        c0 = run(fresh, clip(1))
+        native.load_state_dict(sd)
+    finally:
+        if saved is None:
+            os.environ.pop("ANYV2V_ENGINE_CACHE", None)
+        else:
+            os.environ["ANYV2V_ENGINE_CACHE"] = saved
+    for name, g, r in zip(("inversion", "PnP edit", "CFG reconstruction"), c1, c0):
+        out.append(_res(f"engine reuse: after load_state_dict the kept engines are rebuilt: {name} == fresh pipeline", g, r.float(), 0.0))
+    changed = float((c0[0].float() - a0[0].float()).abs().max()) > 1e-4
+    out.append(dict(name="engine reuse: the reloaded weights do change the result", err=0.0 if changed else 1.0, l2=0.0, tol=0.0, ok=bool(changed)))
     differs = float((b0[1].float() - a0[1].float()).abs().max()) > 1e-3
     out.append(dict(name="engine reuse: the two clips do differ", err=0.0 if differs else 1.0, l2=0.0, tol=0.0, ok=bool(differs)))
     return out
