@@ -444,7 +444,7 @@ def read_mp4(path: str) -> Tuple[List[Image.Image], float]:
                 off += sizes[si]
                 si += 1
         stts = _find(buf, *stbl, b"stts")
-        cnt, delta = struct.unpack(">II", buf[stts[0] + 8:stts[0] + 16])
+        _count, delta = struct.unpack(">II", buf[stts[0] + 8:stts[0] + 16])  # (first run of the time-to-sample table)
         fps = timescale / delta if delta else 0.0
         frames = []
         for off, size in zip(offsets, sizes):
