@@ -62,8 +62,10 @@ typedef struct AnyV2VGemmDesc {
     int32_t F, HW;                      /* mode 2: frames per clip, pixels per frame */
     int32_t act;
     int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging; bit2: never use the
-                            persistent 192x320 kernel; bit3: always use it when the shape allows; bit4: no split-K.
-                            All other bits are ignored by the product library. */
+                            persistent 192x320 kernel (nor the weight-stationary one); bit3: always use it when the shape
+                            allows; bit4: no split-K; bit9 (512): never use the weight-stationary K = 320 kernel; bit10 (1024):
+                            use it whenever the shape allows (mode 0, C0 = 320, C1 = 0, N % 160 = 0, act 0 | 3, no rowvec), also
+                            below its M >= 32768 threshold.  All other bits are ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
 } AnyV2VGemmDesc;

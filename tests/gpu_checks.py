@@ -230,6 +230,63 @@ def check_gemm_big():
     return out
 
 
+def _geglu_pack(wfull, bfull, inner):
+    dim = wfull.shape[1]
+    wh, wg = wfull[:inner].view(inner // 16, 16, dim), wfull[inner:].view(inner // 16, 16, dim)
+    wp = torch.stack([wh, wg], 1).reshape(2 * inner, dim).contiguous()
+    bp = torch.stack([bfull[:inner].view(-1, 16), bfull[inner:].view(-1, 16)], 1).reshape(-1).contiguous()
+    return wp, bp
+
+
+def check_gemm_ws():
+    """Weight-stationary K = 320 kernel (gemm_ws.hip), forced with flag bit10 at sizes the references finish quickly, and
+    through the dispatch threshold at the bench's own row counts: one / several strips per wave, ragged M (row guards and
+    clamped look-ahead), 1 / 2 / 6 / 16 slabs, bias / residual / GEGLU epilogues, strided A / C / R views, and equality
+    with the tile kernels it replaces (flag bit9)."""
+    out = []
+    saved = ops.GEMM_FLAGS
+    K = 320
+    try:
+        for (M, N, res) in [(100, 160, False), (2049, 320, True), (4113, 960, False), (9000, 320, True), (33000, 320, True),
+                            (70001, 960, False)]:
+            a, w, bias = rnd(M, K), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
+            r = rnd(M, N) if res else None
+            ops.GEMM_FLAGS = saved | 1024
+            y = ops.gemm(a, w, bias=bias, residual=r)
+            out.append(_res(f"gemm[ws] M{M} N{N} res={res}", y, _gemm_ref(a, w, bias, residual=r), KTOL))
+            ops.GEMM_FLAGS = saved | 512
+            yt = ops.gemm(a, w, bias=bias, residual=r)
+            out.append(_res(f"gemm[ws] == tile kernels M{M} N{N}", y, yt.float(), 1e-3))
+        # no bias; column windows of wider buffers for A, C and R (the V-only projection writes qkv[:, 640:960])
+        ops.GEMM_FLAGS = saved | 1024
+        big, w = rnd(5000, 960), rnd(320, K, scale=1 / math.sqrt(K))
+        dst = torch.zeros(5000, 960, dtype=torch.float16, device=DEV)
+        rbuf = rnd(5000, 640)
+        ops.gemm(big[:, 320:640], w, out=dst[:, 640:], residual=rbuf[:, 320:])
+        out.append(_res("gemm[ws] strided A / C / R views", dst[:, 640:], _gemm_ref(big[:, 320:640], w, residual=rbuf[:, 320:]), KTOL))
+        out.append(_res("gemm[ws] strided C leaves the other columns alone", dst[:, :640], torch.zeros(5000, 640), 0.0))
+        # GEGLU: 2 slabs (inner 160) and 16 slabs (inner 1280, the layer's own width)
+        for (M, inner) in [(777, 160), (3000, 1280), (40000, 1280)]:
+            a = rnd(M, K)
+            wfull, bfull = rnd(2 * inner, K, scale=1 / math.sqrt(K)), rnd(2 * inner, scale=0.1)
+            wp, bp = _geglu_pack(wfull, bfull, inner)
+            y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU)
+            proj = a.float() @ wfull.float().t() + bfull.float()
+            out.append(_res(f"gemm[ws] GEGLU M{M} inner{inner}", y, proj[:, :inner] * F.gelu(proj[:, inner:]), KTOL))
+        # the dispatch threshold itself (no flag): the inversion step's row count, with residual; bit-reproducible
+        ops.GEMM_FLAGS = saved
+        M = 65536
+        a, w, bias, r = rnd(M, K), rnd(320, K, scale=1 / math.sqrt(K)), rnd(320), rnd(M, 320)
+        y = ops.gemm(a, w, bias=bias, residual=r)
+        out.append(_res("gemm[ws] dispatch M65536 N320 +res", y, _gemm_ref(a, w, bias, residual=r), KTOL))
+        out.append(_res("gemm[ws] bit-reproducible", y, ops.gemm(a, w, bias=bias, residual=r).float(), 0.0))
+        ops.GEMM_FLAGS = saved | 512
+        out.append(_res("gemm[ws] dispatch == tile kernels", y, ops.gemm(a, w, bias=bias, residual=r).float(), 1e-3))
+    finally:
+        ops.GEMM_FLAGS = saved
+    return out
+
+
 def check_gemm_splitk():
     """Split-K path (launches that cannot fill the chip and have >= 16 K-tiles; fp32 partial tiles + a second pass that
     sums them in split order): against torch, against the unsplit kernel (flag bit4), and bit-reproducibility.
