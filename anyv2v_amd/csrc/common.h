@@ -38,21 +38,23 @@ static inline int av_launch_status(const char* what) {
 static inline bool av_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ float av_silu(float x) { return x / (1.0f + __expf(-x)); }
-// erf-GELU (torch F.gelu default).  erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, two orders below fp16
-// resolution) on the raw v_rcp / v_exp instructions: ~14 VALU ops instead of libm erff's ~35 with branches -- the GEGLU
-// epilogue evaluates it for every element of the [tokens, 4*dim] feed-forward activations.
-__device__ __forceinline__ float av_erf(float x) {
+// erf-GELU (torch F.gelu default): gelu(x) = x Phi(x) = max(x, 0) - |x| q(|x|) with q = erfc(|x| / sqrt 2) / 2, and erfc by
+// Abramowitz-Stegun 7.1.26 (q = 0.5 P(t) t exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2); |error of q| <= 0.75e-7) on the raw
+// v_rcp / v_exp instructions.  13 VALU ops -- the GEGLU epilogues evaluate it for every element of the [tokens, 4 dim]
+// feed-forward activations and are VALU-issue bound (profiles/r03_gemm_ws_pmc.txt).  The form has no 1 + erf cancellation: over
+// all 63 488 finite fp16 inputs 0.41 % of the fp16-rounded results differ from the correctly rounded exact value, by 1 ulp
+// (the former 0.5 x (1 + erf) arrangement of the same series: 0.72 %, up to 2 ulp; 16 ops) -- tests/test_host_logic.py.
+__device__ __forceinline__ float av_gelu(float x) {
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    const float r = fmaf(-p * t, e, 1.0f);
-    return copysignf(r, x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.0f));   // p / sqrt 2
+    float p = fmaf(0.5306027145f, t, -0.7265760135f);                      // the series' coefficients, halved
+    p = fmaf(p, t, 0.7107068705f);
+    p = fmaf(p, t, -0.142248368f);
+    p = fmaf(p, t, 0.127414796f);
+    const float u = x * 0.84932180f;                                       // sqrt(log2(e) / 2): exp2(-u^2) = exp(-x^2 / 2)
+    const float q = (p * t) * __builtin_amdgcn_exp2f(-(u * u));
+    return fmaf(-ax, q, fmaxf(x, 0.0f));
 }
-__device__ __forceinline__ float av_gelu(float x) { return 0.5f * x * (1.0f + av_erf(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -118,10 +118,11 @@ __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char*
                 h4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // torch: the proj output is rounded to fp16 before chunk / gelu / mul
-                    const float hv = (float)(half_t)(acc[mf][2 * np][r] + (float)bvec[2 * np][r]);
-                    const float gv = (float)(half_t)(acc[mf][2 * np + 1][r] + (float)bvec[2 * np + 1][r]);
-                    o[r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
+                    // h * gelu(gate) in fp32, ONE rounding (torch's fp16 path rounds proj, gelu and the product; its fp32 path --
+                    // the reference this is checked against -- none of them)
+                    const float hv = acc[mf][2 * np][r] + (float)bvec[2 * np][r];
+                    const float gv = acc[mf][2 * np + 1][r] + (float)bvec[2 * np + 1][r];
+                    o[r] = (half_t)(hv * av_gelu(gv));
                 }
                 *(h4*)(Cs + ml * CS_LD + wc * NF * 8 + np * 16 + 4 * lq) = o;
             }
@@ -169,8 +170,7 @@ __device__ __forceinline__ void epilogue(const GemmK& p, f4 (&acc)[4][NF], char*
             const int m = m_blk + r, n0 = n_out_blk + cc * 8;
             h8 v = *(const h8*)(Cs + r * CS_LD + cc * 8);
             if (p.R != nullptr) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[it][e]);
+                v = v + rr[it];  // fp16 add: correctly rounded, i.e. what the fp32 add + rounding of two fp16 values gives
             }
             if (m < p.M && n0 < Nout) *(h8*)(p.C + (size_t)m * p.ldc + n0) = v;
         }
@@ -733,9 +733,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
                     h4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float hv = (float)(half_t)(acc[mf][2 * np][r] + (float)bvec[2 * np][r]);
-                        const float gv = (float)(half_t)(acc[mf][2 * np + 1][r] + (float)bvec[2 * np + 1][r]);
-                        o[r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
+                        const float hv = acc[mf][2 * np][r] + (float)bvec[2 * np][r];
+                        const float gv = acc[mf][2 * np + 1][r] + (float)bvec[2 * np + 1][r];
+                        o[r] = (half_t)(hv * av_gelu(gv));
                     }
                     *(h4*)(slab + l15 * SLAB_LD + np * 16 + 4 * lq) = o;
                 }
@@ -762,8 +762,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
                 const bool ok = (16 * CPRW % 64 == 0 || c < 16 * CPRW) && m_wave + mf * 16 + row < p.M;
                 h8 v = *(const h8*)(slab + (ok ? row * SLAB_LD + cc * 8 : 0));
                 if (has_res) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[mf & 1][it][e]);
+                    v = v + rr[mf & 1][it];  // fp16 add: correctly rounded, == the fp32 add + rounding of two fp16 values
                 }
                 if (ok) *(h8*)(p.C + (size_t)(m_wave + mf * 16 + row) * p.ldc + n_out_wave + cc * 8) = v;
             }
@@ -820,9 +819,7 @@ __global__ void gemm_naive_kernel(const GemmK p) {
             a0 += (float)p.bias[n];
             a1 += (float)p.bias[n + 16];
         }
-        a0 = (float)(half_t)a0;
-        a1 = (float)(half_t)a1;
-        v = a0 * (float)(half_t)av_gelu(a1);
+        v = a0 * av_gelu(a1);
     } else {
         v = a0;
         if (p.bias != nullptr) v += (float)p.bias[n];

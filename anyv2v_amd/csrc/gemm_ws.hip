@@ -28,12 +28,16 @@ constexpr int WS_KS = WS_K / 32;     // MFMA K-steps per strip
 constexpr int WS_NS = 160;           // W slab columns per block
 constexpr int WS_NF = WS_NS / 16;    // 16-column MFMA fragments per slab
 constexpr int WS_RW = 32;            // rows per wave strip
-constexpr int WS_EARLY = 7;          // K-steps whose fragment registers are re-requested inside the K loop (the rest: after the epilogue)
+#ifndef WS_PRIO
+#define WS_PRIO 1
+#endif
+constexpr int WS_EARLY = 8;          // K-steps whose fragment registers are re-requested inside the K loop (the rest: after the epilogue)
 constexpr int WS_W_BYTES = (WS_K / 64) * WS_NS * 128;  // 102400
 constexpr int WS_BIAS_BYTES = WS_NS * 2;               // slab bias, fp16
 }  // namespace
 
-template <bool GEGLU, bool RES>
+// TRACE (probe build only, tools/gemm_ws_trace.py): s_memtime stamps of the third strip of waves 0 and 4 of every block
+template <bool GEGLU, bool RES, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPlan plan) {
     constexpr int OUT_W = GEGLU ? WS_NS / 2 : WS_NS;   // output columns of a slab
     constexpr int SLAB_LD = OUT_W + 8;                 // halves; keeps rows 16-byte aligned, breaks the power-of-2 stride
@@ -55,11 +59,23 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
     const int s_end = s_begin + plan.spr < plan.nstrips ? s_begin + plan.spr : plan.nstrips;
     const int n_wave = slab * WS_NS;
 
-    // activation fragment (MFMA B operand, swapped form): lane = (token l15, k-chunk lq) -> 16 bytes at row, k = 32 s + 8 lq
+    // Activations are loaded as [16 rows][32 k] pieces, lane = (row l >> 2, 16-byte chunk l & 3): a quad of lanes reads 64
+    // contiguous bytes (the fragment-shaped form -- lane = (row l & 15, chunk l >> 4), 16 different cache lines per quad pass
+    // -- was bound by the texture addresser: ~130 cycles per load, profiles/r03_gemm_ws_ab_v1_fragment_loads.txt) and turned
+    // into the MFMA B-operand layout (token l & 15, k-chunk l >> 4) by four ds_bpermute_b32 per fragment, one K-step ahead.
     auto a_row = [&](int strip, int mf) {
-        int row = strip * WS_RW + mf * 16 + l15;
+        int row = strip * WS_RW + mf * 16 + (lane >> 2);
         row = row < p.M ? row : p.M - 1;
-        return p.A0 + (size_t)row * p.lda0 + lq * 8;
+        return p.A0 + (size_t)row * p.lda0 + (lane & 3) * 8;
+    };
+    const int bperm_addr = ((lane & 15) * 4 + (lane >> 4)) * 4;   // source lane (row l & 15, chunk l >> 4), in bytes
+    auto to_frag = [&](const h8& raw) {
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        const i4 r = __builtin_bit_cast(i4, raw);
+        i4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_ds_bpermute(bperm_addr, r[i]);
+        return __builtin_bit_cast(h8, o);
     };
     h8 a[WS_KS][2];
     int strip = s_begin + w;
@@ -93,7 +109,14 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
     const half_t* const bias_l = (const half_t*)(smem + WS_W_BYTES);
     const int n_out_wave = GEGLU ? n_wave / 2 : n_wave;
 
+    int nth = 0;
     while (strip < s_end) {
+        long long* tr = nullptr;
+        if constexpr (TRACE) {
+            if (nth == 2 && (w == 0 || w == 4) && lane == 0) tr = p.trace + ((size_t)blockIdx.x * 2 + (w >> 2)) * 16;
+            ++nth;
+            if (tr) tr[0] = (long long)__builtin_amdgcn_s_memtime();
+        }
         const int next = strip + 8;
         const int pre = next < s_end ? next : strip;   // last strip of the wave: harmless re-read of its own rows
         const half_t* const pn0 = a_row(pre, 0);
@@ -102,7 +125,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < WS_NF; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < WS_NF; ++j) {   // the accumulators start at the bias (lane: channels 16 j + 4 lq .. + 3)
+                const h4 b = *(const h4*)(bias_l + j * 16 + 4 * lq);
+                acc[i][j] = (f4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
 
         // K loop, written in issue order and pinned (hipcc otherwise sinks the next strip's loads behind the last MFMA and
         // reads each weight fragment right in front of its consumers): weight fragments roll three ahead of their MFMA
@@ -115,24 +141,36 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
             const int s = idx / WS_NF, nf = idx - s * WS_NF;
             return *(const h8*)(wl + (s >> 1) * (WS_NS * 128) + wsw[s & 1] + nf * 2048);
         };
-        h8 wq[4];
+        h8 wq[4], fr[2][2];
         wq[0] = wfrag(0);
         wq[1] = wfrag(1);
         wq[2] = wfrag(2);
+        fr[0][0] = to_frag(a[0][0]);
+        fr[0][1] = to_frag(a[0][1]);
+        // the SIMD's other wave is usually in its epilogue (a dense VALU stream) while this one multiplies: MFMAs first
+        if (WS_PRIO) __builtin_amdgcn_s_setprio(WS_PRIO);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int idx = 0; idx < NFR; ++idx) {
             const int s = idx / WS_NF, nf = idx - s * WS_NF;
             if (idx + 3 < NFR) wq[(idx + 3) & 3] = wfrag(idx + 3);
-            acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx & 3], a[s][0], acc[0][nf], 0, 0, 0);
-            acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx & 3], a[s][1], acc[1][nf], 0, 0, 0);
-            if (nf == WS_NF - 1 && s < WS_EARLY) {
+            acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx & 3], fr[s & 1][0], acc[0][nf], 0, 0, 0);
+            acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx & 3], fr[s & 1][1], acc[1][nf], 0, 0, 0);
+            if (nf == 2 && s + 1 < WS_KS) {   // next K-step's fragments, seven MFMA pairs ahead of their first use
+                fr[(s + 1) & 1][0] = to_frag(a[s + 1][0]);
+                fr[(s + 1) & 1][1] = to_frag(a[s + 1][1]);
+            }
+            if (nf == WS_NF - 1 && (s & 1) && s < WS_EARLY) {   // both halves of a 128-byte line back to back
+                a[s - 1][0] = *(const h8*)(pn0 + (s - 1) * 32);
                 a[s][0] = *(const h8*)(pn0 + s * 32);
+                a[s - 1][1] = *(const h8*)(pn1 + (s - 1) * 32);
                 a[s][1] = *(const h8*)(pn1 + s * 32);
             }
+            if constexpr (TRACE) if (tr && nf == WS_NF - 1) tr[1 + s] = (long long)__builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        if (WS_PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- wave-private epilogue: two 16-row halves, (+bias | GEGLU) -> fp16 -> LDS turn -> (+residual) -> 16-byte stores
         // the epilogue's lane-derived offsets must not be hoisted out of the strip loop (they would live across the K loop
         // next to 176 accumulator / fragment registers and spill): launder the lane id once per strip
@@ -161,25 +199,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
             if constexpr (GEGLU) {
 #pragma unroll
                 for (int np = 0; np < WS_NF / 2; ++np) {
-                    const h4 bh = *(const h4*)(bias_l + (2 * np) * 16 + 4 * lq_e);
-                    const h4 bg = *(const h4*)(bias_l + (2 * np + 1) * 16 + 4 * lq_e);
                     h4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        // torch: the proj output is rounded to fp16 before chunk / gelu / mul
-                        const float hv = (float)(half_t)(acc[mf][2 * np][r] + (float)bh[r]);
-                        const float gv = (float)(half_t)(acc[mf][2 * np + 1][r] + (float)bg[r]);
-                        o[r] = (half_t)(hv * (float)(half_t)av_gelu(gv));
+                        o[r] = (half_t)(acc[mf][2 * np][r] * av_gelu(acc[mf][2 * np + 1][r]));  // fp32 throughout, one rounding
                     }
                     *(h4*)(slabp + l15_e * SLAB_LD + np * 16 + 4 * lq_e) = o;
                 }
             } else {
 #pragma unroll
                 for (int nf = 0; nf < WS_NF; ++nf) {
-                    const h4 b = *(const h4*)(bias_l + nf * 16 + 4 * lq_e);
                     h4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[mf][nf][r] + (float)b[r]);
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)acc[mf][nf][r];
                     *(h4*)(slabp + l15_e * SLAB_LD + nf * 16 + 4 * lq_e) = o;
                 }
             }
@@ -197,18 +229,17 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
                 const bool ok = (16 * CPRW % 64 == 0 || c < 16 * CPRW) && m_wave + mf * 16 + row < p.M;
                 h8 v = *(const h8*)(slabp + (ok ? row * SLAB_LD + cc * 8 : 0));
                 if constexpr (RES) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[mf][it][e]);
+                    v = v + rr[mf][it];  // fp16 add: correctly rounded, == the fp32 add + rounding of two fp16 values
                 }
                 if (ok) *(h8*)(p.C + (size_t)(m_wave + mf * 16 + row) * p.ldc + n_out_wave + cc * 8) = v;
             }
         }
+        if constexpr (TRACE) if (tr) tr[11] = (long long)__builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = WS_EARLY; s < WS_KS; ++s) {
-            a[s][0] = *(const h8*)(pn0 + s * 32);
-            a[s][1] = *(const h8*)(pn1 + s * 32);
-        }
+        for (int s = WS_EARLY; s < WS_KS; ++s) a[s][0] = *(const h8*)(pn0 + s * 32);
+#pragma unroll
+        for (int s = WS_EARLY; s < WS_KS; ++s) a[s][1] = *(const h8*)(pn1 + s * 32);
         __builtin_amdgcn_sched_barrier(0);
         strip = next;
     }
@@ -220,13 +251,26 @@ bool av_gemm_ws_eligible(const AnyV2VGemmDesc* d) {
            (d->act == ACT_NONE || (d->act == ACT_GEGLU && d->R == nullptr)) && d->rowvec == nullptr && d->M > 0;
 }
 
-int av_gemm_ws_launch(const GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s) {
+int av_gemm_ws_launch(const GemmK& k_in, const AnyV2VGemmDesc* d, hipStream_t s) {
+    GemmK k = k_in;
     WsPlan plan;
     plan.S = d->N / WS_NS;
     plan.px = 32 / plan.S;
     plan.nstrips = (d->M + WS_RW - 1) / WS_RW;
     const int nranges = 8 * plan.px;
     plan.spr = (plan.nstrips + nranges - 1) / nranges;
+#ifdef ANYV2V_EXPERIMENTS  // probe build only: per-strip phase timestamps (flags bit5), tools/gemm_ws_trace.py
+    if ((d->flags & 32) && d->workspace != nullptr && (size_t)256 * 2 * 16 * sizeof(long long) <= (size_t)d->workspace_bytes) {
+        k.trace = (long long*)d->workspace;
+        if (d->act == ACT_GEGLU)
+            hipLaunchKernelGGL((gemm_ws_kernel<true, false, true>), dim3(256), dim3(512), 0, s, k, plan);
+        else if (d->R != nullptr)
+            hipLaunchKernelGGL((gemm_ws_kernel<false, true, true>), dim3(256), dim3(512), 0, s, k, plan);
+        else
+            hipLaunchKernelGGL((gemm_ws_kernel<false, false, true>), dim3(256), dim3(512), 0, s, k, plan);
+        return av_launch_status("gemm_ws<trace>");
+    }
+#endif
     if (d->act == ACT_GEGLU)
         hipLaunchKernelGGL((gemm_ws_kernel<true, false>), dim3(256), dim3(512), 0, s, k, plan);
     else if (d->R != nullptr)
