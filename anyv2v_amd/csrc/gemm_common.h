@@ -101,6 +101,7 @@ struct WsPlan {
     int px;       // row ranges per XCD (px * S <= 32 blocks of the 32 CUs of an XCD)
     int nstrips;  // 32-row strips in M
     int spr;      // strips per row range
+    int trace_waves;  // probe build: waves of a block that work (8; 4 / 1 = one wave per SIMD / per CU), tools/gemm_ws_trace.py
 };
 bool av_gemm_ws_eligible(const AnyV2VGemmDesc* d);
 int av_gemm_ws_launch(const GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s);

@@ -17,6 +17,7 @@ from anyv2v_amd import ops  # noqa: E402
 dev = "cuda"
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 7
 lines = []
+VARIANTS = tuple(int(v) for v in os.environ.get("WS_VARIANTS", "").split(",") if v)   # probe: flags bits 11-12
 
 
 def timeit(fn, iters=10):
@@ -41,16 +42,18 @@ def case(tag, M, N, act=0, res=False, ldc=None):
     out = buf[:, (ldc or n_out) - n_out:]
     r = torch.randn(M, n_out, device=dev).half() if res else None
     kw = dict(bias=b, out=out, act=act, residual=r)
-    t = {512: [], 0: []}
+    arms = (512, 0) + tuple(v << 11 for v in VARIANTS)
+    t = {f: [] for f in arms}
     for _ in range(rounds):
-        for flags in (512, 0):
+        for flags in arms:
             ops.GEMM_FLAGS = flags
             t[flags].append(timeit(lambda: ops.gemm(a, w, **kw)))
     fl = 2.0 * M * N * K
     nb = 2.0 * (M * K + N * K + M * n_out * (2 if res else 1))
     old, new = statistics.median(t[512]), statistics.median(t[0])
     lines.append(f"{tag:<26s} M={M:6d} N={N:5d}: tile {old:7.1f} us (min {min(t[512]):7.1f}; {fl / old / 1e6:5.0f} TF, {nb / old / 1e3:5.0f} GB/s)"
-                 f" | ws {new:7.1f} us (min {min(t[0]):7.1f}; {fl / new / 1e6:5.0f} TF, {nb / new / 1e3:5.0f} GB/s) | x{old / new:4.2f}")
+                 f" | ws {new:7.1f} us (min {min(t[0]):7.1f}; {fl / new / 1e6:5.0f} TF, {nb / new / 1e3:5.0f} GB/s) | x{old / new:4.2f}"
+                 + "".join(f" | var{v} {statistics.median(t[v << 11]):7.1f}" for v in VARIANTS))
     print(lines[-1], flush=True)
 
 

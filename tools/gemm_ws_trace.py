@@ -15,7 +15,7 @@ dev = "cuda"
 lines = []
 
 
-def run(tag, M, N, act=0, res=False):
+def run(tag, M, N, act=0, res=False, extra=0):
     K = 320
     a = torch.randn(M, K, device=dev).half()
     w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
@@ -28,7 +28,7 @@ def run(tag, M, N, act=0, res=False):
     ops.GEMM_FLAGS = 0
     for _ in range(2):
         ops.gemm(a, w, **kw)
-    ops.GEMM_FLAGS = 32
+    ops.GEMM_FLAGS = 32 | extra
     ws.zero_()
     ops.gemm(a, w, **kw)
     torch.cuda.synchronize()
@@ -49,5 +49,8 @@ run("B3 out-proj +res", 196608, 320, res=True)
 run("B3 QKV", 196608, 960)
 run("B3 GEGLU", 196608, 2560, act=3)
 run("B1 QKV", 65536, 960)
+run("B3 GEGLU, 4 waves per block (one per SIMD)", 196608, 2560, act=3, extra=8192)
+run("B3 GEGLU, 1 wave per block", 196608, 2560, act=3, extra=16384)
+run("B3 QKV, 4 waves per block", 196608, 960, extra=8192)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", "gemm_ws_trace.txt"), "w").write("\n".join(lines) + "\n")
