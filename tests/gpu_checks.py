@@ -49,7 +49,9 @@ def _res(name, got, ref, tol):
     if not torch.isfinite(got.float()).all():
         return dict(name=name, err=float("nan"), l2=float("nan"), tol=tol, ok=False)
     mx, l2 = _rel(got, ref)
-    return dict(name=name, err=mx, l2=l2, tol=tol, ok=bool(mx <= tol))
+    # both metrics are gated: max |diff| / max |ref| and relative L2 (which is never larger than sqrt(N) x the former but is the one
+    # a systematic small error moves)
+    return dict(name=name, err=mx, l2=l2, tol=tol, ok=bool(mx <= tol and l2 <= tol))
 
 
 # Kernel-level tolerance: max |got - ref| / max |ref| against PyTorch fp32 on identical fp16 inputs.  The measured worst case over
@@ -1277,16 +1279,48 @@ def _sync():
         torch.cuda.synchronize()
 
 
-def _calibrated(name, got, ref, eager, factor=2.0, floor=5e-4):
+_CAPS = None
+
+
+def _recorded_caps():
+    """tests/golden/hip_error_caps.json: the HIP path's own error per whole-model check as last recorded on an MI355X
+    (``ANYV2V_RECORD_ERRS=<file> pytest -m gpu`` / ``tools/gpu_check.py`` writes it).  A calibrated bound is never looser than
+    3 x that record, so a 3 x regression of the HIP path fails even where eager fp16 is far worse (VERDICT r2 weak #2)."""
+    global _CAPS
+    if _CAPS is None:
+        import json
+        path = os.path.join(ROOT, "tests", "golden", "hip_error_caps.json")
+        _CAPS = json.load(open(path)) if os.path.isfile(path) else {}
+    return _CAPS
+
+
+_RECORD = {}
+
+
+def _calibrated(name, got, ref, eager, factor=2.0, floor=5e-4, key=None):
     """SURVEY.md 8(c) tolerance policy: |HIP fp16 - fp32 oracle| <= 2 x |torch-eager fp16 oracle - fp32 oracle| (+ a floor
-    for the cases where both are at rounding level), all three on the same inputs in the same test."""
+    for the cases where both are at rounding level), all three on the same inputs in the same test -- for the max-abs metric AND
+    for relative L2 -- and, with ``key``, additionally <= 3 x the HIP error recorded for this check (``_recorded_caps``)."""
     got, ref, eager = got.float().cpu(), ref.float().cpu(), eager.float().cpu()
     if not torch.isfinite(got).all():
         return dict(name=name, err=float("nan"), l2=float("nan"), tol=0.0, ok=False)
     e_h, l2 = _rel(got, ref)
-    e_e, _ = _rel(eager, ref)
+    e_e, l2_e = _rel(eager, ref)
     tol = factor * e_e + floor
-    return dict(name=f"{name}  [HIP {e_h:.2e} | eager fp16 {e_e:.2e}]", err=e_h, l2=l2, tol=tol, ok=bool(e_h <= tol), eager=e_e)
+    tol_l2 = factor * l2_e + floor
+    cap = None
+    if key is not None:
+        _RECORD[key] = {"err": e_h, "l2": l2, "eager": e_e, "eager_l2": l2_e}
+        rec = _recorded_caps().get(key)
+        if rec is not None:
+            cap = 3.0 * rec["err"] + floor
+            tol, tol_l2 = min(tol, cap), min(tol_l2, 3.0 * rec["l2"] + floor)
+        path = os.environ.get("ANYV2V_RECORD_ERRS")
+        if path:
+            import json
+            json.dump(_RECORD, open(path, "w"), indent=1, sort_keys=True)
+    return dict(name=f"{name}  [HIP {e_h:.2e} (l2 {l2:.2e}) | eager fp16 {e_e:.2e} (l2 {l2_e:.2e})" + (f" | cap {cap:.2e}" if cap else "") + "]",
+                err=e_h, l2=l2, tol=tol, tol_l2=tol_l2, ok=bool(e_h <= tol and l2 <= tol_l2), eager=e_e)
 
 
 def _cond_kw(inp16, device, dtype):
@@ -1355,7 +1389,7 @@ def check_n1_config1(cfg_name="full", Fr=8, hw=32, golden=True, report=None):
     if report is not None:
         report[f"cpu_oracle_seconds_{cfg_name}_B1"] = t_cpu
     out.append(_res(f"fp32 oracle on the GPU == fp32 oracle on the CPU ({cfg_name}, config 1, B=1)", v32.cpu(), v_cpu, 2e-4))
-    out.append(_calibrated(f"unet {cfg_name} config 1 B=1 t=981 vs CPU fp32 oracle", vn, v_cpu, v16))
+    out.append(_calibrated(f"unet {cfg_name} config 1 B=1 t=981 vs CPU fp32 oracle", vn, v_cpu, v16, key=f"n1c1:{cfg_name}:F{Fr}x{hw}:B1:t981"))
     pipe = _hook_all(m, ("o32", "o16", "ocpu"))
     gold = None
     gpath = os.path.join(ROOT, "tests", "golden", "pnp_hooks_full_config1.pt")
@@ -1371,18 +1405,19 @@ def check_n1_config1(cfg_name="full", Fr=8, hw=32, golden=True, report=None):
             if report is not None:
                 report[f"cpu_oracle_seconds_{cfg_name}_B3_t{t}"] = t_cpu
             out.append(_res(f"fp32 oracle GPU == CPU ({cfg_name}, config 1, B=3 + hooks, t={t})", v32.cpu(), v_cpu, 2e-4))
-            out.append(_calibrated(f"unet {cfg_name} config 1 B=3 + 17 hook sites t={t} vs CPU fp32 oracle (pnp_oracle)", vn, v_cpu, v16))
+            out.append(_calibrated(f"unet {cfg_name} config 1 B=3 + 17 hook sites t={t} vs CPU fp32 oracle (pnp_oracle)", vn, v_cpu, v16,
+                                   key=f"n1c1:{cfg_name}:F{Fr}x{hw}:B3:t{t}"))
             if gold is not None:
                 out.append(_res(f"CPU oracle + pnp_oracle == fixture of the reference's pnp_utils on the oracle, t={t}", v_cpu,
                                 gold[f"v_hook_t{t}"], 1e-4))
                 out.append(_calibrated(f"unet full config 1 B=3 + hooks t={t} vs reference-pnp_utils fixture", vn,
-                                       gold[f"v_hook_t{t}"], v16))
+                                       gold[f"v_hook_t{t}"], v16, key=f"n1c1:fixture:t{t}"))
     finally:
         _unhook_all(m, ("o32", "o16", "ocpu"), pipe)
     return out
 
 
-def check_n1_config3_step(cfg_name="full", Fr=16, hw=64, report=None):
+def check_n1_config3_step(cfg_name="full", Fr=16, hw=64, report=None, hooked_ts=(981, 301)):
     """ONE step at the benchmarked size -- BASELINE config 3, latents [B,4,16,64,64] -- B=1 (inversion
     step) and B=3 with all 17 hook sites (PnP step; t=981 every site on, t=301 temporal only), HIP fp16 vs the fp32 oracle
     run by torch-eager on the GPU (checker only), tolerance 2 x the eager-fp16 oracle's error at this size."""
@@ -1412,15 +1447,16 @@ def check_n1_config3_step(cfg_name="full", Fr=16, hw=64, report=None):
         return v32.cpu(), v16.cpu(), vn.cpu()
 
     v32, v16, vn = run_all(1, 981)
-    out.append(_calibrated(f"unet {cfg_name} [1,4,{Fr},{hw},{hw}] t=981 vs fp32 oracle", vn, v32, v16))
+    out.append(_calibrated(f"unet {cfg_name} [1,4,{Fr},{hw},{hw}] t=981 vs fp32 oracle", vn, v32, v16, key=f"n1step:{cfg_name}:F{Fr}x{hw}:B1:t981"))
     pipe = _hook_all(m, ("o32", "o16"))
     try:
-        for t in (981, 301):
+        for t in hooked_ts:
             pnp_utils.register_time(pipe, t)
             for n in ("o32", "o16"):
                 pnp_oracle.register_time(m[n], t)
             v32, v16, vn = run_all(3, t)
-            out.append(_calibrated(f"unet {cfg_name} [3,4,{Fr},{hw},{hw}] + 17 hook sites t={t} vs fp32 oracle", vn, v32, v16))
+            out.append(_calibrated(f"unet {cfg_name} [3,4,{Fr},{hw},{hw}] + 17 hook sites t={t} vs fp32 oracle", vn, v32, v16,
+                                   key=f"n1step:{cfg_name}:F{Fr}x{hw}:B3:t{t}"))
     finally:
         _unhook_all(m, ("o32", "o16"), pipe)
     return out
@@ -1501,10 +1537,9 @@ def check_n1_drift(cfg_name="full", Fr=16, hw=64, n_steps=50, every=10, report=N
                                          ("PnP edit (inversion -> sample_with_pnp)", fwd_ts, ed, ed32, ed16)):
         for i in range(every - 1, n_steps, every):
             t = order[i]
-            r = _calibrated(f"{tag} {name}: drift after {i + 1} steps (t={t})", hip[t], o32_[t], o16_[t], floor=1e-3)
-            if i + 1 < n_steps:
-                r["informational"] = True     # per-10-step drift is REPORTED; the bound is enforced on the final latent
-            rows.append(r)
+            # every row is enforced (round 2: only the final latent): bound = min(2 x eager-fp16 drift, 3 x the HIP drift on record)
+            rows.append(_calibrated(f"{tag} {name}: drift after {i + 1} steps (t={t})", hip[t], o32_[t], o16_[t], floor=1e-3,
+                                    key=f"drift:{cfg_name}:F{Fr}x{hw}:n{n_steps}:{name.split()[0]}:{i + 1}"))
     out.extend(rows)
     # the round trip itself (how well n-step reconstruction returns to the clean latent) -- same for all three paths
     for nm, r_ in (("HIP", rec[fwd_ts[-1]]), ("fp32 oracle", rec32[fwd_ts[-1]]), ("eager fp16 oracle", rec16[fwd_ts[-1]])):
@@ -1513,6 +1548,47 @@ def check_n1_drift(cfg_name="full", Fr=16, hw=64, n_steps=50, every=10, report=N
         out.append(e)
     if report is not None:
         report["drift"] = [(r["name"], r["err"], r.get("eager")) for r in rows]
+    return out
+
+
+def check_inversion_500(cfg_name="full", Fr=16, hw=64, n_steps=500, every=100, report=None):
+    """BASELINE config 2 as the reference ships it (configs/group_ddim_inversion/template.yaml:33: 500 inversion steps,
+    timesteps 1, 3, ..., 999): the product pipeline's ``invert`` (HIP graphs) vs the oracle's ``invert_loop`` in fp32 on the GPU,
+    latent drift every ``every`` steps, bounded by 2 x the eager-fp16 oracle's drift through the same loop."""
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler
+    from oracle import pnp_oracle
+    out = []
+    m = full_models(cfg_name, 1234, want=("native", "o32", "o16"))
+    native, ocfg = m["native"], m["ocfg"]
+    inp = config1_inputs(ocfg, 3, Fr, hw)
+    h = lambda x: x.half()
+    lat0 = h(inp["sample"][:1])
+    ehs, ie, il = h(inp["encoder_hidden_states"]), h(inp["image_embeddings"]), h(inp["image_latents"])
+
+    def oracle_run(o, dt):
+        d = lambda x: x.to(DEV, dt)
+        cond_src = dict(fps=torch.tensor([8], device=DEV), image_latents=d(il[:1]), image_embeddings=d(ie[:1]),
+                        encoder_hidden_states=d(ehs[:1]))
+        pnp_oracle.clear_hooks(o)
+        return pnp_oracle.invert_loop(o, d(lat0), cond_src, n_steps)
+
+    traj32 = {t: v.cpu() for t, v in oracle_run(m["o32"], torch.float32).items()}
+    traj16 = {t: v.cpu() for t, v in oracle_run(m["o16"], torch.float16).items()}
+    g = lambda x: x.to(DEV)
+    pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+    pipe._device = torch.device(DEV)
+    traj = pipe.invert(prompt_embeds=g(ehs[:1]), image_embeddings=g(ie[:1]), image_latents=g(il[:1]), height=hw * 8, width=hw * 8,
+                       num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0, target_fps=8, latents=g(lat0),
+                       return_trajectory=True)
+    ts = sorted(traj32.keys())
+    assert len(ts) == n_steps and sorted(traj.keys()) == ts
+    for i in range(every - 1, n_steps, every):
+        t = ts[i]
+        out.append(_calibrated(f"{cfg_name} [{Fr}f x {hw * 8}^2] {n_steps}-step inversion: drift after {i + 1} steps (t={t})", traj[t],
+                               traj32[t], traj16[t], floor=1e-3, key=f"inv{n_steps}:{cfg_name}:F{Fr}x{hw}:{i + 1}"))
+    if report is not None:
+        report["inversion_500"] = [(r["name"], r["err"], r.get("eager")) for r in out]
     return out
 
 
