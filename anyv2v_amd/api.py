@@ -25,7 +25,7 @@ from .pipeline import I2VGenXLPipeline
 from .run_group_ddim_inversion import ddim_inversion
 from .run_group_pnp_edit import init_pnp
 from .schedulers import DDIMInverseScheduler, DDIMScheduler
-from .utils import export_to_video, load_image
+from .utils import export_to_video, load_image, wait_for_pending_writes
 
 MODEL_ID = "ali-vilab/i2vgen-xl"
 
@@ -72,9 +72,19 @@ class AnyV2V_I2VGenXL:
                        temp_inj, num_inference_steps, guidance_scale, ddim_init_latents_t_idx, ddim_inversion_steps, seed):
         """``gradio_demo.py:80-222``.  Returns the path of ``edited_video.mp4``."""
         tmp_dir = os.path.join(self.tmp_dir, "AnyV2V")
+        wait_for_pending_writes()  # a previous call that raised may still have a trajectory writer staging files in there
         if os.path.exists(tmp_dir):
             shutil.rmtree(tmp_dir)
         os.makedirs(tmp_dir)
+        try:
+            return self._perform(tmp_dir, video_path, video_prompt, video_negative_prompt, edited_first_frame_path, conv_inj,
+                                 spatial_inj, temp_inj, num_inference_steps, guidance_scale, ddim_init_latents_t_idx,
+                                 ddim_inversion_steps, seed)
+        finally:
+            wait_for_pending_writes()  # also when a later step raised: no writer thread outlives the call
+
+    def _perform(self, tmp_dir, video_path, video_prompt, video_negative_prompt, edited_first_frame_path, conv_inj, spatial_inj,
+                 temp_inj, num_inference_steps, guidance_scale, ddim_init_latents_t_idx, ddim_inversion_steps, seed):
         ddim_latents_path = os.path.join(tmp_dir, "ddim_latents")
         frame_list = read_frames(str(video_path))
         cfg = self.config

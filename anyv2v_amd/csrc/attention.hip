@@ -104,7 +104,7 @@ __device__ __forceinline__ h8 join8(fp16x4v_t a, fp16x4v_t b) {
 // the same score registers: true maximum, rescale of O and l, re-exponentiation.  Exact in the sense that P only differs by the
 // rounding of a shifted exponent; on the UNet's data the branch is taken on the first step of a row and practically never again
 // (tests/gpu_checks.py::check_attention_forced_rescale forces it).  Per score this leaves fma + exp2 + add + 1/2 cvt_pk
-// (the textbook form had a max on top and a deferred-rescale test per tile): 154 -> ~120 VALU per wave and KV tile.
+// (the textbook form had a max on top and a deferred-rescale test per tile): 154 -> 136 VALU per wave and KV tile (SQ_INSTS_VALU minus MFMA, profiles/r02_pmc_raw.txt).
 // Measured forms that were dropped (profiles/r02_attn_softmax_forms_ab*.txt): Q pre-multiplied by scale * log2(e) with the
 // running maximum subtracted by the MFMA (C operand = a 16-register block of -m, D != C) removes the fma as well and is as fast
 // as this form, but costs a second fp16 rounding of Q (error 3e-4 -> 7e-4, growing with |s c|); one whole-tile softmax without

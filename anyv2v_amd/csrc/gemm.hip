@@ -225,14 +225,16 @@ struct AGen {
     }
 };
 
-#ifndef AV_TRACE_TILE  // experiments build: which tile of every block (0 = its first) the phase timestamps are taken from
-#define AV_TRACE_TILE 0
+#ifdef ANYV2V_EXPERIMENTS
+#include "../../tools/experiments/gemm_probe_config.h"   // AV_TRACE_TILE (which tile of a block the probe stamps)
+#else
+constexpr int AV_TRACE_TILE = 0;
 #endif
-#ifndef AV_FRAG_ASM
-#define AV_FRAG_ASM 1
-#endif
-#ifndef AV_FRAG_ASM_128  // the 128-row kernel's K-tile (A/B builds)
-#define AV_FRAG_ASM_128 AV_FRAG_ASM
+// The fragment reads below are inline asm with hand-counted waits; what that relies on is checked over the generated assembly by
+// tests/test_isa_guards.py (no scratch access / copy of a pending destination, every MFMA covered by its counted wait).  Validated
+// with ROCm 7.2's hipcc only: a different compiler may schedule around the asm differently -- rerun that test and `-m gpu`.
+#if defined(HIP_VERSION_MAJOR) && (HIP_VERSION_MAJOR != 7 || HIP_VERSION_MINOR != 2)
+#warning "gemm.hip: inline-asm LDS fragment reads were validated with ROCm 7.2 only; rerun tests/test_isa_guards.py and the -m gpu suite"
 #endif
 // Fragment reads of the K-tile below are issued as inline asm with hand-counted `s_waitcnt lgkmcnt(n)`: with an LDS-DMA load
 // (global_load_lds) in flight hipcc treats the LGKM counter as out of order and waits lgkmcnt(0) before every fragment use,
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK p) {
         const int cur = kt & 1;
         const bool has_next = kt + 1 < nk;
         if (has_next && KO != 3) issue(cur ^ 1, KO != 2);
-        if constexpr (GLDS && KO == 0 && AV_FRAG_ASM_128)
+        if constexpr (GLDS && KO == 0)
             mma_tile_asm<NF>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
         else
             mma_tile<NF, KO>(acc, As0 + cur * A_BYTES, Bs0 + cur * B_BYTES, wr, wc, lane);
@@ -519,17 +521,12 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
     const char* b0 = bs + (wc * 160 + l15) * 128;
     const int c0 = ((0 * 4 + lq) ^ (l15 & 7)) * 16, c1 = ((1 * 4 + lq) ^ (l15 & 7)) * 16;
     h8 af[2][MF], bf[2][10];
-#if AV_FRAG_ASM
     // issue order of the reads (seq = running count) and, per fragment, its position in that order
     int seq = 0, a_seq[2] = {0, 0}, b_seq[2][10] = {};
     const unsigned abase[2] = {(unsigned)(size_t)(a0 + c0), (unsigned)(size_t)(a0 + c1)};
     const unsigned bbase[2] = {(unsigned)(size_t)(b0 + c0), (unsigned)(size_t)(b0 + c1)};
 #define AV_RA(ks, mf) (af[ks][mf] = lds_frag(abase[ks], (mf) * 2048), a_seq[ks] = ++seq)
 #define AV_RB(ks, nf) (bf[ks][nf] = lds_frag(bbase[ks], (nf) * 2048), b_seq[ks][nf] = ++seq)
-#else
-#define AV_RA(ks, mf) af[ks][mf] = *(const h8*)(a0 + (mf) * 2048 + ((ks) ? c1 : c0))
-#define AV_RB(ks, nf) bf[ks][nf] = *(const h8*)(b0 + (nf) * 2048 + ((ks) ? c1 : c0))
-#endif
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) AV_RA(0, mf);
     AV_RB(0, 0);
@@ -540,13 +537,11 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int nf = 0; nf < 10; ++nf) {
-#if AV_FRAG_ASM
             {   // everything up to the later of (this group's weight fragment, this K-step's last activation fragment)
                 const int need = b_seq[ks][nf] > a_seq[ks] ? b_seq[ks][nf] : a_seq[ks];
                 lgkm_wait(seq - need);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#endif
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], acc[mf][nf], 0, 0, 0);
@@ -938,19 +933,8 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         if (fills || (d->flags & 8)) {
             k.tilesN = d->N / 320;
             const dim3 grid(tiles_big < 256 ? tiles_big : 256);
-#ifdef ANYV2V_EXPERIMENTS  // probe build only (make experiments -> tools/libanyv2v_hip_experiments.so; tools/gemm_trace.py)
-            if ((d->flags & 32) && d->workspace != nullptr && (size_t)grid.x * 32 * sizeof(long long) <= (size_t)d->workspace_bytes) {
-                k.trace = (long long*)d->workspace;  // debug: phase timestamps of each block's first tile
-                if constexpr (MODE == MODE_LINEAR) {
-                    if (geglu)
-                        hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR, true>), grid, dim3(512), 0, s, k);
-                    else
-                        hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR, true>), grid, dim3(512), 0, s, k);
-                } else {
-                    hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, true>), grid, dim3(512), 0, s, k);
-                }
-                return av_launch_status("gemm_big<trace>");
-            }
+#ifdef ANYV2V_EXPERIMENTS  // probe build only (make experiments): phase-timestamp instantiations, tools/gemm_big_trace.py
+#include "../../tools/experiments/gemm_dispatch_big_probe.inc"
 #endif
             if constexpr (MODE == MODE_LINEAR) {
                 if (geglu)
@@ -981,27 +965,8 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         }
     }
     const dim3 grid(tiles * k.splits);
-#ifdef ANYV2V_EXPERIMENTS  // probe build only: per-block phase timestamps (flag 32) and K-loop knock-outs (flags 64..448,
-                           // wrong results by design) -- tools/gemm_trace.py.  The product library has neither instantiation.
-    if ((d->flags & 32) && glds && k.splits == 1 && d->workspace != nullptr &&
-        (size_t)grid.x * 32 * sizeof(long long) <= (size_t)d->workspace_bytes) {  // debug: per-block phase timestamps
-        k.trace = (long long*)d->workspace;
-        if (geglu)
-            hipLaunchKernelGGL((gemm_mfma_kernel<4, true, true, MODE, true>), grid, dim3(256), 0, s, k);
-        else if (nf == 5)
-            hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, true>), grid, dim3(256), 0, s, k);
-        else
-            hipLaunchKernelGGL((gemm_mfma_kernel<4, true, false, MODE, true>), grid, dim3(256), 0, s, k);
-        return av_launch_status("gemm_mfma<trace>");
-    }
-    const int ko = (d->flags >> 6) & 7;  // debug knock-outs (wrong results by design), NF = 5 plain tiles only
-    if (ko >= 2 && ko <= 5 && glds && !geglu && nf == 5 && k.splits == 1) {
-        if (ko == 2) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 2>), grid, dim3(256), 0, s, k);
-        if (ko == 3) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 3>), grid, dim3(256), 0, s, k);
-        if (ko == 4) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 4>), grid, dim3(256), 0, s, k);
-        if (ko == 5) hipLaunchKernelGGL((gemm_mfma_kernel<5, true, false, MODE, false, 5>), grid, dim3(256), 0, s, k);
-        return av_launch_status("gemm_mfma<knock-out>");
-    }
+#ifdef ANYV2V_EXPERIMENTS  // probe build only: phase timestamps (flag 32) / K-loop knock-outs (flags 64..448), tools/gemm_trace.py
+#include "../../tools/experiments/gemm_dispatch_mfma_probe.inc"
 #endif
 #define AV_LAUNCH2(NF_, GEGLU_)                                                                          \
     do {                                                                                                 \

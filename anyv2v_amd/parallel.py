@@ -55,10 +55,18 @@ def gather_latents(latents: Sequence[torch.Tensor], n_entries: int, like_shape, 
     world = dist.get_world_size()
     slots = max(1, -(-int(n_entries) // world))
     like_shape = tuple(like_shape)[-4:]
+    # Agree on validity BEFORE the collective: a rank that raised on its own (too many results, a clip with another geometry)
+    # would leave the others blocked in all_gather until the backend's timeout.  Every rank reports (ok, its geometry); all of
+    # them then raise together, or none does.
+    mine = [tuple(x.shape[-4:]) for x in latents]
+    ok = len(latents) <= slots and all(sh == like_shape for sh in mine)
+    reports = [None] * world
+    dist.all_gather_object(reports, (bool(ok), len(latents), sorted(set(mine)), like_shape))
+    if not all(r[0] for r in reports) or len({r[3] for r in reports}) != 1:
+        raise ValueError(f"gather_latents: ranks disagree or hold invalid results (ok, n_results, geometries, expected) per rank: "
+                         f"{reports}; {n_entries} entries over {world} ranks = {slots} slots each; all entries must share one geometry")
     buf = torch.zeros((slots,) + like_shape, dtype=dtype, device=device)
-    assert len(latents) <= slots, f"{len(latents)} results on this rank but only {slots} slots ({n_entries} entries / {world} ranks)"
     for k, x in enumerate(latents):
-        assert tuple(x.shape[-4:]) == like_shape, f"entry latents {tuple(x.shape)} != {like_shape}: all entries must share one geometry"
         buf[k].copy_(x.reshape(like_shape))
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)

@@ -353,9 +353,22 @@ class I2VGenXLPipeline:
         eng = self._engines.pop(key, None)
         if eng is None or not eng.rebind(sample, cond):
             eng = _StepEngine(self, sample, cond, **kw)
+        # Every engine pins a private graph pool holding a whole forward's activations (and a nested one for the source-free
+        # steps), so the cache is small and evicts eagerly: one engine per loop kind (a new guidance value or geometry replaces
+        # the old engine of that loop -- a slider in a long-lived front-end must not accumulate pools), at most
+        # ANYV2V_ENGINE_CACHE_MAX (3 = inversion + CFG + PnP) overall; an evicted engine drops its graphs and returns the memory.
+        evict = [k for k in self._engines if k[0] == tag]
         self._engines[key] = eng  # most recently used last
-        while len(self._engines) > 4:
-            self._engines.pop(next(iter(self._engines)))
+        limit = max(1, int(os.environ.get("ANYV2V_ENGINE_CACHE_MAX", "3")))
+        evict += [k for k in list(self._engines)[: max(0, len(self._engines) - len(evict) - limit)] if k not in evict]
+        for k in evict:
+            old = self._engines.pop(k)
+            old.graphs.clear()
+            if old.nosrc is not None:
+                old.nosrc.graphs.clear()
+                old.nosrc = None
+        if evict and sample.is_cuda:
+            torch.cuda.empty_cache()
         return eng
 
     # ------------------------------------------------------------------ A1: DDIM inversion (:1197-1451)

@@ -41,6 +41,14 @@ def main(inv_template, inv_list, edit_template, edit_list, device, logger, synth
     seed_everything(inv_template.seed)  # each stage starts from its template's seed, as two separate processes would
     stage1.main(inv_template, inv_list, device, logger, synthetic_encoders, random_init_seed, frame_parallel, pipe=pipe,
                 trajectories=trajectories)
+    if world > 1 and not frame_parallel:
+        # Sharded mode deals the entries of each stage independently: a rank may edit a clip that another rank inverted (or have no
+        # inversion work at all) and then reads its ddim_latents files -- which must be complete on disk first.  Join this rank's
+        # background writers, then wait for every rank (the two-step CLI gets this for free: stage 1 exits before stage 2 starts).
+        import torch.distributed as dist
+        from .utils import wait_for_pending_writes
+        wait_for_pending_writes()
+        dist.barrier()
     seed_everything(edit_template.seed)
     stage2.main(edit_template, edit_list, device, logger, synthetic_encoders, random_init_seed, frame_parallel, pipe=pipe,
                 trajectories=trajectories)

@@ -332,3 +332,70 @@ def test_fused_runner_matches_the_two_stage_run(tmp_path):
         assert torch.equal(torch.load(os.path.join(inv_a, "ddim_latents", f)), torch.load(os.path.join(inv_b, "ddim_latents", f))), f
     assert torch.equal(torch.load(os.path.join(out_a, "edited_latents.pt")), torch.load(os.path.join(out_b, "edited_latents.pt")))
     assert sorted(os.listdir(out_a)) == sorted(os.listdir(out_b))
+
+
+def _fused_shard_worker(rank, world, port, base):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_emulation as emu
+    emu.install()
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    from anyv2v_amd import run_group_anyv2v as fused
+    inv, inv_list, ed, ed_list = _configs(base, "fshard")
+    inv_list = [dict(inv_list[0], recon_config={"enable_recon": False})]
+    ed_list = [dict(ed_list[0], editing_prompt=f"edit number {i}", edited_video_name=f"edit{i}") for i in range(2)]
+    fused.main(inv, inv_list, ed, ed_list, torch.device("cpu"), logging.getLogger("e2e"), synthetic_encoders=True)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_fused_runner_sharded_world2_one_inversion_two_edits(tmp_path):
+    """the fused runner under torchrun deals each stage's entries independently -- with 1 clip and 2 edits
+    on 2 ranks, rank 1 has no inversion work and its edit needs the files rank 0 is still writing.  The runner now joins the
+    writers and barriers between the stages; both edits complete and equal what the same entries give through the files."""
+    import torch.multiprocessing as mp
+    base = _make_workspace(tmp_path)
+    mp.spawn(_fused_shard_worker, args=(2, _free_port(), base), nprocs=2, join=True)
+    got = torch.load(os.path.join(base, "gathered_latents.pt"))
+    assert tuple(got.shape) == (2, 4, N_FRAMES, SIZE // 8, SIZE // 8)
+    lats = []
+    for k in range(2):
+        root = os.path.join(base, "Results", "Prompt-Based-Editing", "mini-fshard", "clip", f"edit{k}")
+        sub = os.listdir(root)
+        assert len(sub) == 1
+        lat = torch.load(os.path.join(root, sub[0], "edited_latents.pt"))
+        assert torch.equal(got[k], lat[0])
+        lats.append(lat)
+    assert not torch.equal(lats[0], lats[1])
+    inv_dir = os.path.join(base, "inversions", "mini-fshard", "clip", "ddim_latents")
+    assert len(os.listdir(inv_dir)) == N_STEPS and not [f for f in os.listdir(os.path.dirname(inv_dir)) if "partial" in f]
+
+
+def _gather_disagree_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from anyv2v_amd.parallel import gather_latents
+    dist.init_process_group("gloo")
+    shape = (4, 2, 8, 8) if rank == 0 else (4, 2, 4, 4)      # rank 1's clip has another geometry
+    try:
+        gather_latents([torch.zeros((1,) + shape)], 2, (4, 2, 8, 8), torch.float32, "cpu")
+        msg = "no error"
+    except ValueError as e:
+        msg = "ValueError: " + str(e)[:60]
+    open(os.path.join(out, f"rank{rank}.txt"), "w").write(msg)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gather_latents_raises_on_every_rank_together(tmp_path):
+    """a geometry mismatch on one rank used to raise there and leave the others in the collective until the
+    backend timeout; shapes are agreed on first (all_gather_object), so every rank raises the same error at once."""
+    import torch.multiprocessing as mp
+    mp.spawn(_gather_disagree_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(os.path.join(str(tmp_path), f"rank{r}.txt")).read() for r in range(2)]
+    assert all(m.startswith("ValueError: gather_latents") for m in msgs), msgs
