@@ -259,6 +259,95 @@ def whole_clip(pipe, device, seed):
     return out
 
 
+ALGORITHMIC_TFLOP = {"B1": 20.935, "B3": 62.805}   # torch flop counter over the reference architecture, 16 f x 512^2
+
+
+def executed_flops(engine, hooks_t=None):
+    """MFMA work the product path really issues in ONE forward of ``engine`` (vs the algorithmic count, which prices work the edit
+    step skips exactly: V-only projections, shared softmax, shared stem, source-only conv path, hoisted conditioning): every
+    ops.gemm / ops.attention launch of one eager forward is recorded -- 2 M N K per GEMM (taps and both GEGLU halves included),
+    4 b h Sq Sk d per attention launch, x 2/3 when the spatial shared-softmax kernel runs it (one S / softmax for three V)."""
+    from anyv2v_amd import ops, pnp_utils
+    acc = {"gemm": 0.0, "attention": 0.0, "launches": 0}
+    g0, a0 = ops.gemm, ops.attention
+
+    def gemm(a, w, *args, **kw):
+        M = kw.get("M") or a.shape[0]
+        acc["gemm"] += 2.0 * M * w.shape[0] * w.shape[1]
+        acc["launches"] += 1
+        return g0(a, w, *args, **kw)
+
+    def attention(q, k, v, out, **kw):
+        fl = 4.0 * kw["batch"] * kw["heads"] * kw["Sq"] * kw["Sk"] * kw.get("head_dim", 64)
+        if kw.get("qk_mod", 0) and kw["Sq"] > 16 and not (ops.ATTN_FLAGS & 8):
+            fl *= 2.0 / 3.0
+        acc["attention"] += fl
+        acc["launches"] += 1
+        return a0(q, k, v, out, **kw)
+
+    ops.gemm, ops.attention = gemm, attention
+    try:
+        if hooks_t is not None:
+            pnp_utils.register_time(engine.pipe, hooks_t)
+        else:
+            pnp_utils.clear_time(engine.pipe)
+        engine.unet._forward_core(engine.ctx, engine.sample.clone())
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm, ops.attention = g0, a0
+    return acc
+
+
+def clip_towers_timing(device):
+    """The native CLIP towers at the checkpoint's sizes (OpenCLIP ViT-H/14: text 24 x 1024 / 16 heads, 77 tokens; vision 32 x 1280 /
+    16 heads x 80, 257 tokens), random weights: what one clip pays for them -- three prompts (editing, negative, inversion prompt;
+    pipeline_i2vgen_xl.py:1027-1044) and two 224^2 images (source and edited first frame, :1069-1091).  Their attention is the
+    generic one-thread-per-query kernel (anyv2v_attention_small_f16)."""
+    from anyv2v_amd.clip import CLIPTextTower, CLIPTowerConfig, CLIPVisionTower
+
+    def rnd_sd(prefix, H, L, I, extra):
+        g = torch.Generator(device=device).manual_seed(0)
+        r = lambda *sh: (torch.randn(*sh, generator=g, device=device) * 0.02).half()
+        sd = dict(extra(r))
+        for i in range(L):
+            b = f"{prefix}.encoder.layers.{i}."
+            for n in ("q", "k", "v", "out"):
+                sd[b + f"self_attn.{n}_proj.weight"], sd[b + f"self_attn.{n}_proj.bias"] = r(H, H), r(H)
+            sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"], sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"] = r(I, H), r(I), r(H, I), r(H)
+            for n in ("layer_norm1", "layer_norm2"):
+                sd[b + n + ".weight"], sd[b + n + ".bias"] = 1 + r(H), r(H)
+        return sd
+
+    tcfg = CLIPTowerConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, vocab_size=49408,
+                           max_position_embeddings=77)
+    vcfg = CLIPTowerConfig(hidden_size=1280, num_hidden_layers=32, num_attention_heads=16, intermediate_size=5120, image_size=224,
+                           patch_size=14, projection_dim=1024)
+    text = CLIPTextTower(tcfg, rnd_sd("text_model", 1024, 24, 4096, lambda r: {
+        "text_model.embeddings.token_embedding.weight": r(49408, 1024), "text_model.embeddings.position_embedding.weight": r(77, 1024),
+        "text_model.final_layer_norm.weight": 1 + r(1024), "text_model.final_layer_norm.bias": r(1024)})).to(device)
+    vis = CLIPVisionTower(vcfg, rnd_sd("vision_model", 1280, 32, 5120, lambda r: {
+        "vision_model.embeddings.patch_embedding.weight": r(1280, 3, 14, 14), "vision_model.embeddings.class_embedding": r(1280),
+        "vision_model.embeddings.position_embedding.weight": r(257, 1280), "vision_model.pre_layrnorm.weight": 1 + r(1280),
+        "vision_model.pre_layrnorm.bias": r(1280), "vision_model.post_layernorm.weight": 1 + r(1280),
+        "vision_model.post_layernorm.bias": r(1280), "visual_projection.weight": r(1024, 1280)})).to(device)
+    ids = torch.randint(0, 49408, (3, 77), device=device)
+    px = torch.randn(2, 3, 224, 224, device=device).half()
+    out = {}
+    for name, fn in (("text_3_prompts_ms", lambda: text.encode_ids(ids, 1)), ("vision_2_images_ms", lambda: vis.image_embeds(px))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            y = fn()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+        assert bool(torch.isfinite(y.float()).all())
+    out["total_ms"] = round(out["text_3_prompts_ms"] + out["vision_2_images_ms"], 2)
+    out["what"] = ("native CLIP towers (anyv2v_amd/clip.py) at the checkpoint's sizes, random weights, eager launches: 3 prompts x 77 tokens "
+                   "through 24 layers (clip_skip 1) + 2 images x 257 tokens through 32 layers; once per clip, not in `seconds` above")
+    return out
+
+
 def finish_distributed(dist, dt, latents, world, device):
     """The one collective of the sharded job -- all_gather of every rank's edited latents (512 KiB per rank at
     16f x 512^2; RCCL over xGMI on the GPU node, gloo in the CPU test) -- plus MAX over ranks of the timed region."""
@@ -352,6 +441,7 @@ def main():
     if dist is not None:
         dt, _gathered = finish_distributed(dist, dt, s_pnp[2:3].contiguous(), world, device)
     finite = bool(torch.isfinite(s_pnp.float()).all() and torch.isfinite(s_inv.float()).all())
+    rccl_ranks = len(_gathered) if dist is not None else None
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -369,6 +459,30 @@ def main():
                        "excluded": "`value` is the steady-state loop rate: VAE encode/decode, CLIP encoders and file I/O are outside "
                                    "(SURVEY 8(f) F1/F2); the `clip` object times one whole clip including VAE and the trajectory files"},
         }
+        if rccl_ranks is not None:   # how many ranks' edited latents the one all_gather of the job delivered to rank 0
+            line["rccl_ranks"] = rccl_ranks
+            line["rccl_gathered_finite"] = bool(all(torch.isfinite(g.float()).all() for g in _gathered))
+        # what is executed vs what the metric prices: one eager forward of each step kind with every GEMM / attention launch recorded
+        ex1 = executed_flops(e_inv)
+        ex3 = executed_flops(e_pnp, hooks_t=ts_pnp[0])
+        ex_t = (ex1["gemm"] + ex1["attention"] + ex3["gemm"] + ex3["attention"]) / 1e12
+        alg_t = ALGORITHMIC_TFLOP["B1"] + ALGORITHMIC_TFLOP["B3"]
+        line["flops"] = {"algorithmic_tflop_per_step": alg_t, "executed_tflop_per_step": round(ex_t, 3),
+                         "executed_tflop_B1": round((ex1["gemm"] + ex1["attention"]) / 1e12, 3),
+                         "executed_tflop_B3": round((ex3["gemm"] + ex3["attention"]) / 1e12, 3),
+                         "executed_attention_tflop_B3": round(ex3["attention"] / 1e12, 3),
+                         "gemm_attention_launches_B1_B3": [ex1["launches"], ex3["launches"]],
+                         "step_frac_algorithmic": round(alg_t / (ms * 1e-3) / PEAK_MFMA_F16_TFLOPS, 4),
+                         "step_frac_executed": round(ex_t / (ms * 1e-3) / PEAK_MFMA_F16_TFLOPS, 4),
+                         "what": "MFMA work per bench step (1 inversion step B=1 + 1 edit step B=3) / ms_per_step / 2500 TFLOP/s; algorithmic = the "
+                                 "reference architecture's count (SURVEY 8(d)), executed = summed over the launches of one eager forward of each kind "
+                                 "(exact savings: hoisted conditioning, V-only projections, shared softmax, shared stem, source-only conv path)"}
+        traffic = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")))
+        if traffic:
+            try:
+                line["step_traffic"] = dict(json.load(open(traffic[-1])), source=os.path.relpath(traffic[-1], ROOT))
+            except Exception:
+                pass
         if not args.no_roofline:  # rank 0, after the timed region (the other ranks wait at destroy_process_group)
             line["roofline"] = roofline_spatial_attention(device)
             line["roofline_pnp"] = roofline_spatial_attention(device, pnp=True)
@@ -378,6 +492,7 @@ def main():
             torch.cuda.empty_cache()
             pnp_utils.clear_time(pipe)
             line["clip"] = whole_clip(pipe, device, args.seed)
+            line["clip"]["clip_towers"] = clip_towers_timing(device)
             e_inv = e_pnp = None
         if world == 1 and not args.no_cpu_baseline:
             del pipe, e_inv, e_pnp

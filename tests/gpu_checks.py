@@ -1790,9 +1790,11 @@ def check_frame_parallel(Fr=4, hw=16, tol=4e-3):
     import types
     from anyv2v_amd import pnp_utils
     from anyv2v_amd.parallel import FrameParallel
+    from oracle import pnp_oracle
     out = []
     fp = FrameParallel()
-    native, _, ocfg = build_pair("mini", 1234)
+    native, oracle, ocfg = build_pair("mini", 1234)
+    otol = 3e-2   # mini model, HIP fp16 (or the CPU emulation) vs the fp32 CPU oracle: the bound of check_unet_vs_oracle's fixed form
     for B in (1, 3):
         inp = config1_inputs(ocfg, B, Fr, hw)
         if B == 3:  # the edit loop's batch: slots 1 and 2 share latent and image latents (shared stem allowed)
@@ -1809,10 +1811,18 @@ def check_frame_parallel(Fr=4, hw=16, tol=4e-3):
             pnp_utils.register_conv_injection(pipe, ts[:10])
             pnp_utils.register_spatial_attention_pnp(pipe, ts[:25])
             pnp_utils.register_temp_attention_pnp(pipe, ts[:40])
+            pnp_oracle.register_conv_injection(oracle, ts[:10])
+            pnp_oracle.register_spatial_attention_pnp(oracle, ts[:25])
+            pnp_oracle.register_temp_attention_pnp(oracle, ts[:40])
             cases = [("PnP all sites", 981, False), ("PnP temporal only + shared stem", 301, True), ("PnP off", 1, True)]
         for name, t, shared in cases:
             if B == 3:
                 pnp_utils.register_time(pipe, t)
+                pnp_oracle.register_time(oracle, t)
+            with torch.no_grad():  # the checker: fp32 CPU oracle on the same fp16-rounded inputs (not only "vs itself")
+                v_or = oracle(smp.float().cpu(), t, fps=inp["fps"], image_latents=inp["image_latents"].half().float(),
+                              image_embeddings=inp["image_embeddings"].half().float(),
+                              encoder_hidden_states=inp["encoder_hidden_states"].half().float())[0]
             res = []
             for use_fp in (None, fp):
                 native.set_frame_parallel(use_fp)
@@ -1820,6 +1830,9 @@ def check_frame_parallel(Fr=4, hw=16, tol=4e-3):
                 native._ctx.shared_stem = shared
                 res.append(native(smp, t, **kw)[0].float().cpu())
             out.append(_res(f"frame-parallel x{fp.world} rank {fp.rank}: B{B} {name} vs unsharded", res[1], res[0], tol))
+            out.append(_res(f"frame-parallel x{fp.world} rank {fp.rank}: B{B} {name} vs the fp32 CPU oracle", res[1], v_or, otol))
+        if B == 3:
+            pnp_oracle.clear_hooks(oracle)
     # the pipeline loops on top (unchanged code: every rank steps the full, replicated latents): 4-step inversion, then
     # a 4-step PnP edit with schedules that end early (so the 2-branch steps are covered too)
     from anyv2v_amd.pipeline import I2VGenXLPipeline
