@@ -1,4 +1,4 @@
-// Weight-stationary streaming GEMM for the K = 320 Linear layers of the 64x64 level (gfx950).
+// Weight-stationary streaming GEMM for the short-K Linear layers of the 64x64 level (K = 320; transformer_in: K = 512) (gfx950).
 //
 // Replaces (reference = TIGER-AI-Lab/AnyV2V): attn.to_q / to_k / to_v / to_out[0] at the 320-channel level
 // (i2vgen-xl/pnp_utils.py:175,182-183,216), and the diffusers-0.26.3 Transformer2DModel / TransformerTemporalModel
@@ -22,22 +22,21 @@
 #include "gemm_common.h"
 
 namespace {
-
-constexpr int WS_K = 320;            // reduction length this kernel is built for
-constexpr int WS_KS = WS_K / 32;     // MFMA K-steps per strip
-constexpr int WS_NS = 160;           // W slab columns per block
-constexpr int WS_NF = WS_NS / 16;    // 16-column MFMA fragments per slab
 constexpr int WS_RW = 32;            // rows per wave strip
 #ifndef WS_PRIO
 #define WS_PRIO 1
 #endif
-constexpr int WS_W_BYTES = (WS_K / 64) * WS_NS * 128;  // 102400
-constexpr int WS_BIAS_BYTES = WS_NS * 2;               // slab bias, fp16
 }  // namespace
 
 // TRACE (probe build only, tools/gemm_ws_trace.py): s_memtime stamps of the third strip of waves 0 and 4 of every block
-template <bool GEGLU, bool RES, int WS_R, int WQ, bool RR_EARLY, bool TRACE = false>
+// WS_K: reduction length (320: the 64x64 level's transformers; 512: transformer_in), WS_NS: W slab columns per block (W slab =
+// WS_NS x WS_K x 2 bytes of LDS), WS_R: K-steps of register look-ahead (even: line halves requested in pairs), WQ: weight-fragment ring
+template <int WS_K, int WS_NS, bool GEGLU, bool RES, int WS_R, int WQ, bool RR_EARLY, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPlan plan) {
+    constexpr int WS_KS = WS_K / 32;     // MFMA K-steps per strip
+    constexpr int WS_NF = WS_NS / 16;    // 16-column MFMA fragments per slab
+    constexpr int WS_W_BYTES = (WS_K / 64) * WS_NS * 128;
+    constexpr int WS_BIAS_BYTES = WS_NS * 2;               // slab bias, fp16
     constexpr int OUT_W = GEGLU ? WS_NS / 2 : WS_NS;   // output columns of a slab
     constexpr int SLAB_LD = OUT_W + 8;                 // halves; keeps rows 16-byte aligned, breaks the power-of-2 stride
     constexpr int SLAB_BYTES = 16 * SLAB_LD * 2;       // per wave: one 16-row half strip
@@ -110,7 +109,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
     half_t* const slabp = (half_t*)(smem + WS_W_BYTES + WS_BIAS_BYTES + w * SLAB_BYTES);
     const half_t* const bias_l = (const half_t*)(smem + WS_W_BYTES);
     const int n_out_wave = GEGLU ? n_wave / 2 : n_wave;
-    static_assert(WS_KS % WS_R == 0, "static ring indices need WS_R | WS_KS");
+    static_assert(WS_KS % WS_R == 0 && WS_K % 64 == 0 && WS_NS % 16 == 0 && (!GEGLU || WS_NS % 32 == 0), "static ring indices need WS_R | WS_KS");
+    static_assert(WS_W_BYTES + WS_BIAS_BYTES + 8 * SLAB_BYTES <= 160 * 1024, "W slab + epilogue slabs must fit in LDS");
 
     int nth = 0;
     if constexpr (TRACE) if (w >= plan.trace_waves) return;   // probe: one wave per SIMD (4) or per pair of SIMDs (2) only
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
                     a[u % WS_R][mf] = *(const h8*)(q + (u < WS_KS ? u : u - WS_KS) * 32);
                 }
         };
-        constexpr bool PAIRS = WS_R == WS_KS;
+        constexpr bool PAIRS = WS_R % 2 == 0;
         h8 wq[WQ], fr[2][2];
 #pragma unroll
         for (int i = 0; i < WQ - 1; ++i) wq[i] = wfrag(i);
@@ -185,8 +185,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
         if (WS_PRIO) __builtin_amdgcn_s_setprio(WS_PRIO);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int idx = 0; idx < NFR; ++idx) {
-            const int s = idx / WS_NF, nf = idx - s * WS_NF;
+        for (int s = 0; s < WS_KS; ++s)
+#pragma unroll
+        for (int nf = 0; nf < WS_NF; ++nf) {   // (two nested fully unrolled loops: one flat loop of 128 iterations is only partly unrolled)
+            const int idx = s * WS_NF + nf;
             if (idx + WQ - 1 < NFR) wq[(idx + WQ - 1) % WQ] = wfrag(idx + WQ - 1);
             acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx % WQ], fr[s & 1][0], acc[0][nf], 0, 0, 0);
             acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx % WQ], fr[s & 1][1], acc[1][nf], 0, 0, 0);
@@ -255,37 +257,53 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
 }
 
 // host side: can this launch run on the weight-stationary kernel, and how are (slab, row range) dealt to the 256 blocks
+static int ws_slab_cols(const AnyV2VGemmDesc* d) {   // 0 = shape not covered
+    if (d->C0 == 320) return 160;
+    // K = 512 (transformer_in): GEGLU with 128-column slabs (1291 -> 834 us at 196608 rows); plain launches would need 64-column
+    // slabs (128 + their epilogue slabs exceed LDS), which only pays for N = 512 (x 1.07-1.16; QKV N = 1536: x 0.87-0.96, left to
+    // the tile kernels) -- profiles/r03_gemm_ws_ab.txt
+    if (d->C0 == 512) return d->act == ACT_GEGLU ? 128 : (d->N == 512 ? 64 : 0);
+    return 0;
+}
+
 bool av_gemm_ws_eligible(const AnyV2VGemmDesc* d) {
-    return d->mode == MODE_LINEAR && d->C0 == WS_K && d->C1 == 0 && d->N % WS_NS == 0 && d->N / WS_NS <= 32 &&
+    const int ns = ws_slab_cols(d);
+    return d->mode == MODE_LINEAR && ns > 0 && d->C1 == 0 && d->N % ns == 0 && d->N / ns <= 32 &&
            (d->act == ACT_NONE || (d->act == ACT_GEGLU && d->R == nullptr)) && d->rowvec == nullptr && d->M > 0;
 }
 
 int av_gemm_ws_launch(const GemmK& k_in, const AnyV2VGemmDesc* d, hipStream_t s) {
     GemmK k = k_in;
     WsPlan plan;
-    plan.S = d->N / WS_NS;
+    const int ns = ws_slab_cols(d);
+    plan.S = d->N / ns;
     plan.px = 32 / plan.S;
     plan.nstrips = (d->M + WS_RW - 1) / WS_RW;
     const int nranges = 8 * plan.px;
     plan.spr = (plan.nstrips + nranges - 1) / nranges;
     plan.trace_waves = (d->flags & 8192) ? 4 : ((d->flags & 16384) ? 1 : 8);
-    const int var = (d->flags >> 11) & 3;   // A/B of the ring depth / weight-fragment look-ahead / residual request point
-#define WS_GO(G, RS, R, Q, E, T) hipLaunchKernelGGL((gemm_ws_kernel<G, RS, R, Q, E, T>), dim3(256), dim3(512), 0, s, k, plan)
+    const bool geglu = d->act == ACT_GEGLU, res = d->R != nullptr;
+#define WS_GO(K, NS, G, RS, R, Q, E, T) hipLaunchKernelGGL((gemm_ws_kernel<K, NS, G, RS, R, Q, E, T>), dim3(256), dim3(512), 0, s, k, plan)
 #ifdef ANYV2V_EXPERIMENTS  // probe build only: per-strip phase timestamps (flags bit5), tools/gemm_ws_trace.py
-    if ((d->flags & 32) && d->workspace != nullptr && (size_t)256 * 2 * 16 * sizeof(long long) <= (size_t)d->workspace_bytes) {
+    if ((d->flags & 32) && d->C0 == 320 && d->workspace != nullptr && (size_t)256 * 2 * 16 * sizeof(long long) <= (size_t)d->workspace_bytes) {
         k.trace = (long long*)d->workspace;
-        if (d->act == ACT_GEGLU) WS_GO(true, false, 5, 8, false, true);
-        else if (d->R != nullptr) WS_GO(false, true, 10, 4, false, true);
-        else WS_GO(false, false, 10, 4, false, true);
+        if (geglu) WS_GO(320, 160, true, false, 5, 8, false, true);
+        else if (res) WS_GO(320, 160, false, true, 10, 4, false, true);
+        else WS_GO(320, 160, false, false, 10, 4, false, true);
         return av_launch_status("gemm_ws<trace>");
     }
 #endif
     // (A/B in profiles/r03_gemm_ws_ab.txt: ring depth 5 vs 10, weight look-ahead 3 vs 7, residual requested first vs after the
     //  K loop -- all within 3 % except: pairs matter for QKV at 196608 rows, the late residual request for the +residual launches)
-    (void)var;
-    if (d->act == ACT_GEGLU) WS_GO(true, false, 5, 8, false, false);
-    else if (d->R != nullptr) WS_GO(false, true, 10, 4, false, false);
-    else WS_GO(false, false, 10, 4, false, false);
+    if (d->C0 == 320) {
+        if (geglu) WS_GO(320, 160, true, false, 5, 8, false, false);
+        else if (res) WS_GO(320, 160, false, true, 10, 4, false, false);
+        else WS_GO(320, 160, false, false, 10, 4, false, false);
+    } else {
+        if (geglu) WS_GO(512, 128, true, false, 8, 8, false, false);
+        else if (res) WS_GO(512, 64, false, true, 8, 4, false, false);
+        else WS_GO(512, 64, false, false, 8, 8, false, false);
+    }
 #undef WS_GO
     return av_launch_status("gemm_ws");
 }

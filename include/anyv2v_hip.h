@@ -64,7 +64,7 @@ typedef struct AnyV2VGemmDesc {
     int32_t flags;       /* bit0: force the naive reference kernel; bit1: LDS-DMA staging; bit2: never use the
                             persistent 192x320 kernel (nor the weight-stationary one); bit3: always use it when the shape
                             allows; bit4: no split-K; bit9 (512): never use the weight-stationary K = 320 kernel; bit10 (1024):
-                            use it whenever the shape allows (mode 0, C0 = 320, C1 = 0, N % 160 = 0, act 0 | 3, no rowvec), also
+                            use it whenever the shape allows (mode 0, C0 = 320 with N % 160 = 0 or C0 = 512 with N % 64 = 0 (GEGLU: 128), C1 = 0, act 0 | 3, no rowvec), also
                             below its M >= 32768 threshold.  All other bits are ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;

@@ -275,6 +275,25 @@ def check_gemm_ws():
             y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU)
             proj = a.float() @ wfull.float().t() + bfull.float()
             out.append(_res(f"gemm[ws] GEGLU M{M} inner{inner}", y, proj[:, :inner] * F.gelu(proj[:, inner:]), KTOL))
+        # transformer_in's width (K = 512): 64-column slabs (128 for GEGLU), 16 K-steps, ring of 8
+        ops.GEMM_FLAGS = saved | 1024
+        K5 = 512
+        for (M, N, res) in [(4100, 512, True), (9001, 512, False), (33000, 512, True)]:
+            a, w, bias = rnd(M, K5), rnd(N, K5, scale=1 / math.sqrt(K5)), rnd(N)
+            r = rnd(M, N) if res else None
+            ops.GEMM_FLAGS = saved | 1024
+            y = ops.gemm(a, w, bias=bias, residual=r)
+            out.append(_res(f"gemm[ws] K512 M{M} N{N} res={res}", y, _gemm_ref(a, w, bias, residual=r), KTOL))
+            ops.GEMM_FLAGS = saved | 512
+            out.append(_res(f"gemm[ws] K512 == tile kernels M{M} N{N}", y, ops.gemm(a, w, bias=bias, residual=r).float(), 1e-3))
+        ops.GEMM_FLAGS = saved | 1024
+        for (M, inner) in [(3000, 2048), (777, 128)]:
+            a = rnd(M, K5)
+            wfull, bfull = rnd(2 * inner, K5, scale=1 / math.sqrt(K5)), rnd(2 * inner, scale=0.1)
+            wp, bp = _geglu_pack(wfull, bfull, inner)
+            y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU)
+            proj = a.float() @ wfull.float().t() + bfull.float()
+            out.append(_res(f"gemm[ws] K512 GEGLU M{M} inner{inner}", y, proj[:, :inner] * F.gelu(proj[:, inner:]), KTOL))
         # the dispatch threshold itself (no flag): the inversion step's row count, with residual; bit-reproducible
         ops.GEMM_FLAGS = saved
         M = 65536

@@ -32,8 +32,7 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-def case(tag, M, N, act=0, res=False, ldc=None):
-    K = 320
+def case(tag, M, N, act=0, res=False, ldc=None, K=320):
     a = torch.randn(M, K, device=dev).half()
     w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
     b = (torch.randn(N, device=dev) * 0.1).half()
@@ -66,6 +65,9 @@ for B, tagB in ((3, "B3"), (1, "B1")):
     if B == 3:
         case(f"{tagB} V-only (2/3 T, ldc 960)", 2 * 65536, 320, ldc=960)
         case(f"{tagB} QKV source third", 65536, 960)
+    case(f"{tagB} t_in GEGLU K512", T, 4096, act=3, K=512)
+    case(f"{tagB} t_in QKV K512", T, 1536, K=512)
+    case(f"{tagB} t_in proj+res K512", T, 512, res=True, K=512)
 ops.GEMM_FLAGS = 0
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", "gemm_ws_ab.txt"), "w").write("\n".join(lines) + "\n")
