@@ -53,7 +53,9 @@ __device__ __forceinline__ float av_gelu(float x) {
     p = fmaf(p, t, 0.127414796f);
     const float u = x * 0.84932180f;                                       // sqrt(log2(e) / 2): exp2(-u^2) = exp(-x^2 / 2)
     const float q = (p * t) * __builtin_amdgcn_exp2f(-(u * u));
-    return fmaf(-ax, q, fmaxf(x, 0.0f));
+    float m;   // max(x, 0) as ONE instruction: fmaxf() on an MFMA result is preceded by a canonicalising v_max_f32 x, x
+    asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(x));
+    return fmaf(-ax, q, m);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
