@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("stride", C.c_int32), ("up", C.c_int32), ("asym", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32),
         ("act", C.c_int32), ("flags", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("ln_c1", C.c_void_p), ("ln_eps", C.c_float), ("reserved0", C.c_int32),
     ]
 
 

@@ -1039,6 +1039,8 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     k.splits = 1;
     k.partial = nullptr;
     k.trace = nullptr;
+    k.ln_c1 = nullptr;
+    k.ln_eps = 0.f;
     k.vec_epi = (((uintptr_t)d->bias & 7) == 0) && (((uintptr_t)d->rowvec & 7) == 0) && (d->ldrv % 4 == 0) && (d->N % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
 
@@ -1050,6 +1052,14 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
                       k.vec_epi;
     // K = 320 Linear layers with many rows (the 64x64 level): weight-stationary streaming kernel (gemm_ws.hip).
     // flags bit9 (512): never, bit10 (1024): whenever the shape allows (tests; small M leaves most waves idle)
+    if (d->ln_c1 != nullptr) {   // LayerNorm folded into the GEMM: only the weight-stationary kernel implements it
+        if (!(fast && (d->flags & 2) && !(d->flags & 1) && av_gemm_ws_eligible(d) && (((uintptr_t)d->ln_c1) & 15) == 0)) {
+            anyv2v_set_error("gemm: ln_c1 (LayerNorm fold) needs mode 0, C0 = 320 (N %% 160 = 0) or C0 = 512 with GEGLU (N %% 128 = 0), no "
+                             "residual / rowvec, 16-byte aligned operands -- got C0 %d N %d act %d", d->C0, d->N, d->act);
+            return ANYV2V_EUNSUPPORTED;
+        }
+        return av_gemm_ws_launch(k, d, s);
+    }
     if (fast && (d->flags & 2) && !(d->flags & (512 | 4 | 1)) && av_gemm_ws_eligible(d) &&
         (d->M >= 32768 || (d->flags & 1024)))
         return av_gemm_ws_launch(k, d, s);

@@ -23,6 +23,8 @@ struct GemmK {
     int splits;   // split-K factor (128-row kernel only): each split writes an fp32 partial tile, reduced afterwards
     float* partial;  // [splits][M][N] fp32 workspace
     long long* trace;  // debug (flags bit5): 32 timestamps per block, see tools/gemm_trace.py
+    const float* ln_c1;  // LayerNorm fold (gemm_ws.hip): column sums of the gamma-scaled weights, or nullptr
+    float ln_eps;
 };
 
 struct RowInfo {

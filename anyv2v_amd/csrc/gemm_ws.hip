@@ -31,12 +31,13 @@ constexpr int WS_RW = 32;            // rows per wave strip
 // TRACE (probe build only, tools/gemm_ws_trace.py): s_memtime stamps of the third strip of waves 0 and 4 of every block
 // WS_K: reduction length (320: the 64x64 level's transformers; 512: transformer_in), WS_NS: W slab columns per block (W slab =
 // WS_NS x WS_K x 2 bytes of LDS), WS_R: K-steps of register look-ahead (even: line halves requested in pairs), WQ: weight-fragment ring
-template <int WS_K, int WS_NS, bool GEGLU, bool RES, int WS_R, int WQ, bool RR_EARLY, bool TRACE = false>
+template <int WS_K, int WS_NS, bool GEGLU, bool RES, int WS_R, int WQ, bool RR_EARLY, bool TRACE = false, bool LN = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPlan plan) {
     constexpr int WS_KS = WS_K / 32;     // MFMA K-steps per strip
     constexpr int WS_NF = WS_NS / 16;    // 16-column MFMA fragments per slab
     constexpr int WS_W_BYTES = (WS_K / 64) * WS_NS * 128;
-    constexpr int WS_BIAS_BYTES = WS_NS * 2;               // slab bias, fp16
+    constexpr int WS_BIAS_BYTES = WS_NS * 2 + (LN ? WS_NS * 4 : 0);   // slab bias (fp16) [+ the LayerNorm fold's column sums c1, fp32]
+    static_assert(!(LN && RES), "the LayerNorm-folded form has no residual epilogue (QKV / to_q / GEGLU take none)");
     constexpr int OUT_W = GEGLU ? WS_NS / 2 : WS_NS;   // output columns of a slab
     constexpr int SLAB_LD = OUT_W + 8;                 // halves; keeps rows 16-byte aligned, breaks the power-of-2 stride
     constexpr int SLAB_BYTES = 16 * SLAB_LD * 2;       // per wave: one 16-row half strip
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
         if (tid < WS_NS / 4) {
             const h4 b = *(const h4*)(p.bias != nullptr ? p.bias + n_wave + tid * 4 : p.zeros);
             *(h4*)(smem + WS_W_BYTES + tid * 8) = b;
+            if constexpr (LN) *(f4*)(smem + WS_W_BYTES + WS_NS * 2 + tid * 16) = *(const f4*)(p.ln_c1 + n_wave + tid * 4);
         }
     }
     __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) here; nothing LDS-bound is in flight afterwards)
@@ -149,8 +151,15 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
 #pragma unroll
             for (int j = 0; j < WS_NF; ++j) {   // the accumulators start at the bias (lane: channels 16 j + 4 lq .. + 3)
                 const h4 b = *(const h4*)(bias_l + j * 16 + 4 * lq);
-                acc[i][j] = (f4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                acc[i][j] = LN ? (f4){0.f, 0.f, 0.f, 0.f} : (f4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
             }
+        // LayerNorm fold (LN): the rows arrive UN-normalised; with W' = W diag(gamma), c1[n] = sum_k W'[n][k], b' = b + W beta:
+        //   LN(x) W^T + b = rstd (x W'^T - mean c1) + b'.   The row statistics come out of the matrix pipe as well: one MFMA of the
+        // activation fragment with itself per K-step (Gram matrix: its diagonal is sum x^2) and one with a fragment of ones (sum x).
+        f4 accq[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}}, accs[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+        h8 ones;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.0f;
 
         // K loop, written in issue order and pinned (hipcc otherwise sinks the look-ahead loads behind the last MFMA and
         // reads each weight fragment right in front of its consumers): weight fragments roll WQ - 1 MFMA pairs ahead;
@@ -192,6 +201,12 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
             if (idx + WQ - 1 < NFR) wq[(idx + WQ - 1) % WQ] = wfrag(idx + WQ - 1);
             acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx % WQ], fr[s & 1][0], acc[0][nf], 0, 0, 0);
             acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[idx % WQ], fr[s & 1][1], acc[1][nf], 0, 0, 0);
+            if constexpr (LN) {
+                if (nf == 4 || nf == 5) {   // row statistics of this K-step, row block nf - 4
+                    accq[nf - 4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s & 1][nf - 4], fr[s & 1][nf - 4], accq[nf - 4], 0, 0, 0);
+                    accs[nf - 4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, fr[s & 1][nf - 4], accs[nf - 4], 0, 0, 0);
+                }
+            }
             if (nf == 2 && s + 1 < WS_KS) {   // next K-step's fragments, seven MFMA pairs ahead of their first use
                 fr[(s + 1) & 1][0] = to_frag(a[(s + 1) % WS_R][0]);
                 fr[(s + 1) & 1][1] = to_frag(a[(s + 1) % WS_R][1]);
@@ -212,6 +227,31 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmK p, const WsPla
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int l15_e = lane_e & 15, lq_e = lane_e >> 4;
+        float ln_mean[2] = {0.f, 0.f}, ln_rstd[2] = {1.f, 1.f};
+        if constexpr (LN) {
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                // D[i][j] of the Gram MFMA sits in lane (j = l15, lq = i >> 2), register i & 3: token j's own sum x^2 is register
+                // l15 & 3 of the lane with lq == l15 >> 2 -- select, then fetch it from that lane; sum x is in every register
+                const int r3 = l15_e & 3;
+                float d = r3 == 0 ? accq[mf][0] : (r3 == 1 ? accq[mf][1] : (r3 == 2 ? accq[mf][2] : accq[mf][3]));
+                d = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((l15_e >> 2) * 16 + l15_e) * 4, __builtin_bit_cast(int, d)));
+                const float mean = accs[mf][0] * (1.0f / WS_K);
+                const float var = fmaxf(d * (1.0f / WS_K) - mean * mean, 0.0f);
+                ln_mean[mf] = mean;
+                ln_rstd[mf] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+            }
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < WS_NF; ++nf) {
+                    const f4 c1 = *(const f4*)((const char*)bias_l + WS_NS * 2 + (nf * 16 + 4 * lq_e) * 4);
+                    const h4 b = *(const h4*)(bias_l + nf * 16 + 4 * lq_e);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[mf][nf][r] = fmaf(fmaf(-ln_mean[mf], c1[r], acc[mf][nf][r]), ln_rstd[mf], (float)b[r]);
+                }
+        }
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
             if constexpr (GEGLU) {
@@ -268,6 +308,7 @@ static int ws_slab_cols(const AnyV2VGemmDesc* d) {   // 0 = shape not covered
 
 bool av_gemm_ws_eligible(const AnyV2VGemmDesc* d) {
     const int ns = ws_slab_cols(d);
+    if (d->ln_c1 != nullptr && (d->R != nullptr || (d->C0 == 512 && d->act != ACT_GEGLU))) return false;
     return d->mode == MODE_LINEAR && ns > 0 && d->C1 == 0 && d->N % ns == 0 && d->N / ns <= 32 &&
            (d->act == ACT_NONE || (d->act == ACT_GEGLU && d->R == nullptr)) && d->rowvec == nullptr && d->M > 0;
 }
@@ -295,6 +336,19 @@ int av_gemm_ws_launch(const GemmK& k_in, const AnyV2VGemmDesc* d, hipStream_t s)
 #endif
     // (A/B in profiles/r03_gemm_ws_ab.txt: ring depth 5 vs 10, weight look-ahead 3 vs 7, residual requested first vs after the
     //  K loop -- all within 3 % except: pairs matter for QKV at 196608 rows, the late residual request for the +residual launches)
+    if (d->ln_c1 != nullptr) {   // LayerNorm folded in (QKV / to_q / GEGLU-up of the transformer blocks)
+        k.ln_c1 = d->ln_c1;
+        k.ln_eps = d->ln_eps;
+#define WS_GO_LN(K, NS, G, R, Q) hipLaunchKernelGGL((gemm_ws_kernel<K, NS, G, false, R, Q, false, false, true>), dim3(256), dim3(512), 0, s, k, plan)
+        if (d->C0 == 320) {
+            if (geglu) WS_GO_LN(320, 160, true, 5, 4);
+            else WS_GO_LN(320, 160, false, 10, 4);
+        } else {
+            WS_GO_LN(512, 128, true, 8, 4);
+        }
+#undef WS_GO_LN
+        return av_launch_status("gemm_ws<LN>");
+    }
     if (d->C0 == 320) {
         if (geglu) WS_GO(320, 160, true, false, 5, 8, false, false);
         else if (res) WS_GO(320, 160, false, true, 10, 4, false, false);

@@ -48,8 +48,11 @@ def _workspace(device) -> torch.Tensor:
 
 def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowvec=None,
          rowvec_div: int = 0, residual=None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
-         mode: int = MODE_LINEAR, conv=None, temporal=None, M: Optional[int] = None, naive: bool = False):
+         mode: int = MODE_LINEAR, conv=None, temporal=None, M: Optional[int] = None, naive: bool = False, ln=None):
     """out[M, N'] = epilogue(gather(A) @ W^T).  ``w`` is [N, taps*K] packed (see anyv2v_hip.h).
+
+    ``ln`` = (c1 fp32 [N], eps): LayerNorm folded into the projection -- ``a0`` holds the un-normalised rows, ``w`` / ``bias`` the
+    gamma- / beta-folded weights (``ln_fold``); only shapes ``ln_gemm_supported`` accepts.
 
     conv = (Hi, Wi, Ho, Wo, stride, up[, asym]) for MODE_CONV2D; temporal = (F, HW) for MODE_TEMPORAL.
     ``M`` overrides the row count (output rows); A may have a different number of rows for convs.
@@ -97,10 +100,37 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         d.F, d.HW = temporal
     d.act = act
     d.flags = (1 if (naive or FORCE_NAIVE) else 0) | (2 if USE_GLDS else 0) | GEMM_FLAGS
+    if ln is not None:
+        c1, eps = ln
+        assert c1.dtype == torch.float32 and c1.is_cuda and c1.numel() >= N and c1.is_contiguous()
+        d.ln_c1, d.ln_eps = _p(c1), float(eps)
     ws = _workspace(a0.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _lib.check(lib.anyv2v_gemm_f16(C.byref(d), _stream()), "anyv2v_gemm_f16")
     return out
+
+
+def ln_gemm_supported(M: int, K: int, N: int, act: int = ACT_NONE) -> bool:
+    """Shapes for which ``gemm(..., ln=...)`` runs (the weight-stationary kernel, gemm_ws.hip) AND pays: the 64x64 level's row
+    counts.  Mirrors the library's own check; everything else runs ``layernorm`` + ``gemm``."""
+    if FORCE_NAIVE or not USE_GLDS or (GEMM_FLAGS & (512 | 4)) or M < 32768:
+        return False
+    if K == 320:
+        return N % 160 == 0 and N // 160 <= 32
+    return K == 512 and act == ACT_GEGLU and N % 128 == 0 and N // 128 <= 32
+
+
+def ln_fold(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """(W', b', c1) of LN(x) W^T + b = rstd (x W'^T - mean c1) + b':  W' = W diag(gamma) rounded to fp16, c1 = row sums of that
+    ROUNDED W' in fp32 (so that x W'^T - mean c1 is exactly the product of the centred row with the weights the kernel multiplies
+    by: no cancellation error from the rounding), b' = b + W beta."""
+    wf = w.float() * gamma.float()[None, :]
+    w16 = wf.to(torch.float16).contiguous()
+    c1 = w16.float().sum(1).contiguous()
+    b = w.float() @ beta.float()
+    if bias is not None:
+        b = b + bias.float()
+    return w16, b.to(torch.float16).contiguous(), c1
 
 
 def gn_scratch_floats(M: int, rows_per_group: int, groups: int = 32) -> int:

@@ -240,8 +240,18 @@ class HipAttnProcessor:
         self.injection_schedule = injection_schedule
         self.t = None
 
-    def run(self, attn: "Attention", ctx, h, geom: Geom, residual, kv=None):
+    def run(self, attn: "Attention", ctx, h, geom: Geom, residual, kv=None, ln_in=None):
+        """``ln_in`` = (x, (W', b', c1), eps): the block's LayerNorm is folded into this attention's first projection
+        (``ops.gemm(..., ln=...)``); ``h`` is then None and ``x`` the un-normalised residual stream."""
         Cq = attn.inner_dim
+        if ln_in is not None:
+            h, (w_in, b_in, c1_in), ln_eps = ln_in
+
+            def proj(rows, lo=0, out=None):   # rows of x -> columns [lo, ...) of the folded projection
+                return ops.gemm(rows, w_in[lo:], bias=b_in[lo:], ln=(c1_in[lo:], ln_eps), out=out)
+        else:
+            def proj(rows, lo=0, out=None):
+                return ops.gemm(rows, (attn._w_qkv if kv is None else attn.to_q.weight)[lo:], out=out)
         T = h.shape[0]
         o = torch.empty((T, Cq), dtype=torch.float16, device=h.device)
         if kv is None:  # self-attention
@@ -252,16 +262,16 @@ class HipAttnProcessor:
                 # FLOPs and stores in this projection)
                 Ts = T // 3
                 qkv = torch.empty((T, 3 * Cq), dtype=torch.float16, device=h.device)
-                ops.gemm(h[:Ts], attn._w_qkv, out=qkv[:Ts])
-                ops.gemm(h[Ts:], attn._w_qkv[2 * Cq:], out=qkv[Ts:, 2 * Cq:])
+                proj(h[:Ts], 0, qkv[:Ts])
+                proj(h[Ts:], 2 * Cq, qkv[Ts:, 2 * Cq:])
             else:
-                qkv = ops.gemm(h, attn._w_qkv)
+                qkv = proj(h)
             qk_mod = geom.batch // 3 if inject else 0
             ops.attention(qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], o, batch=geom.batch, heads=attn.heads,
                           Sq=geom.S, Sk=geom.S, inner=geom.inner, q_strides=geom.strides, kv_strides=geom.strides,
                           qk_mod=qk_mod, scale=attn.scale)
         else:  # cross-attention against the per-clip cached K/V  ([B*Sk, 2C] column window of ctx.kv_all)
-            q = ops.gemm(h, attn.to_q.weight)
+            q = proj(h)
             k_, v_, Sk = kv
             ops.attention(q, k_, v_, o, batch=geom.batch, heads=attn.heads, Sq=geom.S, Sk=Sk, inner=1,
                           q_strides=geom.strides, kv_strides=(Sk, 0, 1), kv_div=geom.F, scale=attn.scale)
@@ -299,10 +309,11 @@ class Attention(nn.Module):
     def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
         return attention_mask
 
-    def run(self, ctx, h, geom: Geom, residual, kv=None):
+    def run(self, ctx, h, geom: Geom, residual, kv=None, ln_in=None):
         proc = self.processor
         if isinstance(proc, HipAttnProcessor):
-            return proc.run(self, ctx, h, geom, residual, kv)
+            return proc.run(self, ctx, h, geom, residual, kv, ln_in)
+        assert ln_in is None, "a foreign processor takes the normalised hidden states"
         return self._run_foreign(proc, ctx, h, geom, residual, kv)
 
     def _run_foreign(self, proc, ctx, h, geom: Geom, residual, kv):
@@ -356,8 +367,11 @@ class FeedForward(nn.Module):
         act = GEGLU(dim, inner_dim) if self.geglu else GELUProj(dim, inner_dim)
         self.net = nn.ModuleList([act, Identity(), Linear(inner_dim, dim)])
 
-    def run(self, h, residual):
-        if self.geglu:
+    def run(self, h, residual, ln_in=None):
+        if ln_in is not None:   # LayerNorm folded into the GEGLU up-projection (BasicTransformerBlock.pack)
+            x, (w_in, b_in, c1_in), ln_eps = ln_in
+            g = ops.gemm(x, w_in, bias=b_in, act=ACT_GEGLU, ln=(c1_in, ln_eps))
+        elif self.geglu:
             g = ops.gemm(h, self.net[0]._w, bias=self.net[0]._b, act=ACT_GEGLU)
         else:
             g = ops.gemm(h, self.net[0].proj.weight, bias=self.net[0].proj.bias, act=ACT_GELU)
@@ -374,18 +388,61 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.ff = FeedForward(dim)
 
+    def pack(self):
+        """LayerNorm folds for the widths the weight-stationary GEMM covers (``ops.ln_gemm_supported``: the 64x64 level's 320
+        channels; transformer_in's 512 for the GEGLU): norm1 -> attn1's fused QKV, norm2 -> attn2's to_q (cross) or QKV (the
+        temporal blocks' second self-attention), norm3 -> the GEGLU up-projection (interleaved as ``GEGLU.pack`` lays it out)."""
+        self._ln = {}
+        dim = self.norm1.weight.shape[0]
+        if dim not in (320, 512) or _NO_LN_FOLD:
+            return
+        cat = lambda a: torch.cat([a.to_q.weight.data, a.to_k.weight.data, a.to_v.weight.data], 0)
+        if dim == 320:
+            self._ln["attn1"] = ops.ln_fold(cat(self.attn1), None, self.norm1.weight.data, self.norm1.bias.data)
+            w2 = self.attn2.to_q.weight.data if self.attn2.is_cross else cat(self.attn2)
+            self._ln["attn2"] = ops.ln_fold(w2, None, self.norm2.weight.data, self.norm2.bias.data)
+        # norm3 -> GEGLU: the fold is supported (and tested) but does not pay -- the up-projection is bound by its erf-GELU
+        # epilogue, to which the fold adds two fma per output (423 vs 435 us at 196608 rows, profiles/r03_gemm_ws_ab.txt)
+        if self.ff.geglu and _LN_FOLD_FF:
+            g = self.ff.net[0]
+            w, b, c1 = ops.ln_fold(g.proj.weight.data, g.proj.bias.data, self.norm3.weight.data, self.norm3.bias.data)
+            n = g.dim_out
+            il = lambda t: torch.stack([t[:n].reshape(n // 16, 16, *t.shape[1:]), t[n:].reshape(n // 16, 16, *t.shape[1:])], 1) \
+                .reshape(2 * n, *t.shape[1:]).contiguous()
+            self._ln["ff"] = (il(w), il(b), il(c1))
+
+    def _fold(self, name, proc_ok, M, N, act=ACT_NONE):
+        f = getattr(self, "_ln", {}).get(name)
+        return f if (f is not None and proc_ok and ops.ln_gemm_supported(M, self.norm1.weight.shape[0], N, act)) else None
+
     def run(self, ctx, x, geom: Geom, expand=None):
         """``expand`` = (full ctx, full geometry): the block was entered with the shared-stem batch (see
         ``I2VGenXLUNet._forward_core``); after self-attention the tokens are expanded to the full batch, where the
-        branches start to differ (cross-attention context)."""
-        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn1.run(ctx, h, geom, residual=x)
+        branches start to differ (cross-attention context).
+
+        Each LayerNorm is folded into the projection that consumes it where the weight-stationary GEMM covers the shape
+        (``pack``); otherwise -- other widths, small clips, a foreign processor on the seam -- it is the LayerNorm kernel."""
+        dim = x.shape[1]
+        m_min = lambda t: t.shape[0] // 3 if t.shape[0] % 3 == 0 else t.shape[0]   # the V-only split projects thirds
+        f = self._fold("attn1", isinstance(self.attn1.processor, HipAttnProcessor), m_min(x), 3 * dim)
+        if f is not None:
+            x = self.attn1.run(ctx, None, geom, residual=x, ln_in=(x, f, self.norm1.eps))
+        else:
+            h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x = self.attn1.run(ctx, h, geom, residual=x)
         if expand is not None:
             ctx, geom = expand
             x = expand_shared(x, ctx)
-        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         kv = ctx.kv_for(self.attn2) if self.attn2.is_cross else None
-        x = self.attn2.run(ctx, h, geom, residual=x, kv=kv)
+        f = self._fold("attn2", isinstance(self.attn2.processor, HipAttnProcessor), m_min(x), dim if self.attn2.is_cross else 3 * dim)
+        if f is not None:
+            x = self.attn2.run(ctx, None, geom, residual=x, kv=kv, ln_in=(x, f, self.norm2.eps))
+        else:
+            h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            x = self.attn2.run(ctx, h, geom, residual=x, kv=kv)
+        f = self._fold("ff", True, x.shape[0], 8 * dim, ACT_GEGLU)
+        if f is not None:
+            return self.ff.run(None, residual=x, ln_in=(x, f, self.norm3.eps))
         h = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         return self.ff.run(h, residual=x)
 
@@ -672,6 +729,8 @@ class _ConfigView:
 
 
 _V_ONLY = os.environ.get("ANYV2V_VONLY", "1") == "1"
+_NO_LN_FOLD = os.environ.get("ANYV2V_LN_FOLD", "1") != "1"   # A/B switch: LayerNorm kernel + GEMM instead of the folded form
+_LN_FOLD_FF = os.environ.get("ANYV2V_LN_FOLD_FF", "0") == "1"  # also fold norm3 into the GEGLU up-projection (measured: no gain)
 PAD_CIN = 64  # conv_in input channels (8) are zero-padded to one MFMA K-tile
 
 

@@ -68,6 +68,16 @@ typedef struct AnyV2VGemmDesc {
                             below its M >= 32768 threshold.  All other bits are ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
+    /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock.norm1/2/3 -> attn.to_q/k/v / ff.net[0].proj,
+     * consisti2v/consisti2v/models/videoldm_transformer_blocks.py:461-564): with ln_c1 != NULL the rows of A0 are the
+     * UN-normalised residual stream and
+     *     C = act( rstd[m] * (A0 W^T - mean[m] * ln_c1) + bias ),   mean / rstd = LayerNorm statistics of row m over C0, eps = ln_eps,
+     * where the caller passes W = W_proj diag(gamma) (fp16), ln_c1[n] = sum_k W[n][k] (fp32, summed over the fp16-rounded W) and
+     * bias = b_proj + W_proj beta.  Mode 0, C0 = 320 (N % 160 = 0) or C0 = 512 with GEGLU (N % 128 = 0), no rowvec / R: other
+     * shapes return ANYV2V_EUNSUPPORTED (the caller then runs anyv2v_layernorm_f16 + the plain GEMM). */
+    const float* ln_c1;
+    float ln_eps;
+    int32_t reserved0;
 } AnyV2VGemmDesc;
 
 int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream);

@@ -22,8 +22,11 @@ def _h(x):
 
 
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, out=None,
-         mode=MODE_LINEAR, conv=None, temporal=None, M=None, naive=False):
+         mode=MODE_LINEAR, conv=None, temporal=None, M=None, naive=False, ln=None):
     a = a0.float() if a1 is None else torch.cat([a0.float(), a1.float()], 1)
+    if ln is not None:   # LayerNorm fold: gamma / beta live in w / bias, the rows only need centring and scaling
+        mean = a.mean(1, keepdim=True)
+        a = (a - mean) * torch.rsqrt(a.var(1, unbiased=False, keepdim=True) + ln[1])
     K = a.shape[1]
     N = w.shape[0]
     wf = w.float()

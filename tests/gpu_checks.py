@@ -308,6 +308,44 @@ def check_gemm_ws():
     return out
 
 
+def check_gemm_ws_ln():
+    """LayerNorm folded into the weight-stationary kernel (``ops.gemm(..., ln=...)``): un-normalised rows in, gamma / beta folded
+    into the weights (``ops.ln_fold``), row statistics taken by the matrix pipe.  Against torch fp32 LayerNorm -> Linear (-> GEGLU)
+    on the same fp16 inputs, and against the unfused HIP path (layernorm kernel + GEMM); rows with a large mean (|mean| = 6 sigma:
+    the fold subtracts mean x column sums) and ragged row counts included."""
+    out = []
+    eps = 1e-5
+    for (M, K, N, act, shift) in [(40000, 320, 960, 0, 0.0), (33001, 320, 320, 0, 6.0), (36000, 320, 2560, ops.ACT_GEGLU, 0.0),
+                                  (34000, 512, 4096, ops.ACT_GEGLU, 3.0)]:
+        x = (rnd(M, K).float() * (1.0 + 0.5 * torch.rand(M, 1, device=DEV)) + shift * torch.randn(M, 1, device=DEV)).half()
+        gamma, beta = (1.0 + 0.3 * rnd(K).float()).half(), (0.2 * rnd(K, seed=7).float()).half()
+        geglu = act == ops.ACT_GEGLU
+        wfull = rnd(N, K, scale=1 / math.sqrt(K))
+        bfull = rnd(N, scale=0.1) if geglu or N != 960 else None      # attention's to_q / to_k / to_v have no bias
+        y_ln = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), eps)
+        proj = y_ln @ wfull.float().t() + (bfull.float() if bfull is not None else 0.0)
+        if geglu:
+            inner = N // 2
+            ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+            wp, bp = _geglu_pack(wfull, bfull, inner)
+        else:
+            ref, wp, bp = proj, wfull, bfull
+        wq, bq, c1 = ops.ln_fold(wp, bp, gamma, beta)
+        assert ops.ln_gemm_supported(M, K, N, act)
+        y = ops.gemm(x, wq, bias=bq, act=act, ln=(c1, eps))
+        out.append(_res(f"gemm[ws+LN] M{M} K{K} N{N} act{act} mean-shift {shift}: vs torch fp32 LayerNorm -> Linear", y, ref, KTOL))
+        h = ops.layernorm(x, gamma, beta, eps)
+        yu = ops.gemm(h, wp, bias=bp, act=act)
+        out.append(_res(f"gemm[ws+LN] M{M} K{K} N{N}: vs layernorm kernel + GEMM", y, yu.float(), 3e-3))
+    # shapes outside the fold's coverage are refused loudly, not silently computed without the LayerNorm
+    try:
+        ops.gemm(rnd(64, 640), rnd(640, 640), ln=(torch.zeros(640, device=DEV), eps))
+        out.append(dict(name="gemm[ws+LN] unsupported shape is refused", err=1.0, l2=1.0, tol=0.0, ok=False))
+    except Exception as e:
+        out.append(dict(name=f"gemm[ws+LN] unsupported shape is refused ({type(e).__name__})", err=0.0, l2=0.0, tol=0.0, ok=True))
+    return out
+
+
 def check_gemm_splitk():
     """Split-K path (launches that cannot fill the chip and have >= 16 K-tiles; fp32 partial tiles + a second pass that
     sums them in split order): against torch, against the unsplit kernel (flag bit4), and bit-reproducibility.

@@ -56,6 +56,25 @@ def case(tag, M, N, act=0, res=False, ldc=None, K=320):
     print(lines[-1], flush=True)
 
 
+def case_ln(tag, M, N, act=0, K=320):
+    """LayerNorm kernel + GEMM (weight-stationary, unfused) vs the LayerNorm-folded GEMM."""
+    x = torch.randn(M, K, device=dev).half()
+    gamma, beta = (1 + 0.1 * torch.randn(K, device=dev)).half(), (0.1 * torch.randn(K, device=dev)).half()
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+    b = (torch.randn(N, device=dev) * 0.1).half()
+    wq, bq, c1 = ops.ln_fold(w, b, gamma, beta)
+    out = torch.empty(M, N // 2 if act == 3 else N, dtype=torch.float16, device=dev)
+    h = torch.empty_like(x)
+    ops.GEMM_FLAGS = 0
+    t = {"ln+gemm": [], "folded": []}
+    for _ in range(rounds):
+        t["ln+gemm"].append(timeit(lambda: ops.gemm(ops.layernorm(x, gamma, beta, 1e-5, out=h), w, bias=b, act=act, out=out)))
+        t["folded"].append(timeit(lambda: ops.gemm(x, wq, bias=bq, act=act, out=out, ln=(c1, 1e-5))))
+    a, f = statistics.median(t["ln+gemm"]), statistics.median(t["folded"])
+    lines.append(f"{tag:<26s} M={M:6d} N={N:5d} K={K}: layernorm + gemm {a:7.1f} us | LayerNorm folded {f:7.1f} us | x{a / f:4.2f}")
+    print(lines[-1], flush=True)
+
+
 for B, tagB in ((3, "B3"), (1, "B1")):
     T = B * 65536
     case(f"{tagB} out-proj +res", T, 320, res=True)
@@ -65,6 +84,13 @@ for B, tagB in ((3, "B3"), (1, "B1")):
     if B == 3:
         case(f"{tagB} V-only (2/3 T, ldc 960)", 2 * 65536, 320, ldc=960)
         case(f"{tagB} QKV source third", 65536, 960)
+    case_ln(f"{tagB} LN -> QKV", T, 960)
+    case_ln(f"{tagB} LN -> to_q", T, 320)
+    case_ln(f"{tagB} LN -> GEGLU", T, 2560, act=3)
+    case_ln(f"{tagB} LN -> t_in GEGLU", T, 4096, act=3, K=512)
+    if B == 3:
+        case_ln(f"{tagB} LN -> QKV source third", 65536, 960)
+        case_ln(f"{tagB} LN -> V-only 2/3", 131072, 320)
     case(f"{tagB} t_in GEGLU K512", T, 4096, act=3, K=512)
     case(f"{tagB} t_in QKV K512", T, 1536, K=512)
     case(f"{tagB} t_in proj+res K512", T, 512, res=True, K=512)
