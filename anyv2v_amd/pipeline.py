@@ -43,6 +43,34 @@ def _use_graphs() -> bool:
     return os.environ.get("ANYV2V_NO_GRAPH", "0") != "1"
 
 
+class SourceFeatureCache:
+    """Job-level exact saving for several edits of ONE clip (``configs/group_pnp_edit/group_config.json`` holds 8 edits of one
+    clip): the source branch of ``sample_with_pnp`` is only a feature generator -- its v-prediction is discarded
+    (``pipeline_i2vgen_xl.py:1136,1160-1162``) and it depends on the clip, its inversion and the step, not on the edit.  The first
+    edit runs the three-branch steps and RECORDS, per step and injected hook site, what the other branches read from the source
+    branch (Q | K of the 16 attention sites, the conv features of ``up_blocks[1].resnets[1]``); every further edit of the same
+    clip REPLAYS them and runs [negative, editing] only.  Kept in HBM (~0.85 GB per fully injected step at 16 f x 512^2).
+
+    ``signature``: what the recorded features depend on; a different one (next clip, other weights) empties the cache."""
+
+    def __init__(self):
+        self.signature = None
+        self.steps: Dict[int, Dict[str, torch.Tensor]] = {}
+        self.recorded_steps = self.replayed_steps = 0
+
+    def bind(self, signature):
+        if signature != self.signature:
+            self.steps.clear()
+            self.signature = signature
+
+    def has(self, t, names) -> bool:
+        d = self.steps.get(int(t))
+        return d is not None and all(n in d for n in names)
+
+    def nbytes(self) -> int:
+        return sum(v.numel() * v.element_size() for d in self.steps.values() for v in d.values())
+
+
 class _StepEngine:
     """One denoising step = UNet forward on ``sample[B,4,F,h,w]`` + fused CFG/DDIM update of the latent slot.
 
@@ -144,6 +172,7 @@ class I2VGenXLPipeline:
         self._guidance_scale = 1.0
         self._device = torch.device("cpu")
         self._engines: Dict[tuple, _StepEngine] = {}  # step engines (static buffers + HIP graphs) kept across clips, LRU
+        self.source_cache: Optional[SourceFeatureCache] = None   # set (``enable_source_cache``) by multi-edit jobs
 
     # ------------------------------------------------------------------ construction / plumbing
     @classmethod
@@ -337,6 +366,12 @@ class I2VGenXLPipeline:
         return (prompt_embeds.to(device, torch.float16), None if negative_prompt_embeds is None else
                 negative_prompt_embeds.to(device, torch.float16), image_embeddings.to(device, torch.float16),
                 image_latents.to(device, torch.float16))
+
+    def enable_source_cache(self, on: bool = True):
+        """Several edits of one clip (a group job, the front-end called repeatedly): keep the source branch's injected features of
+        the clip in HBM across ``sample_with_pnp`` calls -- ``SourceFeatureCache``.  Off by default: a single edit gains nothing."""
+        self.source_cache = SourceFeatureCache() if on else None
+        return self.source_cache
 
     def _engine(self, tag, sample, cond, **kw) -> _StepEngine:
         """A step engine for this loop: a new one, or -- for the next clip of the same geometry in a multi-clip job -- the one
@@ -546,6 +581,26 @@ class I2VGenXLPipeline:
         skip_src = cfg_on and nb == 3 and os.environ.get("ANYV2V_SRC_SKIP", "1") == "1"
         eng_nosrc = None
         nosrc_bound = False
+        # multi-edit job: record / replay what the injected sites read from the source branch (SourceFeatureCache)
+        cache = self.source_cache if (skip_src and not pnp_utils.has_foreign_hooks(self.unet)
+                                      and getattr(self.unet, "frame_parallel", None) is None) else None
+        sites = pnp_utils.injection_sites(self) if cache is not None else []
+        if cache is not None:
+            fp_ = lambda x: (tuple(x.shape), float(x.float().sum()), float(x.float().abs().sum()))
+            src = ("object", id(traj)) if isinstance(ddim_inv_latents_path, LatentTrajectory) else ("files", os.path.abspath(str(ddim_inv_latents_path)))
+            cache.bind((src, tuple(ts), fp_(load_ddim_latents_at_t(ts[0], traj)), fp_(spe), fp_(sie), fp_(sil), int(target_fps),
+                        self.unet._pack_gen, id(self.unet), tuple(latents.shape)))
+            if not hasattr(eng, "site_bufs"):
+                # rows of ONE branch at the site's level: up_blocks[1] works at 1/16 of the 64x64 level's pixels, [2] at 1/4, [3] at 1/1
+                full = num_frames * (height // self.vae_scale_factor) * (width // self.vae_scale_factor)
+                level_div = {"1": 16, "2": 4, "3": 1}
+                eng.site_bufs = {name: torch.empty((full // level_div[name.split(".up")[1][0]], cols), dtype=torch.float16, device=device)
+                                 for name, _obj, cols in sites}
+
+        def set_io(mode, names):
+            for name, obj, _ in sites:
+                obj.src_io = (mode, eng.site_bufs[name]) if (mode is not None and name in names) else None
+
         for i, t in enumerate(ts):
             pnp_utils.register_time(self, t)  # host-side only: python int, no device sync (:1143)
             state = pnp_utils.injection_state(self)
@@ -562,9 +617,32 @@ class I2VGenXLPipeline:
                                                 dup_slots=[0], shared_stem=True)
                     eng_nosrc, nosrc_bound = eng.nosrc, True
                 eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-nosrc",))
+            elif cache is not None and cache.has(t, [n for (n, _, _), on in zip(sites, state) if on]):
+                # replay: the source features of this step are in HBM -- [negative, editing] only
+                names = [n for (n, _, _), on in zip(sites, state) if on]
+                if not nosrc_bound:
+                    cond2 = {k: v[1:].contiguous() for k, v in cond.items()}
+                    if eng.nosrc is None or not eng.nosrc.rebind(sample[1:], cond2):
+                        eng.nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale,
+                                                dup_slots=[0], shared_stem=True)
+                    eng_nosrc, nosrc_bound = eng.nosrc, True
+                for n in names:
+                    eng.site_bufs[n].copy_(cache.steps[t][n], non_blocking=True)
+                set_io("replay", names)
+                eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-replay",) + state)
+                set_io(None, ())
+                cache.replayed_steps += 1
             else:
                 sample[0].copy_(load_ddim_latents_at_t(t, traj).to(device=device, dtype=torch.float16)[0], non_blocking=True)
-                eng.step(t_table[i], coef_table[i], key=("pnp",) + state)
+                if cache is not None:
+                    names = [n for (n, _, _), on in zip(sites, state) if on]
+                    set_io("record", names)
+                    eng.step(t_table[i], coef_table[i], key=("pnp-record",) + state)
+                    set_io(None, ())
+                    cache.steps.setdefault(t, {}).update({n: eng.site_bufs[n].clone() for n in names})
+                    cache.recorded_steps += 1
+                else:
+                    eng.step(t_table[i], coef_table[i], key=("pnp",) + state)
             if latents_trace is not None:
                 latents_trace[t] = sample[nb - 1:nb].clone()
         return self._finish(sample[nb - 1:nb].clone(), output_type, decode_chunk_size, return_dict)

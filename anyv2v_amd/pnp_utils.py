@@ -89,6 +89,20 @@ def injection_state(model):
     return tuple(state)
 
 
+def injection_sites(model):
+    """The 17 hook sites in ``injection_state`` order: [(name, object carrying .t / .injection_schedule / .src_io, columns)], columns
+    = width of the source features a multi-edit job keeps per site (conv: Cout; attention: Q | K = 2 x inner dim)."""
+    unet = model.unet
+    r = unet.up_blocks[1].resnets[1]
+    sites = [("conv.up1.res1", r, r.out_channels)]
+    for kind in ("attentions", "temp_attentions"):
+        for res, blocks in _ATTN_SITES.items():
+            for block in blocks:
+                a = getattr(unet.up_blocks[res], kind)[block].transformer_blocks[0].attn1
+                sites.append((f"{kind}.up{res}.{block}", a.processor, 2 * a.inner_dim))
+    return sites
+
+
 def has_foreign_hooks(unet) -> bool:
     """True when a torch-style processor / ``forward`` from outside this package is plugged into the seams B1 / B2 (e.g.
     the reference's own ``pnp_utils.py`` hooks): such code may sync or allocate, so steps are not captured into HIP graphs."""

@@ -77,7 +77,15 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         if config_entry["active"] is False:
             logger.info(f"Skipping config_entry: {config_entry}")
     my_latents, lat_shape = [], None
-    for config_entry in shard_entries(configs_list, e_rank, e_world):
+    my_entries = shard_entries(configs_list, e_rank, e_world)
+    # Several edits of one clip on this rank (the demo group config: 8 edits of one clip): keep the source branch's injected features
+    # in HBM after the first edit, so that the further ones run [negative, editing] only (pipeline.SourceFeatureCache; exact).
+    # ANYV2V_SOURCE_CACHE=0 switches it off.
+    clips = [e.get("video_name") for e in my_entries]
+    if os.environ.get("ANYV2V_SOURCE_CACHE", "1") == "1" and len(clips) != len(set(clips)) and pipe.source_cache is None:
+        pipe.enable_source_cache(True)
+    loaded_trajectories = {}   # one LatentTrajectory object per clip (read once, shared by the clip's edits)
+    for config_entry in my_entries:
         entry_idx = all_active.index(config_entry)
         logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
         config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
@@ -103,9 +111,16 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         ddim_scheduler.set_timesteps(config.n_steps)
         logger.info(f"ddim_scheduler.timesteps: {ddim_scheduler.timesteps}")
         # read the whole source trajectory once into HBM (the reference re-reads one file per step, :1134)
-        handed = (trajectories or {}).get(os.path.abspath(str(config.ddim_latents_path)))
-        traj = handed if handed is not None else LatentTrajectory.load(
-            config.ddim_latents_path, device=device, timesteps=[int(t) for t in ddim_scheduler.timesteps[t_idx:]])
+        tkey = (os.path.abspath(str(config.ddim_latents_path)), int(config.n_steps), int(t_idx))
+        handed = (trajectories or {}).get(tkey[0])
+        if handed is not None:
+            traj = handed
+        else:
+            if tkey not in loaded_trajectories:
+                loaded_trajectories.clear()   # (one clip's trajectory at a time: 50 x 512 KiB at 16 f x 512^2)
+                loaded_trajectories[tkey] = LatentTrajectory.load(
+                    config.ddim_latents_path, device=device, timesteps=[int(t) for t in ddim_scheduler.timesteps[t_idx:]])
+            traj = loaded_trajectories[tkey]
         ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
         seed_everything(seed_for_entry(template_config.seed, entry_idx) if e_world > 1 else template_config.seed)
         random_latents = torch.randn(ddim_latents_at_t.shape, dtype=torch.float32).to(ddim_latents_at_t)  # drawn even if unused (:124)

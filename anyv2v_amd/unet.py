@@ -239,6 +239,10 @@ class HipAttnProcessor:
     def __init__(self, injection_schedule=None):
         self.injection_schedule = injection_schedule
         self.t = None
+        # source-feature cache of a multi-edit job (pipeline.SourceFeatureCache): None, ("record", buf) -- copy the source branch's
+        # Q | K columns of this step into ``buf`` [Ts, 2 C] -- or ("replay", buf): the batch is [negative, editing] only and the
+        # source branch's Q, K are read from ``buf`` (recorded by an earlier edit of the same clip)
+        self.src_io = None
 
     def run(self, attn: "Attention", ctx, h, geom: Geom, residual, kv=None, ln_in=None):
         """``ln_in`` = (x, (W', b', c1), eps): the block's LayerNorm is folded into this attention's first projection
@@ -256,6 +260,19 @@ class HipAttnProcessor:
         o = torch.empty((T, Cq), dtype=torch.float16, device=h.device)
         if kv is None:  # self-attention
             inject = pnp_on(self.t, self.injection_schedule)
+            io = self.src_io if inject else None
+            if io is not None and io[0] == "replay":
+                # [negative, editing] with the source branch's Q, K from the cache: only V is projected here; the kernel aliases
+                # Q, K of batch element i to element i % (batch / 2) of the cached source rows (same arithmetic per output as the
+                # three-branch shared-softmax launch: bit-equal, tests/gpu_checks.py)
+                src_qk = io[1]
+                assert src_qk.shape[0] * 2 == T and src_qk.shape[1] == 2 * Cq
+                qkv = torch.empty((T, 3 * Cq), dtype=torch.float16, device=h.device)
+                proj(h, 2 * Cq, qkv[:, 2 * Cq:])
+                ops.attention(src_qk[:, :Cq], src_qk[:, Cq:], qkv[:, 2 * Cq:], o, batch=geom.batch, heads=attn.heads, Sq=geom.S,
+                              Sk=geom.S, inner=geom.inner, q_strides=geom.strides, kv_strides=geom.strides,
+                              qk_mod=geom.batch // 2, scale=attn.scale)
+                return ops.gemm(o, attn.to_out[0].weight, bias=attn.to_out[0].bias, residual=residual)
             if inject and T % 3 == 0 and _V_ONLY:
                 # Q and K of the negative / editing branches are never read on an injection step (they alias the source
                 # branch's): project Q,K,V for the source third and only V for the other two thirds (exact, 44 % fewer
@@ -266,6 +283,8 @@ class HipAttnProcessor:
                 proj(h[Ts:], 2 * Cq, qkv[Ts:, 2 * Cq:])
             else:
                 qkv = proj(h)
+            if io is not None and io[0] == "record":
+                io[1].copy_(qkv[:T // 3, :2 * Cq])
             qk_mod = geom.batch // 3 if inject else 0
             ops.attention(qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], o, batch=geom.batch, heads=attn.heads,
                           Sq=geom.S, Sk=geom.S, inner=geom.inner, q_strides=geom.strides, kv_strides=geom.strides,
@@ -532,6 +551,7 @@ class ResnetBlock2D(nn.Module):
         self.output_scale_factor = 1.0
         self.t = None
         self.injection_schedule = None
+        self.src_io = None  # source-feature cache, see HipAttnProcessor: ("record" | "replay", buf [Ts, Cout]) of the conv features
         self._temb_col = 0  # column of this block's time_emb_proj inside ctx.temb_all
 
     def forward(self, input_tensor, temb, scale: float = 1.0):
@@ -565,6 +585,17 @@ class ResnetBlock2D(nn.Module):
         HW = H * W
         T = x0.shape[0]
         inject = pnp_on(self.t, self.injection_schedule)
+        io = self.src_io if inject else None
+        if io is not None and io[0] == "replay":
+            # [negative, editing] only: both take the source branch's conv features recorded by an earlier edit of this clip --
+            # the main path (two GroupNorms, two 3x3 convolutions) is not run at all
+            res = self.conv_shortcut.tokens(x0, H, W, x1=x1) if self.conv_shortcut is not None else x0
+            hs, Th = io[1], T // 2
+            assert hs.shape[0] == Th
+            out = torch.empty((T, self.out_channels), dtype=torch.float16, device=x0.device)
+            for b in range(2):
+                ops.add(res[b * Th:(b + 1) * Th], hs, out=out[b * Th:(b + 1) * Th])
+            return out
         Ts = T // 3 if inject else T  # injection step: main path only for the source branch (exact)
         a0 = x0[:Ts]
         a1 = x1[:Ts] if x1 is not None else None
@@ -581,6 +612,8 @@ class ResnetBlock2D(nn.Module):
         if not inject:
             return self.conv2.tokens(h, H, W, residual=res)
         hs = self.conv2.tokens(h, H, W)  # source-branch features, shared by all three branches
+        if io is not None and io[0] == "record":
+            io[1].copy_(hs)
         out = torch.empty((T, self.out_channels), dtype=torch.float16, device=x0.device)
         for b in range(3):
             ops.add(res[b * Ts:(b + 1) * Ts], hs, out=out[b * Ts:(b + 1) * Ts])

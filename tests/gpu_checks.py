@@ -1292,6 +1292,118 @@ def check_loops_mini():
 _MODELS = {}
 
 
+def check_source_cache(cfg_name="mini", Fr=4, hw=8, n_steps=6):
+    """Multi-edit job (``pipeline.SourceFeatureCache``): three edits of ONE clip -- different prompts and edited frames, the third
+    also with shorter injection schedules -- with the cache (the first records, the others replay and run [negative, editing]
+    only) must be BIT-EQUAL to the same three edits without it; the cache really is used (replayed steps counted) and is dropped
+    when the clip changes."""
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    out = []
+    native, _, ocfg = build_pair(cfg_name, 1234)
+    inp = config1_inputs(ocfg, 3, Fr, hw)
+    g = lambda x: x.half().to(DEV)
+    lat0, ehs, ie, il = g(inp["sample"][:1]), g(inp["encoder_hidden_states"]), g(inp["image_embeddings"]), g(inp["image_latents"])
+    gen = torch.Generator().manual_seed(77)
+    edits = []
+    for k in range(3):   # (prompt embeds, negative embeds, image embedding, image latents of the edited frame, schedule ratios)
+        r = lambda *sh: torch.randn(*sh, generator=gen).half().to(DEV)
+        il_k = il[2:3].clone()
+        il_k[:, :, 0] = r(*il_k[:, :, 0].shape)
+        edits.append((r(*ehs[2:3].shape), ehs[1:2], r(*ie[2:3].shape), il_k, (0.5, 0.67, 1.0) if k < 2 else (0.2, 0.34, 0.5)))
+
+    def run_all(use_cache):
+        pipe = I2VGenXLPipeline(unet=native, scheduler=DDIMInverseScheduler())
+        pipe._device = torch.device(DEV)
+        cache = pipe.enable_source_cache(True) if use_cache else None
+        traj = pipe.invert(prompt_embeds=ehs[:1], image_embeddings=ie[:1], image_latents=il[:1], height=hw * 8, width=hw * 8,
+                           num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0, target_fps=8, latents=lat0,
+                           return_trajectory=True)
+        T = max(traj.keys())
+        res = []
+        for (pe, npe, ie_k, il_k, ratios) in edits:
+            sched = DDIMScheduler()
+            sched.set_timesteps(n_steps)
+            pipe.register_modules(scheduler=sched)
+            k = lambda r_: sched.timesteps[: int(n_steps * r_)]
+            pnp_utils.register_conv_injection(pipe, k(ratios[0]))
+            pnp_utils.register_spatial_attention_pnp(pipe, k(ratios[1]))
+            pnp_utils.register_temp_attention_pnp(pipe, k(ratios[2]))
+            res.append(pipe.sample_with_pnp(prompt_embeds=pe, negative_prompt_embeds=npe, image_embeddings=ie_k, image_latents=il_k,
+                                            height=hw * 8, width=hw * 8, num_frames=Fr, num_inference_steps=n_steps,
+                                            guidance_scale=9.0, target_fps=8, latents=traj[T].clone(), output_type="latent",
+                                            ddim_init_latents_t_idx=0, ddim_inv_latents_path=traj, ddim_inv_prompt_embeds=ehs[:1],
+                                            ddim_inv_image_embeddings=ie[:1], ddim_inv_image_latents=il[:1]).frames.float().cpu())
+            pnp_utils.clear_time(pipe)
+        return res, cache, pipe, traj
+
+    plain, _, _, _ = run_all(False)
+    cached, cache, pipe, traj = run_all(True)
+    # On the GPU the kernels' arithmetic per output element does not depend on the batch, so the replayed two-branch steps are
+    # BIT-equal to the three-branch ones.  The CPU op emulation (torch matmul picks its summation order by shape) is not: there
+    # the first edit (recorded, three-branch) must still be bit-equal and the replayed ones agree to fp16 rounding amplified by
+    # cfg 9 over the steps -- a wrong feature at any site is an O(1) error (the single-forward check below is the sharp one).
+    exact = DEV != "cpu"
+    for k in range(3):
+        out.append(_res(f"source cache: edit {k} with the cache == without ({'bit-equal' if exact or k == 0 else 'fp16 drift'})",
+                        cached[k], plain[k], 0.0 if (exact or k == 0) else 0.12))
+    # one forward, every site type on: [negative, editing] with replayed source features vs branches 1, 2 of the three-branch forward
+    import types
+    smp = torch.cat([lat0, lat0 * 0.7, lat0 * 0.7])
+    il3 = torch.cat([il[:1], il[2:3], il[2:3]])
+    kw = dict(fps=torch.tensor([8, 8, 8], device=DEV), image_latents=il3, image_embeddings=ie, encoder_hidden_states=ehs)
+    p2 = types.SimpleNamespace(unet=native)
+    tsl = [981 - 20 * i for i in range(50)]
+    pnp_utils.register_conv_injection(p2, tsl)
+    pnp_utils.register_spatial_attention_pnp(p2, tsl)
+    pnp_utils.register_temp_attention_pnp(p2, tsl)
+    pnp_utils.register_time(p2, 981)
+    sites = pnp_utils.injection_sites(p2)
+    full = Fr * hw * hw
+    bufs = {n: torch.zeros((full // {"1": 16, "2": 4, "3": 1}[n.split(".up")[1][0]], c), dtype=torch.float16, device=DEV) for n, _o, c in sites}
+    for n, o, _c in sites:
+        o.src_io = ("record", bufs[n])
+    v3 = native(smp, 981, **kw)[0].float().cpu()
+    for n, o, _c in sites:
+        o.src_io = ("replay", bufs[n])
+    v2 = native(smp[1:], 981, **{k_: v_[1:] for k_, v_ in kw.items()})[0].float().cpu()
+    for n, o, _c in sites:
+        o.src_io = None
+    pnp_utils.clear_time(p2)
+    out.append(_res("source cache: one forward, 17 sites replayed ([negative, editing]) vs the three-branch forward", v2, v3[1:],
+                    0.0 if exact else 4e-3))
+    out.append(_res("source cache: the edits differ from each other (not vacuous)", (plain[0] - plain[1]).abs().max().reshape(1),
+                    torch.zeros(1), float("inf")))
+    out[-1]["ok"] = bool((plain[0] - plain[1]).abs().max() > 1e-3)
+    n_inj = n_steps  # schedules of edit 0 / 1 cover every step at ratio 1.0 for the temporal sites
+    ok = cache.recorded_steps >= n_inj and cache.replayed_steps >= n_inj
+    out.append(dict(name=f"source cache: recorded {cache.recorded_steps} steps, replayed {cache.replayed_steps} ({cache.nbytes() / 2**20:.1f} MiB)",
+                    err=0.0 if ok else 1.0, l2=0.0, tol=0.5, ok=ok))
+    # another clip (other trajectory object): the signature changes, nothing of the old clip is replayed
+    before = cache.replayed_steps
+    traj2 = pipe.invert(prompt_embeds=ehs[:1], image_embeddings=ie[:1], image_latents=il[:1], height=hw * 8, width=hw * 8,
+                        num_frames=Fr, num_inference_steps=n_steps, guidance_scale=1.0, target_fps=8, latents=lat0 * 0.5,
+                        return_trajectory=True)
+    sched = DDIMScheduler()
+    sched.set_timesteps(n_steps)
+    pipe.register_modules(scheduler=sched)
+    pnp_utils.register_conv_injection(pipe, sched.timesteps)
+    pnp_utils.register_spatial_attention_pnp(pipe, sched.timesteps)
+    pnp_utils.register_temp_attention_pnp(pipe, sched.timesteps)
+    pe, npe, ie_k, il_k, _ = edits[0]
+    pipe.sample_with_pnp(prompt_embeds=pe, negative_prompt_embeds=npe, image_embeddings=ie_k, image_latents=il_k, height=hw * 8,
+                         width=hw * 8, num_frames=Fr, num_inference_steps=n_steps, guidance_scale=9.0, target_fps=8,
+                         latents=traj2[max(traj2.keys())].clone(), output_type="latent", ddim_init_latents_t_idx=0,
+                         ddim_inv_latents_path=traj2, ddim_inv_prompt_embeds=ehs[:1], ddim_inv_image_embeddings=ie[:1],
+                         ddim_inv_image_latents=il[:1])
+    pnp_utils.clear_time(pipe)
+    ok = cache.replayed_steps == before
+    out.append(dict(name="source cache: a new clip empties it (no replay of the old clip's features)", err=0.0 if ok else 1.0, l2=0.0,
+                    tol=0.5, ok=ok))
+    return out
+
+
 def full_models(cfg_name="full", seed=1234, want=("native", "o32", "o16")):
     """One set of models per process, shared by the full-size parity checks: the native HIP UNet, the oracle in fp32 on
     the GPU (the CHECKER at sizes the CPU cannot reach in test time; validated against the CPU oracle in

@@ -71,6 +71,11 @@ def test_pipeline_loops_vs_oracle(cpu_ops):
     _ok(gc.check_loops_mini())
 
 
+def test_source_feature_cache_multi_edit_is_bit_equal(cpu_ops):
+    """Several edits of one clip: record once, replay for the further edits -- bit-equal to the uncached run (CPU op emulation)."""
+    _ok(gc.check_source_cache())
+
+
 def test_step_engines_are_reused_across_clips_without_stale_state(cpu_ops):
     _ok(gc.check_engine_reuse_across_clips())
 
