@@ -17,6 +17,7 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 #define WAVE 64
 
 void anyv2v_set_error(const char* fmt, ...);
+int av_hint_rows(int rows);   // rows as the launch heuristics should see them (anyv2v_set_batch_hint), errors.hip
 
 #define AV_CHECK(cond, ...)                 \
     do {                                    \

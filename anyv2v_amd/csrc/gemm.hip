@@ -899,8 +899,11 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         // the 256 CUs for a whole number of rounds well enough (>= 75 %), or when forced (flags bit3)
         constexpr int BMB = 192;
         const int tiles_big = ((d->M + BMB - 1) / BMB) * (d->N / 320);
-        const int rounds = (tiles_big + 255) / 256;
-        const bool fills = tiles_big >= 224 && tiles_big * 4 >= rounds * 256 * 3;
+        // every DECISION below is taken on the hinted row count (anyv2v_set_batch_hint: a two-branch step chooses what the
+        // three-branch step it stands for chooses -- same split-K factor, same summation order); grids use the true count
+        const int tiles_h = ((av_hint_rows(d->M) + BMB - 1) / BMB) * (d->N / 320);
+        const int rounds = (tiles_h + 255) / 256;
+        const bool fills = tiles_h >= 224 && tiles_h * 4 >= rounds * 256 * 3;
         // launches that cannot fill the CUs but have a long K loop (8x8-level convs / FF-down of the 3-clip batch, M = 3072):
         // split K so that (tiles x splits) is one nearly full round of 256 work items; the ordered reduce pass finishes them.
         // Measured (profiles/r01_gemm_split_ab.txt): 1.2-1.4x over the 128-row kernel's split path from 80 K-tiles on with
@@ -908,12 +911,12 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         int big_splits = 1;
         {
             const int nk_all = k.taps * (k.nt0 + k.nt1);
-            if (!fills && !geglu && !(d->flags & (16 | 8)) && d->workspace != nullptr && tiles_big <= 128 && nk_all >= 72 &&
+            if (!fills && !geglu && !(d->flags & (16 | 8)) && d->workspace != nullptr && tiles_h <= 128 && nk_all >= 72 &&
                 d->N % 8 == 0) {
-                int sp = 256 / tiles_big;
+                int sp = 256 / tiles_h;
                 if (sp > 8) sp = 8;
                 if (sp > nk_all / 12) sp = nk_all / 12;
-                if (sp >= 2 && tiles_big * sp >= 224 &&
+                if (sp >= 2 && tiles_h * sp >= 224 &&
                     (size_t)sp * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes)
                     big_splits = sp;
             }
@@ -948,15 +951,16 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         }
     }
     const int tiles = ((d->M + 127) / 128) * k.tilesN;
+    const int tiles_hint = ((av_hint_rows(d->M) + 127) / 128) * k.tilesN;   // decisions: hinted rows (see above)
     // split-K for launches that cannot fill the chip (512 block slots) and have a long K loop (the 8x8 / 16x16-level
     // convs: 64..256 tiles x 180..360 K-tiles); needs the caller's fp32 workspace
     const int nk = k.taps * (k.nt0 + k.nt1);
     // (measured, tools history in DESIGN.md: with 20 K-tiles the second pass costs more than the idle CUs; with 60 it
     //  pays only when fewer than a quarter of the block slots would be busy; from ~72 K-tiles on it always pays)
-    const bool split_pays = (tiles <= 128 && nk >= 32) || nk >= 72;
-    if (glds && !geglu && d->act != ACT_F32OUT && !(d->flags & 16) && d->workspace != nullptr && tiles < 384 && split_pays &&
+    const bool split_pays = (tiles_hint <= 128 && nk >= 32) || nk >= 72;
+    if (glds && !geglu && d->act != ACT_F32OUT && !(d->flags & 16) && d->workspace != nullptr && tiles_hint < 384 && split_pays &&
         d->N % 8 == 0) {
-        int splits = (512 + tiles - 1) / tiles;
+        int splits = (512 + tiles_hint - 1) / tiles_hint;
         if (splits > 8) splits = 8;
         if (splits > nk / 8) splits = nk / 8;
         if (splits >= 2 && (size_t)splits * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes) {
@@ -1061,7 +1065,7 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
         return av_gemm_ws_launch(k, d, s);
     }
     if (fast && (d->flags & 2) && !(d->flags & (512 | 4 | 1)) && av_gemm_ws_eligible(d) &&
-        (d->M >= 32768 || (d->flags & 1024)))
+        (av_hint_rows(d->M) >= 32768 || (d->flags & 1024)))
         return av_gemm_ws_launch(k, d, s);
     if (d->mode == MODE_CONV2D) return dispatch<MODE_CONV2D>(k, d, fast, s);
     if (d->mode == MODE_TEMPORAL) return dispatch<MODE_TEMPORAL>(k, d, fast, s);

@@ -197,7 +197,10 @@ static int gn_plan(GnPlan& pl, const void* X0, const void* X1, int32_t C0, int32
     pl.threads = pl.V * pl.rpb;
     if (pl.threads < 64) pl.threads = 64;
     if (pl.threads < G) pl.threads = G;
-    int nchunks = (1536 + pl.nsg - 1) / pl.nsg;
+    // (chunking decided on the hinted number of statistics groups -- anyv2v_set_batch_hint: a two-branch step sums its chunks in
+    //  the order the three-branch step does)
+    const int nsg_h = av_hint_rows(M) / rows_per_group > 0 ? av_hint_rows(M) / rows_per_group : 1;
+    int nchunks = (1536 + nsg_h - 1) / nsg_h;
     int max_chunks = (rows_per_group + pl.rpb * 8 - 1) / (pl.rpb * 8);  // >= 8 row-iterations per thread
     if (max_chunks < 1) max_chunks = 1;
     if (nchunks > max_chunks) nchunks = max_chunks;

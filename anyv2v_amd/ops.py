@@ -113,7 +113,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
 def ln_gemm_supported(M: int, K: int, N: int, act: int = ACT_NONE) -> bool:
     """Shapes for which ``gemm(..., ln=...)`` runs (the weight-stationary kernel, gemm_ws.hip) AND pays: the 64x64 level's row
     counts.  Mirrors the library's own check; everything else runs ``layernorm`` + ``gemm``."""
-    if FORCE_NAIVE or not USE_GLDS or (GEMM_FLAGS & (512 | 4)) or M < 32768:
+    if FORCE_NAIVE or not USE_GLDS or (GEMM_FLAGS & (512 | 4)) or M * _HINT[0] // _HINT[1] < 32768:
         return False
     if K == 320:
         return N % 160 == 0 and N // 160 <= 32
@@ -323,6 +323,28 @@ def ddim_step(v: torch.Tensor, x: torch.Tensor, sa_t: float, sb_t: float, sa_p: 
     _lib.check(lib.anyv2v_ddim_step_f16(_p(v), _p(x), _p(out), sa_t, sb_t, sa_p, sb_p, x.numel(), _stream()),
                "anyv2v_ddim_step_f16")
     return out
+
+
+_HINT = [1, 1]   # mirrored for the host-side decisions (ln_gemm_supported)
+
+
+class batch_hint:
+    """``with ops.batch_hint(3, 2): ...`` -- the launches inside choose kernels / split-K factors / GroupNorm chunking as if they had
+    3/2 of their rows (``anyv2v_set_batch_hint``): a [negative, editing] step then computes, bit for bit, what the three-branch step
+    computes for those branches.  Also valid around a HIP-graph capture (the choices are baked at capture time)."""
+
+    def __init__(self, num: int, den: int):
+        self.num, self.den = int(num), int(den)
+
+    def __enter__(self):
+        _lib.check(_lib.load().anyv2v_set_batch_hint(self.num, self.den), "anyv2v_set_batch_hint")
+        _HINT[:] = [self.num, self.den]
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.load().anyv2v_set_batch_hint(1, 1), "anyv2v_set_batch_hint")
+        _HINT[:] = [1, 1]
+        return False
 
 
 def selftest(scratch: torch.Tensor):

@@ -79,8 +79,11 @@ class _StepEngine:
     step is overwritten by the caller with the source trajectory before each step.
     """
 
-    def __init__(self, pipe, sample, cond, b_unc, b_cond, guidance, dup_slots, shared_stem=False):
+    def __init__(self, pipe, sample, cond, b_unc, b_cond, guidance, dup_slots, shared_stem=False, batch_hint=None):
         self.pipe, self.unet = pipe, pipe.unet
+        # (num, den): this engine runs a subset of another engine's branches ([negative, editing] of a three-branch edit step) and
+        # must make the same launch choices -- ops.batch_hint
+        self.batch_hint = batch_hint
         self.sample = sample
         self.cond = cond
         self.b_unc, self.b_cond, self.guidance = b_unc, b_cond, float(guidance)
@@ -96,8 +99,9 @@ class _StepEngine:
         unet = self.unet
         if not unet._packed:
             unet.pack()
-        self.ctx = unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
-                                      cond["image_embeddings"])
+        with ops.batch_hint(*(batch_hint or (1, 1))):
+            self.ctx = unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
+                                          cond["image_embeddings"])
         # CFG batches [.., negative, positive]: the last two slots hold the same latent (dup_slots) and -- checked here,
         # once -- the same image latents and fps, so the UNet may share their stem (exact; unet._forward_core)
         self._shared_stem_requested = bool(shared_stem)
@@ -119,8 +123,9 @@ class _StepEngine:
             return False
         if sample_init.data_ptr() != self.sample.data_ptr():
             self.sample.copy_(sample_init)
-        fresh = self.unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
-                                        cond["image_embeddings"])
+        with ops.batch_hint(*(self.batch_hint or (1, 1))):
+            fresh = self.unet._prepare_clip(B, F, H, W, cond["encoder_hidden_states"], cond["fps"], cond["image_latents"],
+                                            cond["image_embeddings"])
         if fresh is not self.ctx:
             if (fresh.Sk, fresh.F) != (self.ctx.Sk, self.ctx.F):
                 return False
@@ -136,6 +141,12 @@ class _StepEngine:
         return True
 
     def _body(self):
+        if self.batch_hint is not None:
+            with ops.batch_hint(*self.batch_hint):
+                return self._body_inner()
+        return self._body_inner()
+
+    def _body_inner(self):
         vtok = self.unet._forward_core(self.ctx, self.sample)
         L = self.lat_slot
         lat = self.sample[L:L + 1]
@@ -152,7 +163,11 @@ class _StepEngine:
         g = self.graphs.get(key)
         if g is None:
             # warm up eagerly on the side (pure: the UNet forward does not touch the latents), then capture
-            self.unet._forward_core(self.ctx, self.sample)
+            if self.batch_hint is not None:
+                with ops.batch_hint(*self.batch_hint):
+                    self.unet._forward_core(self.ctx, self.sample)
+            else:
+                self.unet._forward_core(self.ctx, self.sample)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -614,7 +629,7 @@ class I2VGenXLPipeline:
                     cond2 = {k: v[1:].contiguous() for k, v in cond.items()}
                     if eng.nosrc is None or not eng.nosrc.rebind(sample[1:], cond2):
                         eng.nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale,
-                                                dup_slots=[0], shared_stem=True)
+                                                dup_slots=[0], shared_stem=True, batch_hint=(3, 2))
                     eng_nosrc, nosrc_bound = eng.nosrc, True
                 eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-nosrc",))
             elif cache is not None and cache.has(t, [n for (n, _, _), on in zip(sites, state) if on]):
@@ -624,7 +639,7 @@ class I2VGenXLPipeline:
                     cond2 = {k: v[1:].contiguous() for k, v in cond.items()}
                     if eng.nosrc is None or not eng.nosrc.rebind(sample[1:], cond2):
                         eng.nosrc = _StepEngine(self, sample[1:], cond2, b_unc=0, b_cond=1, guidance=guidance_scale,
-                                                dup_slots=[0], shared_stem=True)
+                                                dup_slots=[0], shared_stem=True, batch_hint=(3, 2))
                     eng_nosrc, nosrc_bound = eng.nosrc, True
                 for n in names:
                     eng.site_bufs[n].copy_(cache.steps[t][n], non_blocking=True)

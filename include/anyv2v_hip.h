@@ -192,6 +192,11 @@ int anyv2v_ddim_step_f16(const void* V, const void* X, void* Y, float sa_t, floa
                          int64_t n, void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------- */
+/* Launch heuristics (kernel family, split-K factor, GroupNorm chunking) see rows * num / den from now on; grids and bounds keep the true
+ * row counts.  The PnP edit runs some steps on [negative, editing] only (steps outside every injection schedule; steps whose source
+ * features are replayed from a multi-edit cache, pipeline_i2vgen_xl.py:1136-1162): with the hint 3 / 2 those launches choose what the
+ * three-branch launch chooses, so every fp32 summation order -- and the result, bit for bit -- is the same.  (1, 1) resets. */
+int anyv2v_set_batch_hint(int32_t num, int32_t den);
 const char* anyv2v_last_error(void);
 int anyv2v_version(void);
 /* MFMA / LDS layout self-test used by the gpu test-suite (returns 0 when the layouts the kernels assume hold) */
