@@ -893,39 +893,63 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     }
     const bool glds = (d->flags & 2) != 0;
     const int nf = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
-    k.tilesN = (d->N + nf * 32 - 1) / (nf * 32);
-    if (glds && !(d->flags & 4) && d->N % 320 == 0 && (!geglu || MODE == MODE_LINEAR) && (geglu || d->act == ACT_NONE)) {
-        // large launches: persistent 192 x 320 tiles, one block per CU (see gemm_big_kernel); taken when the tiles fill
-        // the 256 CUs for a whole number of rounds well enough (>= 75 %), or when forced (flags bit3)
-        constexpr int BMB = 192;
-        const int tiles_big = ((d->M + BMB - 1) / BMB) * (d->N / 320);
-        // every DECISION below is taken on the hinted row count (anyv2v_set_batch_hint: a two-branch step chooses what the
-        // three-branch step it stands for chooses -- same split-K factor, same summation order); grids use the true count
-        const int tiles_h = ((av_hint_rows(d->M) + BMB - 1) / BMB) * (d->N / 320);
-        const int rounds = (tiles_h + 255) / 256;
-        const bool fills = tiles_h >= 224 && tiles_h * 4 >= rounds * 256 * 3;
-        // launches that cannot fill the CUs but have a long K loop (8x8-level convs / FF-down of the 3-clip batch, M = 3072):
-        // split K so that (tiles x splits) is one nearly full round of 256 work items; the ordered reduce pass finishes them.
-        // Measured (profiles/r01_gemm_split_ab.txt): 1.2-1.4x over the 128-row kernel's split path from 80 K-tiles on with
-        // >= 224 work items; slower below 72 K-tiles or with a 3/4-full round (M = 1024), which stay on the 128-row kernel.
-        int big_splits = 1;
-        {
-            const int nk_all = k.taps * (k.nt0 + k.nt1);
-            if (!fills && !geglu && !(d->flags & (16 | 8)) && d->workspace != nullptr && tiles_h <= 128 && nk_all >= 72 &&
-                d->N % 8 == 0) {
-                int sp = 256 / tiles_h;
+    const int tilesN_small = (d->N + nf * 32 - 1) / (nf * 32);
+    const int nk_all = k.taps * (k.nt0 + k.nt1);
+    constexpr int BMB = 192;
+    const bool big_ok = glds && !(d->flags & 4) && d->N % 320 == 0 && (!geglu || MODE == MODE_LINEAR) && (geglu || d->act == ACT_NONE);
+    // Launch plan as a function of the row count: kernel family (persistent 192 x 320 tiles / 128-row tiles) and split-K factor.
+    //  * persistent kernel: taken when its tiles fill the 256 CUs for a whole number of rounds well enough (>= 75 %), or when
+    //    forced (flags bit3);
+    //  * launches that cannot fill the CUs but have a long K loop (8x8-level convs / FF-down of the 3-clip batch, M = 3072): split K
+    //    so that (tiles x splits) is one nearly full round of 256 work items; the ordered reduce pass finishes them.  Measured
+    //    (profiles/r01_gemm_split_ab.txt): 1.2-1.4x over the 128-row kernel's split path from 80 K-tiles on with >= 224 work items;
+    //    slower below 72 K-tiles or with a 3/4-full round (M = 1024), which stay on the 128-row kernel;
+    //  * 128-row kernel split-K for launches that cannot fill the chip (512 block slots) and have a long K loop (with 20 K-tiles the
+    //    second pass costs more than the idle CUs; with 60 it pays only when fewer than a quarter of the block slots would be busy;
+    //    from ~72 K-tiles on it always pays).
+    struct Plan { int big, splits; };
+    auto plan = [&](int rows) -> Plan {
+        const bool ws_ok = d->workspace != nullptr && d->N % 8 == 0;
+        if (big_ok) {
+            const int tb = ((rows + BMB - 1) / BMB) * (d->N / 320);
+            const int rounds = (tb + 255) / 256;
+            const bool fills = tb >= 224 && tb * 4 >= rounds * 256 * 3;
+            if (!fills && !geglu && !(d->flags & (16 | 8)) && ws_ok && tb <= 128 && nk_all >= 72) {
+                int sp = 256 / tb;
                 if (sp > 8) sp = 8;
                 if (sp > nk_all / 12) sp = nk_all / 12;
-                if (sp >= 2 && tiles_h * sp >= 224 &&
-                    (size_t)sp * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes)
-                    big_splits = sp;
+                if (sp >= 2 && tb * sp >= 224 && (size_t)sp * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {1, sp};
             }
+            if (fills || (d->flags & 8)) return {1, 1};
         }
-        if (big_splits > 1) {
-            k.tilesN = d->N / 320;
-            k.splits = big_splits;
+        const int tm = ((rows + 127) / 128) * tilesN_small;
+        const bool split_pays = (tm <= 128 && nk_all >= 32) || nk_all >= 72;
+        if (glds && !geglu && d->act != ACT_F32OUT && !(d->flags & 16) && ws_ok && tm < 384 && split_pays) {
+            int sp = (512 + tm - 1) / tm;
+            if (sp > 8) sp = 8;
+            if (sp > nk_all / 8) sp = nk_all / 8;
+            if (sp >= 2 && (size_t)sp * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {0, sp};
+        }
+        return {0, 1};
+    };
+    // Batch hint (anyv2v_set_batch_hint): what fixes the ARITHMETIC is the split-K factor (fp32 partial tiles summed afterwards);
+    // the two kernel families accumulate every output element in the same order (tests/gpu_checks.py asserts it bit for bit).  A
+    // hinted launch therefore takes the split factor of the launch it stands for and is otherwise planned on its own row count.
+    Plan use = plan(d->M);
+    if (av_hint_rows(d->M) != d->M) {
+        const Plan ref = plan(av_hint_rows(d->M));
+        if (ref.splits > 1)
+            use = ref;
+        else if (use.splits > 1)
+            use = Plan{0, 1};
+    }
+    if (use.big) {
+        const int tiles_big = ((d->M + BMB - 1) / BMB) * (d->N / 320);
+        k.tilesN = d->N / 320;
+        if (use.splits > 1) {
+            k.splits = use.splits;
             k.partial = (float*)d->workspace;
-            const dim3 grid(tiles_big * big_splits < 256 ? tiles_big * big_splits : 256);
+            const dim3 grid(tiles_big * use.splits < 256 ? tiles_big * use.splits : 256);
             hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, false, true>), grid, dim3(512), 0, s, k);
             const long long total = (long long)d->M * (d->N / 8);
             long long blocks = (total + 255) / 256;
@@ -933,40 +957,27 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k);
             return av_launch_status("gemm_big<split-K>");
         }
-        if (fills || (d->flags & 8)) {
-            k.tilesN = d->N / 320;
-            const dim3 grid(tiles_big < 256 ? tiles_big : 256);
+        const dim3 grid(tiles_big < 256 ? tiles_big : 256);
 #ifdef ANYV2V_EXPERIMENTS  // probe build only (make experiments): phase-timestamp instantiations, tools/gemm_big_trace.py
 #include "../../tools/experiments/gemm_dispatch_big_probe.inc"
 #endif
-            if constexpr (MODE == MODE_LINEAR) {
-                if (geglu)
-                    hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR>), grid, dim3(512), 0, s, k);
-                else
-                    hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR>), grid, dim3(512), 0, s, k);
-            } else {
-                hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE>), grid, dim3(512), 0, s, k);
-            }
-            return av_launch_status("gemm_big");
+        if constexpr (MODE == MODE_LINEAR) {
+            if (geglu)
+                hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR>), grid, dim3(512), 0, s, k);
+            else
+                hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR>), grid, dim3(512), 0, s, k);
+        } else {
+            hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE>), grid, dim3(512), 0, s, k);
         }
+        return av_launch_status("gemm_big");
     }
+    k.tilesN = tilesN_small;
     const int tiles = ((d->M + 127) / 128) * k.tilesN;
-    const int tiles_hint = ((av_hint_rows(d->M) + 127) / 128) * k.tilesN;   // decisions: hinted rows (see above)
-    // split-K for launches that cannot fill the chip (512 block slots) and have a long K loop (the 8x8 / 16x16-level
-    // convs: 64..256 tiles x 180..360 K-tiles); needs the caller's fp32 workspace
-    const int nk = k.taps * (k.nt0 + k.nt1);
-    // (measured, tools history in DESIGN.md: with 20 K-tiles the second pass costs more than the idle CUs; with 60 it
-    //  pays only when fewer than a quarter of the block slots would be busy; from ~72 K-tiles on it always pays)
-    const bool split_pays = (tiles_hint <= 128 && nk >= 32) || nk >= 72;
-    if (glds && !geglu && d->act != ACT_F32OUT && !(d->flags & 16) && d->workspace != nullptr && tiles_hint < 384 && split_pays &&
-        d->N % 8 == 0) {
-        int splits = (512 + tiles_hint - 1) / tiles_hint;
-        if (splits > 8) splits = 8;
-        if (splits > nk / 8) splits = nk / 8;
-        if (splits >= 2 && (size_t)splits * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes) {
-            k.splits = splits;
-            k.partial = (float*)d->workspace;
-        }
+    const int nk = nk_all;
+    (void)nk;
+    if (use.splits > 1) {
+        k.splits = use.splits;
+        k.partial = (float*)d->workspace;
     }
     const dim3 grid(tiles * k.splits);
 #ifdef ANYV2V_EXPERIMENTS  // probe build only: phase timestamps (flag 32) / K-loop knock-outs (flags 64..448), tools/gemm_trace.py

@@ -328,6 +328,13 @@ def ddim_step(v: torch.Tensor, x: torch.Tensor, sa_t: float, sb_t: float, sa_p: 
 _HINT = [1, 1]   # mirrored for the host-side decisions (ln_gemm_supported)
 
 
+def set_batch_hint(num: int, den: int):
+    """Switch the hint inside a forward (the shared stem of a CFG batch has one branch less than the layers behind it, so its
+    ratio differs: ``I2VGenXLUNet._forward_core``)."""
+    _lib.check(_lib.load().anyv2v_set_batch_hint(int(num), int(den)), "anyv2v_set_batch_hint")
+    _HINT[:] = [int(num), int(den)]
+
+
 class batch_hint:
     """``with ops.batch_hint(3, 2): ...`` -- the launches inside choose kernels / split-K factors / GroupNorm chunking as if they had
     3/2 of their rows (``anyv2v_set_batch_hint``): a [negative, editing] step then computes, bit for bit, what the three-branch step

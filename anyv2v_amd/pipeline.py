@@ -142,6 +142,7 @@ class _StepEngine:
 
     def _body(self):
         if self.batch_hint is not None:
+            self.ctx.batch_hint = self.batch_hint   # (the forward switches between the stem's and the full batch's ratio)
             with ops.batch_hint(*self.batch_hint):
                 return self._body_inner()
         return self._body_inner()
@@ -164,6 +165,7 @@ class _StepEngine:
         if g is None:
             # warm up eagerly on the side (pure: the UNet forward does not touch the latents), then capture
             if self.batch_hint is not None:
+                self.ctx.batch_hint = self.batch_hint
                 with ops.batch_hint(*self.batch_hint):
                     self.unet._forward_core(self.ctx, self.sample)
             else:

@@ -450,8 +450,11 @@ class BasicTransformerBlock(nn.Module):
             h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             x = self.attn1.run(ctx, h, geom, residual=x)
         if expand is not None:
+            after = getattr(ctx, "batch_hint_after", None)
             ctx, geom = expand
             x = expand_shared(x, ctx)
+            if after is not None:   # the stem ends here: from now on the full batch's hint
+                ops.set_batch_hint(*after)
         kv = ctx.kv_for(self.attn2) if self.attn2.is_cross else None
         f = self._fold("attn2", isinstance(self.attn2.processor, HipAttnProcessor), m_min(x), dim if self.attn2.is_cross else 3 * dim)
         if f is not None:
@@ -981,6 +984,13 @@ class I2VGenXLUNet(nn.Module):
         # -- conv_in, transformer_in, the first ResNet / temporal-conv / self-attention of down_blocks[0] -- runs
         # once for the pair and is expanded where the branches start to differ (exact).
         stem = ctx.stem_ctx if (getattr(ctx, "shared_stem", False) and B >= 2 and self.down_blocks[0].has_cross_attention) else None
+        # batch hint (ops.batch_hint; set by a step engine that runs a subset of another engine's branches, e.g. (3, 2)): the
+        # shared stem holds one branch less on both sides -- (2, 1) -- until the first transformer block expands it
+        hint = getattr(ctx, "batch_hint", None)
+        ctx.stem_ctx.batch_hint_after = None
+        if hint is not None:
+            ctx.stem_ctx.batch_hint_after = hint if stem is not None else None
+            ops.set_batch_hint(*((hint[0] - 1, hint[1] - 1) if stem is not None else hint))
         if stem is not None:
             T2 = (B - 1) * F * H * W
             ops.ncfhw_to_tokens(sample[:B - 1], ctx.xin[:T2], col0=0)

@@ -392,11 +392,13 @@ def multi_edit(pipe, device, seed):
     cached = [edit(k) for k in range(3)]      # edit 0 records (+ captures the record / replay graphs on first use), 1 and 2 replay
     cached2 = [edit(k) for k in range(3)]     # steady state: everything replayed
     equal = all(bool(torch.equal(a[1], b[1])) for a, b in zip(plain, cached)) and all(bool(torch.equal(a[1], b[1])) for a, b in zip(plain, cached2))
+    md = lambda a, b: float((a[1].float() - b[1].float()).abs().max())
     res = {"edit_seconds_without_cache": [round(x[0], 3) for x in plain],
            "edit_seconds_with_cache_first_pass": [round(x[0], 3) for x in cached],
            "edit_seconds_with_cache_replay": [round(x[0], 3) for x in cached2],
            "speedup_per_additional_edit": round(sum(x[0] for x in plain) / sum(x[0] for x in cached2), 3),
-           "bit_equal_to_uncached": equal, "cache_gib": round(cache.nbytes() / 2**30, 2),
+           "bit_equal_to_uncached": equal, "max_abs_diff_first_pass": [md(a, b) for a, b in zip(plain, cached)],
+           "max_abs_diff_replay_pass": [md(a, b) for a, b in zip(plain, cached2)], "cache_gib": round(cache.nbytes() / 2**30, 2),
            "recorded_steps": cache.recorded_steps, "replayed_steps": cache.replayed_steps,
            "what": "50-step PnP edits (cfg 9, conv + spatial + temporal injection on every step) of one inverted 16 f x 512^2 clip, "
                    "latents out; first pass: edit 0 records the source branch's features (three-branch steps + copies), edits 1-2 replay "

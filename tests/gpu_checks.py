@@ -180,6 +180,12 @@ def check_gemm_big():
             out.append(_res(f"gemm[big] M{M} N{N} K{K} res={res} rowvec={bool(rvd)}", y, _gemm_ref(a, w, bias, rv, rvd, r), KTOL))
             yn = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r, naive=True)
             out.append(_res(f"gemm[big] == naive kernel M{M} N{N} K{K}", y, yn.float(), 2e-3))
+            # the two tile-kernel families accumulate every output element in the same order: BIT-equal without split-K (what lets a
+            # batch-hinted launch keep its own kernel family and only take the reference launch's split factor, gemm.hip dispatch)
+            ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
+            ys = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r)
+            ops.GEMM_FLAGS = (saved & ~4) | 8
+            out.append(_res(f"gemm[big] bit-equal to the 128-row kernel M{M} N{N} K{K}", y, ys.float(), 0.0))
         # two-source K loop (skip concat)
         a0, a1 = rnd(768, 128), rnd(768, 64)
         w = rnd(320, 192, scale=0.1)
@@ -204,6 +210,11 @@ def check_gemm_big():
                      mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0))
         ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + temb.float().repeat_interleave(2, 0)[:, :, None, None]
         out.append(_res("conv3x3[big] s1 +bias+temb+res", y, _to_tokens(ref) + res.float(), KTOL))
+        ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
+        ys = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=2 * H * W, residual=res, mode=ops.MODE_CONV2D,
+                      conv=(H, W, H, W, 1, 0))
+        ops.GEMM_FLAGS = (saved & ~4) | 8
+        out.append(_res("conv3x3[big] bit-equal to the 128-row kernel", y, ys.float(), 0.0))
         y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, H // 2, W // 2, 2, 0),
                      M=n * (H // 2) * (W // 2))
         out.append(_res("conv3x3[big] stride 2", y, _to_tokens(F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1)), KTOL))
