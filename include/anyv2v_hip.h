@@ -143,10 +143,11 @@ typedef struct AnyV2VAttnDesc {
 
 int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);
 
-/* Small generic attention (any head_dim <= 128, one thread per (batch, head, query)); used once per clip for
- * image_latents_temporal_encoder (2 heads x dim 4) and for the CLIP towers of encode_prompt / _encode_image
- * (pipeline_i2vgen_xl.py:224-441: text 16 heads x 64 with the causal mask, vision 16 heads x 80).  Same addressing as
- * above with explicit head_dim; flags bit4 (16): causal mask (key j visible to query s iff j <= s). */
+/* Attention for any head_dim <= 128, used once per clip: image_latents_temporal_encoder (2 heads x dim 4) and the CLIP towers of
+ * encode_prompt / _encode_image (pipeline_i2vgen_xl.py:224-441: text 16 heads x 64 with the causal mask, vision 16 heads x 80).
+ * head_dim a multiple of 16 and Sk <= 288: a whole-sequence MFMA kernel (K and V^T of a head in LDS, exact softmax over the
+ * score row block in registers); anything else, or flags bit0: one thread per (batch, head, query).  Same addressing as above
+ * with explicit head_dim; flags bit4 (16): causal mask (key j visible to query s iff j <= s). */
 int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream);
 
 /* ---- elementwise / layout --------------------------------------------------------------------- */

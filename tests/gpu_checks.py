@@ -766,6 +766,29 @@ def check_attention(naive_too=True):
 
 
 # ------------------------------------------------------------------------------------------------ CLIP towers (F1)
+def check_attention_small_mfma():
+    """Whole-sequence MFMA attention of the CLIP towers (``anyv2v_attention_small_f16``: head_dim a multiple of 16, Sk <= 288) vs
+    fp32 SDPA and vs the one-thread-per-query kernel it replaces: ViT-H/14 (257 tokens, 16 x 80), the text tower (77 tokens, 16 x 64,
+    causal), head_dim 128, query counts that are not multiples of the 64-query block, column windows of a fused QKV matrix."""
+    out = []
+    for (B, h, S, d, causal) in [(2, 16, 257, 80, False), (3, 16, 77, 64, True), (1, 4, 200, 128, False), (2, 3, 50, 96, True),
+                                 (1, 2, 288, 64, False)]:
+        H = h * d
+        qkv = rnd(B * S, 3 * H, seed=S + d)
+        o = torch.zeros(B * S, H, dtype=torch.float16, device=DEV)
+        kw = dict(batch=B, heads=h, Sq=S, Sk=S, inner=1, q_strides=(S, 0, 1), kv_strides=(S, 0, 1), scale=d ** -0.5, head_dim=d,
+                  causal=causal)
+        ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, **kw)
+        sp = lambda x: x.float().view(B, S, h, d).transpose(1, 2)
+        ref = F.scaled_dot_product_attention(sp(qkv[:, :H]), sp(qkv[:, H:2 * H]), sp(qkv[:, 2 * H:]), is_causal=causal)
+        ref = ref.transpose(1, 2).reshape(B * S, H)
+        out.append(_res(f"attention[small mfma] B{B} h{h} S{S} d{d} causal={causal} vs fp32 SDPA", o, ref, KTOL))
+        o2 = torch.zeros_like(o)
+        ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o2, naive=True, **kw)
+        out.append(_res(f"attention[small mfma] == one-thread-per-query kernel S{S} d{d}", o, o2.float(), 1.5e-3))
+    return out
+
+
 def check_clip():
     """``anyv2v_amd.clip`` on the real kernels vs ``transformers``' CLIPTextModel / CLIPVisionModelWithProjection in
     fp32 on the CPU, same weights: a tiny pair (3 / 2 layers) and the checkpoint's widths (text 1024 / 16 heads x 64 / 4096 with
@@ -1958,7 +1981,8 @@ def check_vae(full: bool = True):
     return out
 
 
-ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_splitk, check_conv, check_norms, check_attention, check_elementwise,
+ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_ws, check_gemm_ws_ln, check_gemm_splitk, check_conv, check_norms, check_attention,
+                     check_attention_small_mfma, check_elementwise,
                      check_full_size_properties, check_vae_kernels]
 
 
