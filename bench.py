@@ -140,6 +140,27 @@ def roofline_conv(device):
             "context": SUSTAINED_NOTE_16}
 
 
+def roofline_gemm_ws(device):
+    """Transformer feed-forward up-projection + GEGLU at the edit step's 64x64 level (98304 tokens, 320 -> 2 x 1280): the
+    weight-stationary kernel (gemm_ws.hip).  2*M*K*N FLOP with N = 2560 (both halves of the GEGLU projection)."""
+    from anyv2v_amd import ops
+    M, K, N = 98304, 320, 2560
+    x = torch.randn(M, K, device=device).to(torch.float16)
+    w = (torch.randn(N, K, device=device) / K ** 0.5).to(torch.float16)
+    b = torch.zeros(N, dtype=torch.float16, device=device)
+    out = torch.empty(M, N // 2, dtype=torch.float16, device=device)
+    fn = lambda: ops.gemm(x, w, bias=b, act=ops.ACT_GEGLU, out=out)
+    ms = measure_kernel(fn)
+    flops = 2.0 * M * K * N
+    ach = flops / (ms * 1e-3) / 1e12
+    traffic, src = measured_traffic("gemm_ws_kernel<320, 160, true")
+    return {"bound": "mfma", "kernel": "gemm_ws_kernel<K=320, GEGLU> (feed-forward up-projection + GEGLU, 98304 x 320 -> 1280; "
+                                       "weight slab resident in LDS, wave-private row strips)", "achieved": round(ach, 2),
+            "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": M * K * 2 + N * K * 2 + M * (N // 2) * 2, "context": SUSTAINED_NOTE_16}
+
+
 def effective_cpus() -> int:
     """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU box shows 256 hardware
     threads but runs under a 16-CPU cgroup quota; 256 torch threads there get CFS-throttled to a crawl."""
@@ -547,6 +568,7 @@ def main():
             line["roofline"] = roofline_spatial_attention(device)
             line["roofline_pnp"] = roofline_spatial_attention(device, pnp=True)
             line["roofline_gemm"] = roofline_conv(device)
+            line["roofline_gemm_ws"] = roofline_gemm_ws(device)
         if world == 1 and not args.no_clip:
             del e_inv, e_pnp
             torch.cuda.empty_cache()

@@ -30,5 +30,14 @@ for flags in [int(f) for f in os.environ.get("PMC_GEMM_FLAGS", "0").split(",")]:
     for _ in range(reps):
         ops.gemm(x, w, bias=b, mode=ops.MODE_CONV2D, conv=(H, H, H, H, 1, 0), out=out)
 ops.GEMM_FLAGS = 0
+# weight-stationary GEMMs of the 64x64 level at the edit step's row count: feed-forward up-projection + GEGLU and fused QKV
+M, K = 98304, C
+xa = torch.randn(M, K, device="cuda").half()
+for Nn, act in ((2560, ops.ACT_GEGLU), (960, ops.ACT_NONE)):
+    ww = (torch.randn(Nn, K, device="cuda") / K ** 0.5).half()
+    bb = torch.zeros(Nn, dtype=torch.float16, device="cuda")
+    oo = torch.empty(M, Nn // 2 if act == ops.ACT_GEGLU else Nn, dtype=torch.float16, device="cuda")
+    for _ in range(reps):
+        ops.gemm(xa, ww, bias=bb, act=act, out=oo)
 torch.cuda.synchronize()
 print("done")
