@@ -31,7 +31,7 @@ for flags in [int(f) for f in os.environ.get("PMC_GEMM_FLAGS", "0").split(",")]:
         ops.gemm(x, w, bias=b, mode=ops.MODE_CONV2D, conv=(H, H, H, H, 1, 0), out=out)
 ops.GEMM_FLAGS = 0
 # weight-stationary GEMMs of the 64x64 level at the edit step's row count: feed-forward up-projection + GEGLU and fused QKV
-M, K = 98304, C
+M, K = 196608, C
 xa = torch.randn(M, K, device="cuda").half()
 for Nn, act in ((2560, ops.ACT_GEGLU), (960, ops.ACT_NONE)):
     ww = (torch.randn(Nn, K, device="cuda") / K ** 0.5).half()

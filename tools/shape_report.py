@@ -60,13 +60,13 @@ def main():
         return wrapped
 
     def gemm_key(a0, w, *, a1=None, bias=None, rowvec=None, rowvec_div=0, residual=None, act=0, out=None, mode=0, conv=None,
-                 temporal=None, M=None, naive=False):
+                 temporal=None, M=None, naive=False, ln=None):
         M = M if M is not None else a0.shape[0]
         N, K = w.shape
         n_out = N // 2 if act == 3 else N
         nb = 2 * (a0.shape[0] * (a0.shape[1] + (a1.shape[1] if a1 is not None else 0)) + N * K + M * n_out * (2 if residual is not None else 1))
         return ((f"mode{mode}", f"act{act}", M, N, K, "2src" if a1 is not None else "", "res" if residual is not None else "",
-                 "rv" if rowvec is not None else "", str(conv or temporal or "")), 2.0 * M * N * K, nb)
+                 "rv" if rowvec is not None else "", "ln" if ln is not None else "", str(conv or temporal or "")), 2.0 * M * N * K, nb)
 
     def gn_key(x0, gamma, beta, stats, rpg, *, x1=None, groups=32, eps=1e-5, silu=False, out=None, **_kw):
         C = x0.shape[1] + (x1.shape[1] if x1 is not None else 0)
