@@ -141,10 +141,10 @@ def roofline_conv(device):
 
 
 def roofline_gemm_ws(device):
-    """Transformer feed-forward up-projection + GEGLU at the edit step's 64x64 level (98304 tokens, 320 -> 2 x 1280): the
+    """Transformer feed-forward up-projection + GEGLU at the edit step's 64x64 level (3 branches x 16 frames x 4096 = 196608 tokens, 320 -> 2 x 1280): the
     weight-stationary kernel (gemm_ws.hip).  2*M*K*N FLOP with N = 2560 (both halves of the GEGLU projection)."""
     from anyv2v_amd import ops
-    M, K, N = 98304, 320, 2560
+    M, K, N = 196608, 320, 2560
     x = torch.randn(M, K, device=device).to(torch.float16)
     w = (torch.randn(N, K, device=device) / K ** 0.5).to(torch.float16)
     b = torch.zeros(N, dtype=torch.float16, device=device)
@@ -154,7 +154,7 @@ def roofline_gemm_ws(device):
     flops = 2.0 * M * K * N
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = measured_traffic("gemm_ws_kernel<320, 160, true")
-    return {"bound": "mfma", "kernel": "gemm_ws_kernel<K=320, GEGLU> (feed-forward up-projection + GEGLU, 98304 x 320 -> 1280; "
+    return {"bound": "mfma", "kernel": "gemm_ws_kernel<K=320, GEGLU> (feed-forward up-projection + GEGLU, 196608 x 320 -> 1280; "
                                        "weight slab resident in LDS, wave-private row strips)", "achieved": round(ach, 2),
             "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
             "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src,
