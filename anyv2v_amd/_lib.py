@@ -67,6 +67,8 @@ SYMBOLS = {
     "anyv2v_tokens_to_ncfhw_f16": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "anyv2v_adaptive_avgpool_f16": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "anyv2v_copy_cols_f16": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _I64, _I32, _VP]),
+    "anyv2v_gather_rows_f16": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),
+    "anyv2v_rotary_f16": (C.c_int, [_VP, _I32, _I64, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "anyv2v_cfg_ddim_step_f16": (C.c_int, [_VP, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "anyv2v_ddim_step_f16": (C.c_int, [_VP, _VP, _VP, _F32, _F32, _F32, _F32, _I64, _VP]),
     "anyv2v_set_batch_hint": (C.c_int, [_I32, _I32]),

@@ -1,0 +1,468 @@
+"""The ConsistI2V hook family: the decoder blocks that carry every PnP hook site of
+``consisti2v/pnp_utils.py:19-345`` -- ``VideoLDMCrossAttnUpBlock`` (``consisti2v/consisti2v/models/videoldm_unet_blocks.py:548-745``)
+with its ``ResnetBlock2D`` / ``TemporalResnetBlock`` / spatial and temporal ``Transformer2DConditionModel`` layers -- on the HIP
+kernels, plus the four registration functions with the reference's names and arguments.
+
+Scope: the blocks ``model.unet.up_blocks[1..3]`` the hooks index, not the whole ``VideoLDMUNet3DConditionModel`` (its released
+``unet/config.json`` is not in the reference tree; the encoder half, mid block and conditioning embeddings hold no hook site).
+Module tree and state-dict keys are the reference's, so a block of a real checkpoint loads unchanged.
+
+What differs from the I2VGen-XL family (``anyv2v_amd/unet.py``) and how it is computed here, all on the token layout
+``X[(b f)(h w), C]``:
+
+* spatial ``attn1`` attends over [own frame ; first frame of the clip] (``videoldm_transformer_blocks.py:479-489``): K and V are
+  per-token projections, so the first-frame half IS the K / V rows of frame 0 -- one fused QKV GEMM, one row gather that lays the
+  two halves side by side, the flash kernel with Sk = 2 HW.  PnP injection (``consisti2v/pnp_utils.py:188-197``) aliases Q and K
+  of all three branches to the source branch inside the kernel (qk_mod), as for I2VGen-XL.
+* temporal ``attn1`` attends over [the pixel's F frames ; the pixel's 8 neighbours in the first frame] with rotary position
+  embedding on the first half of the channels (``:490-503``, ``videoldm_attention.py:589-599,773-777``).  The rotary kernel runs in
+  place on the Q and K columns of the fused projection with the frame index as position; the neighbour keys have position 0
+  (``key_pos_idx``), where the rotation is the identity -- they are rows of frame 0 of the same K / V, fetched by the row gather.
+  Injection happens before the rotation in the reference (``pnp_utils.py:296-310``); the rotation depends on the position only,
+  so aliasing after it is the same thing.
+* temporal ``attn2`` (text cross-attention, ``RotaryEmbAttnProcessor2_0``): only Q is rotated (qlen != klen).
+* ``TemporalResnetBlock`` and the temporal transformer blend with a learned ``alpha``: alpha x + (1 - alpha)(x + f(x)) =
+  x + (1 - alpha) f(x); (1 - alpha) is folded into the last projection's weights at pack time.
+* GroupNorm of the temporal layers is the 4-D one (per frame), eps 1e-6.
+
+Performance is not tuned for this family (temporal attention at head_dim C / 8 runs on the generic small-attention kernels).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import ACT_NONE, MODE_TEMPORAL
+from .unet import (Conv2d, Conv3dTemporal, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU, Upsample2D, _param,
+                   pnp_on)
+
+ROTARY_THETA = 10000.0  # rotary_embedding.py:76 (freqs_for="lang")
+
+
+class _Ctx:
+    """Per-call state of a block: geometry, GroupNorm scratch, this block's time-embedding projections, the text tokens."""
+
+    def __init__(self, B, F, H, W, device, groups):
+        self.B, self.F, self.H, self.W = B, F, H, W
+        self.stats = torch.empty(ops.gn_scratch_floats(B * F, 1, groups), dtype=torch.float32, device=device)
+        self.temb_all = None
+        self.emb = None
+        self.context = None   # [B * L, D] text tokens, one copy per batch element
+        self.L = 0
+        self._idx: Dict[tuple, torch.Tensor] = {}
+
+
+def _first_frame_index(B, F, HW, device):
+    """Row index of the key / value sequence [own frame ; first frame] of every image: out row ((n, half, s)) -> qkv row."""
+    n = torch.arange(B * F, device=device)
+    own = n[:, None] * HW + torch.arange(HW, device=device)[None]
+    first = ((n // F) * F)[:, None] * HW + torch.arange(HW, device=device)[None]
+    return torch.stack([own, first], 1).reshape(-1).to(torch.int32).contiguous()
+
+
+def _window_index(B, F, H, W, device):
+    """Row index of the key / value sequence of every (b, pixel): its F frames, then its 8 neighbours in frame 0 in the order of
+    ``first_frame_windows[..., mask]`` (``videoldm_transformer_blocks.py:494-497``: 3 x 3 window of the replicate-padded frame,
+    row-major, centre removed)."""
+    HW = H * W
+    y, x = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+    nb = []
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            if dy == 0 and dx == 0:
+                continue
+            nb.append(((y + dy).clamp(0, H - 1) * W + (x + dx).clamp(0, W - 1)).reshape(-1))
+    nb = torch.stack(nb, 1)                                                    # [HW, 8] pixel index inside frame 0
+    p = torch.arange(HW, device=device)
+    b = torch.arange(B, device=device)
+    frames = (b[:, None, None] * F + torch.arange(F, device=device)[None, None, :]) * HW + p[None, :, None]   # [B, HW, F]
+    window = (b[:, None, None] * F * HW) + nb[None]                            # [B, HW, 8]
+    return torch.cat([frames, window], 2).reshape(-1).to(torch.int32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------- attention
+class HipSpaAttnProcessor:
+    """Native ``ModifiedSpaAttnProcessor`` (``consisti2v/pnp_utils.py:133-225``) / ``AttnProcessor2_0`` of a spatial
+    ``ConditionalAttention``; ``injection_schedule`` / ``t`` as in the reference."""
+
+    def __init__(self, injection_schedule=None):
+        self.injection_schedule = injection_schedule
+        self.t = None
+
+    def run(self, attn, ctx, h, residual, first_frame: bool, kv=None):
+        B, F, HW, C = ctx.B, ctx.F, ctx.H * ctx.W, attn.inner_dim
+        T = h.shape[0]
+        o = torch.empty((T, C), dtype=torch.float16, device=h.device)
+        if kv is not None:   # text cross-attention: every frame of batch element b reads the same L text tokens
+            q = ops.gemm(h, attn.to_q.weight)
+            k_, v_ = kv
+            ops.attention(q, k_, v_, o, batch=B * F, heads=attn.heads, Sq=HW, Sk=ctx.L, q_strides=(HW, 0, 1), kv_strides=(ctx.L, 0, 1),
+                          kv_div=F, scale=attn.scale, head_dim=attn.dim_head)
+            return ops.gemm(o, attn.to_out[0].weight, bias=attn.to_out[0].bias, residual=residual)
+        inject = pnp_on(self.t, self.injection_schedule)
+        qkv = ops.gemm(h, attn._w_qkv)
+        qk_mod = (B * F) // 3 if inject else 0
+        if first_frame:
+            key = ("ff", B, F, HW)
+            if key not in ctx._idx:
+                ctx._idx[key] = _first_frame_index(B, F, HW, h.device)
+            kvc = torch.empty((2 * T, 2 * C), dtype=torch.float16, device=h.device)
+            ops.gather_rows(qkv, C, ctx._idx[key], kvc, 0, 2 * C)
+            ops.attention(qkv[:, :C], kvc[:, :C], kvc[:, C:], o, batch=B * F, heads=attn.heads, Sq=HW, Sk=2 * HW, q_strides=(HW, 0, 1),
+                          kv_strides=(2 * HW, 0, 1), qk_mod=qk_mod, scale=attn.scale, head_dim=attn.dim_head)
+        else:
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=B * F, heads=attn.heads, Sq=HW, Sk=HW,
+                          q_strides=(HW, 0, 1), kv_strides=(HW, 0, 1), qk_mod=qk_mod, scale=attn.scale, head_dim=attn.dim_head)
+        return ops.gemm(o, attn.to_out[0].weight, bias=attn.to_out[0].bias, residual=residual)
+
+
+class HipTmpAttnProcessor:
+    """Native ``ModifiedTmpAttnProcessor`` (``consisti2v/pnp_utils.py:229-345``) / ``RotaryEmbAttnProcessor2_0``
+    (``videoldm_attention.py:710-808``) of a ``TemporalConditionalAttention`` with rotary position embedding."""
+
+    def __init__(self, injection_schedule=None):
+        self.injection_schedule = injection_schedule
+        self.t = None
+
+    def run(self, attn, ctx, h, residual, adjacent: bool, kv=None):
+        B, F, H, W, C = ctx.B, ctx.F, ctx.H, ctx.W, attn.inner_dim
+        HW = H * W
+        T = h.shape[0]
+        o = torch.empty((T, C), dtype=torch.float16, device=h.device)
+        qs = (F * HW, 1, HW)   # sequence of (b, pixel): F rows, HW apart
+        if kv is not None:     # text cross-attention; qlen != klen: only the queries are rotated (videoldm_attention.py:773-777)
+            q = ops.gemm(h, attn.to_q.weight)
+            ops.rotary(q, 0, attn.rot_dim, HW, F, ROTARY_THETA)
+            k_, v_ = kv
+            # (the K / V batch index i // kv_div = b is decomposed with the same ``inner`` as the queries': b = (b // HW) HW + b % HW)
+            ops.attention(q, k_, v_, o, batch=B * HW, heads=attn.heads, Sq=F, Sk=ctx.L, inner=HW, q_strides=qs,
+                          kv_strides=(HW * ctx.L, ctx.L, 1), kv_div=HW, scale=attn.scale, head_dim=attn.dim_head)
+            return ops.gemm(o, attn.to_out[0].weight, bias=attn.to_out[0].bias, residual=residual)
+        inject = pnp_on(self.t, self.injection_schedule)
+        qkv = ops.gemm(h, attn._w_qkv)
+        ops.rotary(qkv, 0, attn.rot_dim, HW, F, ROTARY_THETA)   # Q
+        ops.rotary(qkv, C, attn.rot_dim, HW, F, ROTARY_THETA)   # K (frame 0: angle 0, unchanged -- the neighbour keys' position)
+        qk_mod = (B * HW) // 3 if inject else 0
+        if adjacent:
+            key = ("win", B, F, H, W)
+            if key not in ctx._idx:
+                ctx._idx[key] = _window_index(B, F, H, W, h.device)
+            S = F + 8
+            kvc = torch.empty((B * HW * S, 2 * C), dtype=torch.float16, device=h.device)
+            ops.gather_rows(qkv, C, ctx._idx[key], kvc, 0, 2 * C)
+            ops.attention(qkv[:, :C], kvc[:, :C], kvc[:, C:], o, batch=B * HW, heads=attn.heads, Sq=F, Sk=S, inner=HW, q_strides=qs,
+                          kv_strides=(HW * S, S, 1), qk_mod=qk_mod, scale=attn.scale, head_dim=attn.dim_head)
+        else:
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=B * HW, heads=attn.heads, Sq=F, Sk=F, inner=HW,
+                          q_strides=qs, kv_strides=qs, qk_mod=qk_mod, scale=attn.scale, head_dim=attn.dim_head)
+        return ops.gemm(o, attn.to_out[0].weight, bias=attn.to_out[0].bias, residual=residual)
+
+
+class ConditionalAttention(nn.Module):
+    """``videoldm_attention.py:49-176`` (the fields the decoder uses): bias-free q / k / v, ``to_out = [Linear, Dropout]``."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        self.inner_dim, self.heads, self.dim_head = heads * dim_head, heads, dim_head
+        self.scale = dim_head ** -0.5
+        self.is_cross = cross_attention_dim is not None
+        kdim = cross_attention_dim if self.is_cross else query_dim
+        self.to_q = Linear(query_dim, self.inner_dim, bias=False)
+        self.to_k = Linear(kdim, self.inner_dim, bias=False)
+        self.to_v = Linear(kdim, self.inner_dim, bias=False)
+        self.to_out = nn.ModuleList([Linear(self.inner_dim, query_dim, bias=True), Identity()])
+        self.spatial_norm = self.group_norm = self.norm_cross = None
+        self.residual_connection, self.rescale_output_factor = False, 1.0
+        self.processor = HipSpaAttnProcessor()
+        self._w_qkv = self._w_kv = None
+
+    def pack(self):
+        if self.is_cross:
+            self._w_kv = torch.cat([self.to_k.weight.data, self.to_v.weight.data], 0).contiguous()
+        else:
+            self._w_qkv = torch.cat([self.to_q.weight.data, self.to_k.weight.data, self.to_v.weight.data], 0).contiguous()
+
+    def text_kv(self, ctx):
+        kv = ops.gemm(ctx.context, self._w_kv)   # [B L, 2 C]
+        return kv[:, :self.inner_dim], kv[:, self.inner_dim:]
+
+
+class _RotaryFreqs(nn.Module):
+    """``RotaryEmbedding.freqs`` (``rotary_embedding.py:88-100``): a (non-learned) Parameter in the reference's state dict."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.freqs = nn.Parameter(1.0 / (ROTARY_THETA ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)), requires_grad=False)
+
+
+class _RelativePositionBias(nn.Module):
+    """``videoldm_attention.py:668-707``: constructed by the reference, never used by its forward (commented out at :765-768)."""
+
+    def __init__(self, heads, num_buckets=32):
+        super().__init__()
+        self.relative_attention_bias = nn.Embedding(num_buckets, heads)
+
+
+class TemporalConditionalAttention(ConditionalAttention):
+    """``videoldm_attention.py:552-641`` with ``rotary_emb=True`` (the released model's ``temp_pos_embedding: rotary``)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, n_frames=16):
+        super().__init__(query_dim, cross_attention_dim, heads, dim_head)
+        self.n_frames = n_frames
+        self.use_rotary_emb = True
+        self.rot_dim = self.inner_dim // 2           # RotaryEmbedding(self.inner_dim // 2), applied before the head split
+        self.rotary_emb = _RotaryFreqs(self.rot_dim)
+        self.rotary_bias = _RelativePositionBias(heads)
+        self.processor = HipTmpAttnProcessor()
+
+    def pack(self):
+        super().pack()
+        want = 1.0 / (ROTARY_THETA ** (torch.arange(0, self.rot_dim, 2)[: self.rot_dim // 2].float() / self.rot_dim))
+        if not torch.allclose(self.rotary_emb.freqs.detach().float().cpu(), want, rtol=1e-4, atol=0):
+            raise NotImplementedError("rotary frequencies other than theta = 10000 ('lang') are not supported by anyv2v_rotary_f16")
+        assert self.rot_dim % 8 == 0, "rotary window must be a multiple of 8 channels"
+
+
+# ------------------------------------------------------------------------------------------------- transformer blocks
+class BasicConditionalTransformerBlock(nn.Module):
+    """``videoldm_transformer_blocks.py:321-563``: norm1 -> attn1 (+first frame / +adjacent first-frame window) -> norm2 -> attn2
+    (text) -> norm3 -> GEGLU feed-forward, each with a residual."""
+
+    def __init__(self, dim, heads, dim_head, cross_attention_dim, n_frames, is_temporal, augment_temporal_attention):
+        super().__init__()
+        self.n_frames, self.is_temporal, self.augment_temporal_attention = n_frames, is_temporal, augment_temporal_attention
+        self.only_cross_attention = False
+        A = (lambda **kw: TemporalConditionalAttention(n_frames=n_frames, **kw)) if is_temporal else ConditionalAttention
+        self.norm1 = LayerNorm(dim)
+        self.attn1 = A(query_dim=dim, heads=heads, dim_head=dim_head)
+        self.norm2 = LayerNorm(dim)
+        self.attn2 = A(query_dim=dim, cross_attention_dim=cross_attention_dim, heads=heads, dim_head=dim_head)
+        self.norm3 = LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def run(self, ctx, x, condition_on_first_frame):
+        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        if self.is_temporal:
+            x = self.attn1.processor.run(self.attn1, ctx, h, x, adjacent=self.augment_temporal_attention)
+        else:
+            x = self.attn1.processor.run(self.attn1, ctx, h, x, first_frame=condition_on_first_frame)
+        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        kv = self.attn2.text_kv(ctx)
+        if self.is_temporal:
+            x = self.attn2.processor.run(self.attn2, ctx, h, x, adjacent=False, kv=kv)
+        else:
+            x = self.attn2.processor.run(self.attn2, ctx, h, x, first_frame=False, kv=kv)
+        h = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self.ff.run(h, x)
+
+
+class Transformer2DConditionModel(nn.Module):
+    """``videoldm_transformer_blocks.py:26-318`` (continuous input): GroupNorm(eps 1e-6) -> proj_in -> blocks -> proj_out ->
+    + input; the temporal variant blends with ``alpha``.  ``use_linear_projection`` only decides the shape of the proj weights
+    (Linear [C, C] or 1 x 1 Conv2d [C, C, 1, 1]): the arithmetic is the same per-token GEMM."""
+
+    def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups, n_frames, is_temporal=False,
+                 augment_temporal_attention=False, use_linear_projection=True, num_layers=1):
+        super().__init__()
+        inner = heads * dim_head
+        self.use_linear_projection = use_linear_projection
+        self.norm = GroupNorm(groups, in_channels, eps=1e-6)
+        mk = (lambda a, b: Linear(a, b)) if use_linear_projection else (lambda a, b: Conv2d(a, b, 1))
+        self.proj_in = mk(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([
+            BasicConditionalTransformerBlock(inner, heads, dim_head, cross_attention_dim, n_frames, is_temporal, augment_temporal_attention)
+            for _ in range(num_layers)])
+        self.proj_out = mk(inner, in_channels)
+        self.alpha = nn.Parameter(torch.ones(1), requires_grad=False) if is_temporal else None
+        self._w_out = self._b_out = None
+
+    def pack(self):
+        w, b = self.proj_out.weight.data.reshape(self.proj_out.weight.shape[0], -1), self.proj_out.bias.data
+        if self.alpha is not None:   # alpha x + (1 - alpha)(x + f(x)) = x + (1 - alpha) f(x)
+            s = 1.0 - float(self.alpha.detach().float().clamp(0, 1))
+            w, b = (w.float() * s).to(torch.float16), (b.float() * s).to(torch.float16)
+        self._w_out, self._b_out = w.contiguous(), b.contiguous()
+
+    def run(self, ctx, x, condition_on_first_frame=False):
+        HW = ctx.H * ctx.W
+        h = ops.groupnorm(x, self.norm.weight, self.norm.bias, ctx.stats, HW, groups=self.norm.num_groups, eps=self.norm.eps)
+        h = ops.gemm(h, self.proj_in.weight.reshape(self.proj_in.weight.shape[0], -1), bias=self.proj_in.bias)
+        for blk in self.transformer_blocks:
+            h = blk.run(ctx, h, condition_on_first_frame)
+        return ops.gemm(h, self._w_out, bias=self._b_out, residual=x)
+
+
+class _Conv3DLayer(Conv3dTemporal):
+    """``videoldm_unet_blocks.py:316-328``: Conv3d (3,1,1), padding (1,0,0)."""
+
+
+class TemporalResnetBlock(nn.Module):
+    """``videoldm_unet_blocks.py:225-313`` as the decoder calls it (``conv3d(hidden_states)``: no time embedding):
+    GroupNorm -> SiLU -> (3,1,1) conv -> GroupNorm -> SiLU -> (3,1,1) conv, residual, alpha blend."""
+
+    def __init__(self, in_channels, groups=32, eps=1e-6, temb_channels=512):
+        super().__init__()
+        self.norm1 = GroupNorm(groups, in_channels, eps)
+        self.conv1 = _Conv3DLayer(in_channels, in_channels)
+        self.time_emb_proj = Linear(temb_channels, in_channels)   # in the reference's state dict; unused (temb is None)
+        self.norm2 = GroupNorm(groups, in_channels, eps)
+        self.conv2 = _Conv3DLayer(in_channels, in_channels)
+        self.nonlinearity = SiLU()
+        self.alpha = nn.Parameter(torch.ones(1), requires_grad=False)
+        self.output_scale_factor = 1.0
+        self._w2 = self._b2 = None
+
+    def pack(self):
+        self.conv1.pack()
+        self.conv2.pack()
+        s = 1.0 - float(self.alpha.detach().float().clamp(0, 1))
+        self._w2 = (self.conv2._w.float() * s).to(torch.float16).contiguous()
+        self._b2 = (self.conv2.bias.data.float() * s).to(torch.float16).contiguous()
+
+    def run(self, ctx, x):
+        HW = ctx.H * ctx.W
+        g = self.norm1.num_groups
+        h = ops.groupnorm(x, self.norm1.weight, self.norm1.bias, ctx.stats, HW, groups=g, eps=self.norm1.eps, silu=True)
+        h = ops.gemm(h, self.conv1._w, bias=self.conv1.bias, mode=MODE_TEMPORAL, temporal=(ctx.F, HW))
+        h = ops.groupnorm(h, self.norm2.weight, self.norm2.bias, ctx.stats, HW, groups=g, eps=self.norm2.eps, silu=True)
+        return ops.gemm(h, self._w2, bias=self._b2, mode=MODE_TEMPORAL, temporal=(ctx.F, HW), residual=x)
+
+
+# ------------------------------------------------------------------------------------------------- the decoder block
+class VideoLDMCrossAttnUpBlock(nn.Module):
+    """``videoldm_unet_blocks.py:548-745`` with the released model's options (temporal layers on, rotary temporal position
+    embedding, ``first_frame_condition_mode`` "concat" or "none"; the "conv2d" mode is not built).  Constructor argument names are
+    the reference's."""
+
+    def __init__(self, in_channels, out_channels, prev_output_channel, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
+                 num_attention_heads=1, cross_attention_dim=1280, add_upsample=True, use_linear_projection=False, use_temporal=True,
+                 augment_temporal_attention=False, n_frames=8, n_temp_heads=8, first_frame_condition_mode="none", rotary_emb=False,
+                 transformer_layers_per_block=1, **unused):
+        super().__init__()
+        if not use_temporal or not rotary_emb or first_frame_condition_mode == "conv2d":
+            raise NotImplementedError("native VideoLDMCrossAttnUpBlock: use_temporal=True, rotary_emb=True, first_frame_condition_mode in "
+                                      "('none', 'input_only', 'concat') only")
+        self.n_frames, self.n_temp_heads, self.num_attention_heads = n_frames, n_temp_heads, num_attention_heads
+        self.first_frame_condition_mode = first_frame_condition_mode
+        self.has_cross_attention, self.use_temporal = True, True
+        self.groups, self.cross_attention_dim = resnet_groups, cross_attention_dim
+        self.resnets, self.attentions = nn.ModuleList(), nn.ModuleList()
+        self.conv3ds, self.tempo_attns = nn.ModuleList(), nn.ModuleList()
+        for i in range(num_layers):
+            skip = in_channels if i == num_layers - 1 else out_channels
+            rin = prev_output_channel if i == 0 else out_channels
+            self.resnets.append(ResnetBlock2D(rin + skip, out_channels, temb_channels, resnet_groups, resnet_eps))
+            self.attentions.append(Transformer2DConditionModel(num_attention_heads, out_channels // num_attention_heads, out_channels,
+                                                               cross_attention_dim, resnet_groups, n_frames,
+                                                               use_linear_projection=use_linear_projection,
+                                                               num_layers=transformer_layers_per_block))
+            self.conv3ds.append(TemporalResnetBlock(out_channels))
+            self.tempo_attns.append(Transformer2DConditionModel(n_temp_heads, out_channels // n_temp_heads, out_channels,
+                                                                cross_attention_dim, resnet_groups, n_frames, is_temporal=True,
+                                                                augment_temporal_attention=augment_temporal_attention,
+                                                                use_linear_projection=use_linear_projection,
+                                                                num_layers=transformer_layers_per_block))
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+        self._packed = False
+        self._w_temb = self._b_temb = None
+
+    def pack(self):
+        for m in self.modules():
+            if m is not self and hasattr(m, "pack"):
+                m.pack()
+        col = 0
+        for r in self.resnets:   # one GEMM for the time-embedding projections of the block's resnets
+            r._temb_col = col
+            col += r.out_channels
+        self._w_temb = torch.cat([r.time_emb_proj.weight.data for r in self.resnets], 0).contiguous()
+        self._b_temb = torch.cat([r.time_emb_proj.bias.data for r in self.resnets], 0).contiguous()
+        self._packed = True
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        out = super().load_state_dict(sd, strict=strict, **kw)   # (weights are converted to the parameters' fp16; alpha / freqs stay fp32)
+        self._packed = False
+        return out
+
+    def run(self, ctx, x, skips: List[torch.Tensor]):
+        cond = self.first_frame_condition_mode not in ("none", "input_only")
+        for resnet, conv3d, attn, tattn in zip(self.resnets, self.conv3ds, self.attentions, self.tempo_attns):
+            x = resnet.run(ctx, x, skips.pop(), ctx.H, ctx.W)
+            x = conv3d.run(ctx, x)
+            x = attn.run(ctx, x, condition_on_first_frame=cond)
+            x = tattn.run(ctx, x)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
+        return x
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, **unused):
+        """The reference's call (``videoldm_unet_blocks.py:696-745``): ``hidden_states`` [(b f), C, H, W], the skip tensors of the
+        encoder (last one is consumed first), ``temb`` [(b f), D] and ``encoder_hidden_states`` [(b f), L, D] -- both repeated per
+        frame by the reference's UNet; the first frame's copy of each batch element is read here."""
+        if not self._packed:
+            self.pack()
+        N, C, H, W = hidden_states.shape
+        F = self.n_frames
+        B = N // F
+        dev = hidden_states.device
+        ctx = _Ctx(B, F, H, W, dev, self.groups)
+
+        def tok(t):
+            return t.to(torch.float16).permute(0, 2, 3, 1).reshape(N * H * W, t.shape[1]).contiguous()
+        emb = temb.to(torch.float16).view(B, F, -1)[:, 0].contiguous()
+        ctx.emb = emb
+        ctx.temb_all = ops.gemm(ops.silu(emb), self._w_temb, bias=self._b_temb)
+        ehs = encoder_hidden_states.to(torch.float16)[::F]
+        ctx.L = ehs.shape[1]
+        ctx.context = ehs.reshape(B * ctx.L, -1).contiguous()
+        y = self.run(ctx, tok(hidden_states), [tok(s) for s in res_hidden_states_tuple])
+        Ho, Wo = (2 * H, 2 * W) if self.upsamplers is not None else (H, W)
+        return y.view(N, Ho, Wo, -1).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------- hook registration
+_UP_RES = {1: [0, 1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}      # consisti2v/pnp_utils.py:22 (register_time)
+_INJ_RES = {1: [1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}        # :228, :356 (decoder blocks 4-11)
+
+
+def _sched(injection_schedule):
+    """Schedules may be tensors / lists in the reference's scripts; membership tests must not sync the device."""
+    if injection_schedule is None:
+        return None
+    if isinstance(injection_schedule, torch.Tensor):
+        return frozenset(int(v) for v in injection_schedule.tolist())
+    return frozenset(int(v) for v in injection_schedule)
+
+
+def register_time(model, t):
+    """``consisti2v/pnp_utils.py:19-29``."""
+    t = int(t)
+    setattr(model.unet.up_blocks[1].resnets[1], "t", t)
+    for res, blocks in _UP_RES.items():
+        for block in blocks:
+            setattr(model.unet.up_blocks[res].attentions[block].transformer_blocks[0].attn1.processor, "t", t)
+            setattr(model.unet.up_blocks[res].tempo_attns[block].transformer_blocks[0].attn1.processor, "t", t)
+
+
+def register_conv_injection(model, injection_schedule):
+    """``consisti2v/pnp_utils.py:39-128``: the native ``ResnetBlock2D.run`` holds the injection (source branch's conv features
+    into the other two branches); only the schedule is attached."""
+    setattr(model.unet.up_blocks[1].resnets[1], "injection_schedule", _sched(injection_schedule))
+
+
+def register_spatial_attention_pnp(model, injection_schedule):
+    """``consisti2v/pnp_utils.py:131-240``."""
+    for res, blocks in _INJ_RES.items():
+        for block in blocks:
+            module = model.unet.up_blocks[res].attentions[block].transformer_blocks[0].attn1
+            module.processor = HipSpaAttnProcessor(_sched(injection_schedule))
+
+
+def register_temp_attention_pnp(model, injection_schedule):
+    """``consisti2v/pnp_utils.py:244-362``."""
+    for res, blocks in _INJ_RES.items():
+        for block in blocks:
+            module = model.unet.up_blocks[res].tempo_attns[block].transformer_blocks[0].attn1
+            module.processor = HipTmpAttnProcessor(_sched(injection_schedule))

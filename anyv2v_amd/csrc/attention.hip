@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Generic reference kernel: one thread per (batch, head, query); any head_dim <= 128, any strides, optional causal mask.
+// Generic reference kernel: one thread per (batch, head, query); any head_dim <= 160, any strides, optional causal mask.
 __global__ void attn_naive_kernel(const AttnK p) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)p.batch * p.heads * p.Sq;
@@ -495,7 +495,7 @@ __global__ void attn_naive_kernel(const AttnK p) {
     const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
     const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
     const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-    float q[128], o[128];
+    float q[160], o[160];
     const half_t* qp = p.Q + (qbase + (long long)s * p.q_seq) * p.ldq + h * D;
     for (int d = 0; d < D; ++d) {
         q[d] = (float)qp[d];
@@ -709,7 +709,7 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
 }
 
 extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream) {
-    AV_CHECK(head_dim > 0 && head_dim <= 128, "attention_small: head_dim must be in 1..128");
+    AV_CHECK(head_dim > 0 && head_dim <= 160, "attention_small: head_dim must be in 1..160");
     AttnK k;
     int rc = fill(d, k, head_dim);
     if (rc != ANYV2V_OK) return rc;
@@ -717,7 +717,7 @@ extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_
     // short sequences, head_dim a multiple of 16: whole-sequence MFMA kernel (K and V^T of a head in LDS); flag bit0 = naive kernel
     const int ds = (head_dim + 31) / 32;
     const int nkb = d->Sk <= 96 ? 6 : (d->Sk <= 288 ? 18 : 0);
-    const bool fast = !(d->flags & 1) && head_dim % 16 == 0 && ds >= 2 && nkb > 0 && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
+    const bool fast = !(d->flags & 1) && head_dim % 16 == 0 && ds >= 2 && ds <= 4 && nkb > 0 && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
                       d->ldv % 8 == 0 && d->ldo % 4 == 0 && av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) &&
                       (((uintptr_t)d->O) & 7) == 0 && d->heads <= 65535 && d->batch <= 65535;
     if (!fast) return launch_naive(k, (hipStream_t)stream);
@@ -727,7 +727,7 @@ extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_
     do {                                                                                                                   \
         static bool attr_set = false;                                                                                      \
         if (!attr_set) {                                                                                                   \
-            hipFuncSetAttribute((const void*)small_attn_mfma_kernel<DS_, NKB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)small_attn_mfma_kernel<DS_, NKB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                                 \
             attr_set = true;                                                                                               \
         }                                                                                                                  \

@@ -84,6 +84,44 @@ __global__ void copy_cols_kernel(const half_t* __restrict__ X, int ldx, int xcol
     }
 }
 
+// Y[m, ycol0 : ycol0 + C] = X[idx[m], xcol0 : xcol0 + C]: one thread per 16-byte chunk (C % 8 == 0, 16-byte aligned rows)
+__global__ void gather_rows_kernel(const half_t* __restrict__ X, int ldx, int xcol0, const int* __restrict__ idx,
+                                   half_t* __restrict__ Y, int ldy, int ycol0, long long M, int C8) {
+    const long long total = M * C8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C8;
+        const int c = (int)(i - m * C8) * 8;
+        *(h8*)(Y + m * ldy + ycol0 + c) = *(const h8*)(X + (long long)idx[m] * ldx + xcol0 + c);
+    }
+}
+
+// Rotary position embedding, in place: the pair (2 i, 2 i + 1) of columns [col0, col0 + rot_dim) of row r is rotated by the
+// angle pos(r) * theta^(-2 i / rot_dim), pos(r) = (r / rows_per_pos) % n_pos.  One thread per 4 pairs (16 bytes).
+__global__ void rotary_kernel(half_t* __restrict__ X, int ld, long long rows, int col0, int rot_dim, int rows_per_pos,
+                              int n_pos, float log2_theta) {
+    const int C8 = rot_dim >> 3;
+    const long long total = rows * C8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C8;
+        const int c = (int)(i - r * C8) * 8;
+        const float pos = (float)((r / rows_per_pos) % n_pos);
+        half_t* px = X + r * ld + col0 + c;
+        h8 v = *(const h8*)px;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float freq = exp2f(-log2_theta * (float)(c + 2 * e) / (float)rot_dim);
+            float sn, cs;
+            sincosf(pos * freq, &sn, &cs);
+            const float a = (float)v[2 * e], b = (float)v[2 * e + 1];
+            v[2 * e] = (half_t)(a * cs - b * sn);
+            v[2 * e + 1] = (half_t)(b * cs + a * sn);
+        }
+        *(h8*)px = v;
+    }
+}
+
 __global__ void cfg_ddim_step_kernel(const half_t* __restrict__ V, int ldv, int b_unc, int b_cond, float g,
                                      const float* __restrict__ coef, const half_t* __restrict__ lat,
                                      half_t* __restrict__ out, int C, int F, int HW) {
@@ -218,6 +256,26 @@ extern "C" int anyv2v_copy_cols_f16(const void* X, int32_t ldx, int32_t xcol0, v
     hipLaunchKernelGGL(copy_cols_kernel, dim3(nblk(M * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)X, ldx, xcol0, (half_t*)Y, ldy, ycol0, (long long)M, C);
     return av_launch_status("copy_cols");
+}
+
+extern "C" int anyv2v_gather_rows_f16(const void* X, int32_t ldx, int32_t xcol0, const int32_t* idx, void* Y, int32_t ldy,
+                                      int32_t ycol0, int64_t M, int32_t C, void* stream) {
+    AV_CHECK(X && Y && idx && M > 0 && C > 0, "gather_rows: bad arguments");
+    AV_CHECK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcol0 % 8 == 0 && ycol0 % 8 == 0 && av_aligned16(X) && av_aligned16(Y),
+             "gather_rows: rows and column windows must be 16-byte aligned");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk(M * (C / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)X, ldx, xcol0, (const int*)idx, (half_t*)Y, ldy, ycol0, (long long)M, C / 8);
+    return av_launch_status("gather_rows");
+}
+
+extern "C" int anyv2v_rotary_f16(void* X, int32_t ld, int64_t rows, int32_t col0, int32_t rot_dim, int32_t rows_per_pos,
+                                 int32_t n_pos, float theta, void* stream) {
+    AV_CHECK(X && rows > 0 && rot_dim > 0 && rows_per_pos > 0 && n_pos > 0 && theta > 0.f, "rotary: bad arguments");
+    AV_CHECK(rot_dim % 8 == 0 && ld % 8 == 0 && col0 % 8 == 0 && col0 + rot_dim <= ld && av_aligned16(X),
+             "rotary: the rotated column window must be 16-byte aligned and inside the row");
+    hipLaunchKernelGGL(rotary_kernel, dim3(nblk(rows * (rot_dim / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)X, ld, (long long)rows, col0, rot_dim, rows_per_pos, n_pos, log2f(theta));
+    return av_launch_status("rotary");
 }
 
 extern "C" int anyv2v_softmax_rows_f32_f16(const float* S, int32_t lds_, void* P, int32_t ldp, int32_t rows, int32_t cols,

@@ -301,6 +301,27 @@ def copy_cols(x: torch.Tensor, xcol0: int, y: torch.Tensor, ycol0: int, ncols: i
     return y
 
 
+def gather_rows(x: torch.Tensor, xcol0: int, idx: torch.Tensor, y: torch.Tensor, ycol0: int, ncols: int):
+    """y[m, ycol0:ycol0+ncols] = x[idx[m], xcol0:xcol0+ncols]; ``idx`` int32 on the device, one entry per row of ``y``."""
+    lib = _lib.load()
+    _rowmajor(x, "X")
+    _rowmajor(y, "Y")
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == y.shape[0] and idx.device == x.device
+    _lib.check(lib.anyv2v_gather_rows_f16(_p(x), x.stride(0), xcol0, _p(idx), _p(y), y.stride(0), ycol0, y.shape[0], ncols,
+                                          _stream()), "anyv2v_gather_rows_f16")
+    return y
+
+
+def rotary(x: torch.Tensor, col0: int, rot_dim: int, rows_per_pos: int, n_pos: int, theta: float = 10000.0):
+    """In-place rotary position embedding of columns [col0, col0+rot_dim) (interleaved pairs); the position of row r is
+    (r // rows_per_pos) % n_pos -- see include/anyv2v_hip.h."""
+    lib = _lib.load()
+    _rowmajor(x, "X")
+    _lib.check(lib.anyv2v_rotary_f16(_p(x), x.stride(0), x.shape[0], col0, rot_dim, rows_per_pos, n_pos, float(theta), _stream()),
+               "anyv2v_rotary_f16")
+    return x
+
+
 def cfg_ddim_step(vtok: torch.Tensor, b_unc: int, b_cond: int, guidance: float, coef: torch.Tensor,
                   lat: torch.Tensor, out: torch.Tensor):
     """lat/out: [1, C, F, H, W] fp16; vtok: [(nb F) HW, ld] channels-last v-prediction; coef: 4 device floats."""

@@ -143,7 +143,7 @@ typedef struct AnyV2VAttnDesc {
 
 int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);
 
-/* Attention for any head_dim <= 128, used once per clip: image_latents_temporal_encoder (2 heads x dim 4) and the CLIP towers of
+/* Attention for any head_dim <= 160, used once per clip (and by the ConsistI2V hook family's temporal attention, head_dim = C / 8): image_latents_temporal_encoder (2 heads x dim 4) and the CLIP towers of
  * encode_prompt / _encode_image (pipeline_i2vgen_xl.py:224-441: text 16 heads x 64 with the causal mask, vision 16 heads x 80).
  * head_dim a multiple of 16 and Sk <= 288: a whole-sequence MFMA kernel (K and V^T of a head in LDS, exact softmax over the
  * score row block in registers); anything else, or flags bit0: one thread per (batch, head, query).  Same addressing as above
@@ -165,6 +165,19 @@ int anyv2v_tokens_to_ncfhw_f16(const void* X, void* Y, int32_t B, int32_t C, int
 /* AdaptiveAvgPool2d over channels-last tokens [N, Hi, Wi, C] -> [N, Ho, Wo, C] */
 int anyv2v_adaptive_avgpool_f16(const void* X, void* Y, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
                                 int32_t C, void* stream);
+/* Row gather with column windows: Y[m, ycol0 : ycol0+C] = X[idx[m], xcol0 : xcol0+C] (idx: int32 on the device; C, ld, col0
+ * multiples of 8).  Builds the key / value sequences of ConsistI2V's first-frame-conditioned attention without a second
+ * projection: spatial attn1 attends over [own frame ; first frame] (videoldm_transformer_blocks.py:479-489), temporal attn1 over
+ * [the pixel's frames ; the 8 neighbours of the pixel in the first frame] (:490-503, videoldm_attention.py:589-599) -- both are
+ * rows of the K / V projections that already exist. */
+int anyv2v_gather_rows_f16(const void* X, int32_t ldx, int32_t xcol0, const int32_t* idx, void* Y, int32_t ldy, int32_t ycol0,
+                           int64_t M, int32_t C, void* stream);
+/* Rotary position embedding in place (consisti2v/consisti2v/models/rotary_embedding.py:29-49,143-163 as called by
+ * RotaryEmbAttnProcessor2_0 / ModifiedTmpAttnProcessor, videoldm_attention.py:773-777, consisti2v/pnp_utils.py:306-310):
+ * columns [col0, col0+rot_dim) of row r, in interleaved pairs (2i, 2i+1), rotated by pos(r) * theta^(-2i/rot_dim) with
+ * pos(r) = (r / rows_per_pos) % n_pos -- for token matrices [(b f)(h w), C]: rows_per_pos = HW, n_pos = F.  fp32 angles. */
+int anyv2v_rotary_f16(void* X, int32_t ld, int64_t rows, int32_t col0, int32_t rot_dim, int32_t rows_per_pos, int32_t n_pos,
+                      float theta, void* stream);
 /* rows copy with column window: Y[m, ycol0 : ycol0+C] = X[m, xcol0 : xcol0+C] */
 int anyv2v_copy_cols_f16(const void* X, int32_t ldx, int32_t xcol0, void* Y, int32_t ldy, int32_t ycol0, int64_t M,
                          int32_t C, void* stream);

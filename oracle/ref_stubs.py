@@ -111,7 +111,7 @@ def load_reference_inverse_scheduler():
     return _load(os.path.join(REFERENCE_ROOT, "consisti2v", "ddim_inverse_scheduler.py"), "_ref_ddim_inverse")
 
 
-def load_reference_consisti2v_models():
+def load_reference_consisti2v_models(attention_base=None, package="_ref_consisti2v_models"):
     """The reference's in-tree restatements of the diffusers building blocks, verbatim:
     ``consisti2v/consisti2v/models/videoldm_attention.py`` (``ConditionalAttention`` -- diffusers' ``Attention`` constructor,
     head reshapes and score arithmetic), ``videoldm_transformer_blocks.py`` (``BasicConditionalTransformerBlock`` /
@@ -149,6 +149,29 @@ def load_reference_consisti2v_models():
             def forward(self, x, scale: float = 1.0):
                 return super().forward(x)
 
+        class ResnetBlock2D(uo.ResnetBlock2D):  # diffusers signature in front of the oracle's block (pinned elsewhere: its body ==
+            # i2vgen-xl/pnp_utils.py:46-126 and == seine/models/resnet.py:113-206 at one frame); LoRA-compatible layers because
+            # consisti2v/pnp_utils.py:40-128 calls conv1(h, scale) / time_emb_proj(temb, scale)
+            def __init__(self, *, in_channels, out_channels, temb_channels, eps=1e-5, groups=32, dropout=0.0,
+                         time_embedding_norm="default", non_linearity="swish", output_scale_factor=1.0, pre_norm=True, **kw):
+                assert time_embedding_norm == "default" and dropout == 0.0
+                super().__init__(in_channels, out_channels, temb_channels, groups, eps)
+                self.conv1 = LoRACompatibleConv(in_channels, out_channels, 3, padding=1)
+                self.conv2 = LoRACompatibleConv(out_channels, out_channels, 3, padding=1)
+                self.time_emb_proj = LoRACompatibleLinear(temb_channels, out_channels)
+                if in_channels != out_channels:
+                    self.conv_shortcut = LoRACompatibleConv(in_channels, out_channels, 1)
+                self.output_scale_factor = output_scale_factor
+
+        class Upsample2D(uo.Upsample2D):
+            def __init__(self, channels, use_conv=True, out_channels=None, **kw):
+                assert use_conv and (out_channels is None or out_channels == channels)
+                super().__init__(channels)
+
+            def forward(self, x, output_size=None, scale=1.0):
+                assert output_size is None
+                return super().forward(x)
+
         class Transformer2DModelOutput:
             def __init__(self, sample):
                 self.sample = sample
@@ -160,7 +183,9 @@ def load_reference_consisti2v_models():
         _mod("diffusers.utils.torch_utils", randn_tensor=None, maybe_allow_in_graph=ident)
         _mod("diffusers.models.lora", LoRACompatibleLinear=LoRACompatibleLinear, LoRACompatibleConv=LoRACompatibleConv,
              LoRALinearLayer=_Dummy)
-        ap = _mod("diffusers.models.attention_processor", AttnProcessor2_0=uo.AttnProcessor2_0, Attention=_Dummy)
+        # ``TemporalConditionalAttention`` subclasses diffusers' ``Attention``; load_reference_consisti2v_decoder() passes the
+        # reference's own in-tree ``ConditionalAttention`` (the same constructor, restated by the reference) as that base
+        ap = _mod("diffusers.models.attention_processor", AttnProcessor2_0=uo.AttnProcessor2_0, Attention=attention_base or _Dummy)
         for n in ("AttnAddedKVProcessor", "AttnAddedKVProcessor2_0", "AttnProcessor", "SpatialNorm", "CustomDiffusionAttnProcessor",
                   "CustomDiffusionXFormersAttnProcessor", "SlicedAttnAddedKVProcessor", "XFormersAttnAddedKVProcessor",
                   "LoRAAttnAddedKVProcessor", "XFormersAttnProcessor", "LoRAXFormersAttnProcessor", "LoRAAttnProcessor",
@@ -173,25 +198,56 @@ def load_reference_consisti2v_models():
         _mod("diffusers.models.modeling_utils", ModelMixin=nn.Module)
         _mod("diffusers.models.transformer_2d", Transformer2DModelOutput=Transformer2DModelOutput)
         _mod("diffusers.models.unet_2d_blocks", DownBlock2D=_Dummy, UpBlock2D=_Dummy)
-        _mod("diffusers.models.resnet", ResnetBlock2D=uo.ResnetBlock2D, Downsample2D=uo.Downsample2D, Upsample2D=uo.Upsample2D)
+        _mod("diffusers.models.resnet", ResnetBlock2D=ResnetBlock2D, Downsample2D=uo.Downsample2D, Upsample2D=Upsample2D)
         _mod("diffusers.models.dual_transformer_2d", DualTransformer2DModel=_Dummy)
         _mod("diffusers.models.activations", get_activation=lambda name: nn.SiLU())
         import typing
         _mod("beartype", beartype=ident)
         _mod("beartype.typing", Literal=typing.Literal, Union=typing.Union, Optional=typing.Optional)
         pkg_dir = os.path.join(REFERENCE_ROOT, "consisti2v", "consisti2v", "models")
-        pkg = types.ModuleType("_ref_consisti2v_models")
+        pkg = types.ModuleType(package)
         pkg.__path__ = [pkg_dir]
-        sys.modules["_ref_consisti2v_models"] = pkg
+        sys.modules[package] = pkg
         import importlib
-        att = importlib.import_module("_ref_consisti2v_models.videoldm_attention")
-        blocks = importlib.import_module("_ref_consisti2v_models.videoldm_transformer_blocks")
-        ublocks = importlib.import_module("_ref_consisti2v_models.videoldm_unet_blocks")
+        att = importlib.import_module(package + ".videoldm_attention")
+        blocks = importlib.import_module(package + ".videoldm_transformer_blocks")
+        ublocks = importlib.import_module(package + ".videoldm_unet_blocks")
     finally:
         for k in set(sys.modules) - before:
             if k.split(".")[0] in ("torchvision", "diffusers", "beartype"):
                 del sys.modules[k]
     return att, blocks, ublocks
+
+
+def load_reference_consisti2v_decoder():
+    """Everything the ConsistI2V hook family touches, from the reference's own files: ``VideoLDMCrossAttnUpBlock``
+    (``consisti2v/consisti2v/models/videoldm_unet_blocks.py:548-745`` -- ResnetBlock2D / TemporalResnetBlock / spatial and temporal
+    ``Transformer2DConditionModel`` per layer), ``TemporalConditionalAttention`` with the rotary embedding
+    (``videoldm_attention.py:552-641``, ``rotary_embedding.py``) and the hook functions of ``consisti2v/pnp_utils.py:19-345``.
+    ``TemporalConditionalAttention`` derives from diffusers' ``Attention`` (not installed): the module is imported a second time
+    with the reference's in-tree ``ConditionalAttention`` of the first import as that base class (the reference's own copy of the
+    same constructor and helpers).  Returns (attention module, transformer-blocks module, unet-blocks module, pnp_utils module)."""
+    att1, _, _ = load_reference_consisti2v_models()
+    att, blocks, ublocks = load_reference_consisti2v_models(attention_base=att1.ConditionalAttention,
+                                                            package="_ref_consisti2v_models_dec")
+    from oracle import unet_oracle as uo
+    before = set(sys.modules)
+    install_stubs()
+    try:
+        _mod("diffusers.models.resnet", Upsample2D=uo.Upsample2D, Downsample2D=uo.Downsample2D)
+        _mod("diffusers.models.attention_processor", AttnProcessor2_0=uo.AttnProcessor2_0, Attention=att.ConditionalAttention)
+        _mod("consisti2v")
+        _mod("consisti2v.models")
+        sys.modules["consisti2v.models.videoldm_attention"] = att
+        spec = importlib.util.spec_from_file_location("_ref_consisti2v_pnp_utils",
+                                                      os.path.join(REFERENCE_ROOT, "consisti2v", "pnp_utils.py"))
+        pnp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pnp)
+    finally:
+        for k in set(sys.modules) - before:
+            if k.split(".")[0] in ("torchvision", "diffusers", "consisti2v"):
+                del sys.modules[k]
+    return att, blocks, ublocks, pnp
 
 
 def load_reference_seine_blocks():

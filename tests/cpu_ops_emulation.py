@@ -197,6 +197,24 @@ def copy_cols(x, xcol0, y, ycol0, ncols):
     return y
 
 
+def gather_rows(x, xcol0, idx, y, ycol0, ncols):
+    y[:, ycol0:ycol0 + ncols] = x[idx.long(), xcol0:xcol0 + ncols]
+    return y
+
+
+def rotary(x, col0, rot_dim, rows_per_pos, n_pos, theta=10000.0):
+    rows = x.shape[0]
+    pos = ((torch.arange(rows) // rows_per_pos) % n_pos).float()
+    freq = theta ** (-torch.arange(0, rot_dim, 2).float() / rot_dim)
+    ang = pos[:, None] * freq[None]
+    cs, sn = ang.cos(), ang.sin()
+    v = x[:, col0:col0 + rot_dim].float()
+    a, b = v[:, 0::2], v[:, 1::2]
+    out = torch.stack([a * cs - b * sn, b * cs + a * sn], -1).reshape(rows, rot_dim)
+    x[:, col0:col0 + rot_dim] = _h(out)
+    return x
+
+
 def cfg_ddim_step(vtok, b_unc, b_cond, guidance, coef, lat, out):
     _, C, Fr, H, W = lat.shape
     n = Fr * H * W
@@ -229,7 +247,7 @@ def install(monkeypatch=None):
     """Replace every function of ``anyv2v_amd.ops`` with the emulation (tests only)."""
     from anyv2v_amd import ops
     names = ["gemm", "groupnorm", "layernorm", "softmax_rows", "attention", "silu", "add", "timestep_embedding", "ncfhw_to_tokens",
-             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "cfg_ddim_step", "ddim_step"]
+             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "gather_rows", "rotary", "cfg_ddim_step", "ddim_step"]
     g = globals()
     for n in names:
         if monkeypatch is not None:

@@ -16,6 +16,7 @@
    inversion -> CFG reconstruction -> PnP edit of one synthetic clip around the oracle UNet (fp32, CPU), the reference's
    vendored inverse scheduler and toy VAE / CLIP components: the conditioning tensors its glue code built, the trajectory it
    wrote, the reconstructed and the edited latents.  The -m gpu suite runs the HIP pipeline on the same inputs against it.
+4. ``consisti2v_decoder_hooks.pt`` (``--consisti2v``): the ConsistI2V hook family -- see ``gen_consisti2v``.
 """
 import os
 import sys
@@ -172,8 +173,41 @@ def gen_ref_pipeline(name):
     print("  |edit_ref| max", float(fx["edit_ref"].float().abs().max()), " inv_ts", fx["inv_ts"])
 
 
+def gen_consisti2v():
+    """``consisti2v_decoder_hooks.pt`` (``--consisti2v``): the reference's own ``VideoLDMCrossAttnUpBlock``
+    (``consisti2v/consisti2v/models/videoldm_unet_blocks.py:548-745``, with everything below it from the reference's files, see
+    ``oracle.ref_stubs.load_reference_consisti2v_decoder``) as stand-ins for ``unet.up_blocks[1..3]``, the reference's own
+    ``consisti2v/pnp_utils.py`` hooks registered on them; outputs un-hooked and hooked at t = 981 (conv + spatial + temporal
+    injection) / 301 (temporal only); t = 101 (no schedule) is checked to equal the un-hooked output and not stored."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import consisti2v_spec as spec
+    att, blocks_mod, ublocks, pnp = ref_stubs.load_reference_consisti2v_decoder()
+    blocks = {i: spec.fill_weights(ublocks.VideoLDMCrossAttnUpBlock(**spec.block_kwargs(i))).eval() for i in spec.BLOCKS}
+
+    def call(blk, x, skips, temb, ehs):
+        with torch.no_grad():
+            return blk(x, skips, temb, encoder_hidden_states=ehs).clone()
+    out = spec.run_cases(blocks, pnp, call)
+    fx = {"spec": dict(B=spec.B, FR=spec.FR, H=spec.H, W=spec.W, weight_seed=spec.WEIGHT_SEED, input_seed=spec.INPUT_SEED, pnp=spec.PNP)}
+    for i in spec.BLOCKS:
+        a, b = out[f"block{i}_nohook"], out[f"block{i}_hook_t101"]
+        assert torch.equal(a, b), "a timestep outside every schedule must leave the block un-hooked"
+        fx[f"block{i}_nohook"] = a
+        for t in spec.TS_CASES:
+            h = out[f"block{i}_hook_t{t}"]
+            fx[f"block{i}_hook_t{t}"] = h
+            third = h.shape[0] // 3
+            print(f"block{i} t={t}: shape {tuple(h.shape)} max {float(h.abs().max()):.3f}  hooked vs un-hooked (branches 1-2) "
+                  f"{float((h[third:] - a[third:]).abs().max() / a.abs().max()):.3f}  source branch unchanged "
+                  f"{bool(torch.equal(h[:third], a[:third]))}")
+    torch.save(fx, os.path.join(HERE, "consisti2v_decoder_hooks.pt"))
+
+
 if __name__ == "__main__":
     assert ref_stubs.reference_available(), "needs /root/reference"
+    if "--consisti2v" in sys.argv:
+        gen_consisti2v()
+        sys.exit(0)
     if "--pipeline" in sys.argv:
         gen_ref_pipeline("mini")
     elif "--pipeline-full" in sys.argv:

@@ -933,6 +933,29 @@ def check_elementwise():
     x0 = 0.8 * xx - 0.6 * v3[2]
     eps = 0.8 * v3[2] + 0.6 * xx
     out.append(_res("ddim step", o2, 0.9 * x0 + float(coef[3]) * eps, 3e-3))
+    # row gather with column windows (ConsistI2V's [own frame ; first frame] / [frames ; first-frame window] key sequences)
+    src = rnd(300, 96)
+    idx = torch.randint(0, 300, (517,), device=DEV, dtype=torch.int32)
+    dst = torch.zeros(517, 80, dtype=torch.float16, device=DEV)
+    ops.gather_rows(src, 32, idx, dst, 16, 64)
+    want = torch.zeros_like(dst)
+    want[:, 16:80] = src[idx.long(), 32:96]
+    out.append(dict(name="gather_rows (column windows)", err=float((dst.float() - want.float()).abs().max()), tol=0.0,
+                    ok=bool(torch.equal(dst, want))))
+    # rotary position embedding in place vs the formula of rotary_embedding.py:29-49 in fp32
+    HW_, F_, C_ = 6, 5, 96
+    xr = rnd(2 * F_ * HW_, C_)
+    got = ops.rotary(xr.clone(), 32, 48, HW_, F_)
+    pos = ((torch.arange(xr.shape[0], device=DEV) // HW_) % F_).float()
+    freq = 10000.0 ** (-torch.arange(0, 48, 2, device=DEV).float() / 48)
+    ang = (pos[:, None] * freq[None]).repeat_interleave(2, dim=1)
+    t = xr[:, 32:80].float()
+    rot = torch.stack([-t[:, 1::2], t[:, 0::2]], -1).reshape(t.shape)
+    want = xr.float().clone()
+    want[:, 32:80] = t * ang.cos() + rot * ang.sin()
+    out.append(_res("rotary (window of columns, frame positions)", got, want, 2e-3))
+    out.append(dict(name="rotary leaves the other columns alone", err=0.0, tol=0.0,
+                    ok=bool(torch.equal(got[:, :32], xr[:, :32]) and torch.equal(got[:, 80:], xr[:, 80:]))))
     return out
 
 
@@ -2024,6 +2047,29 @@ def check_vae(full: bool = True):
         d0 = oracle.decode(z)
         d1 = native.decode(z.to(DEV))
         out.append(_res(f"vae[{name}] decode vs oracle", d1.cpu(), d0, 2e-2))
+    return out
+
+
+def check_consisti2v_hooks():
+    """the ConsistI2V hook family (``anyv2v_amd/consisti2v.py``) on the kernels vs the fixture the REFERENCE's
+    own ``VideoLDMCrossAttnUpBlock`` + ``consisti2v/pnp_utils.py`` produced on the CPU in fp32 (``make_golden.py --consisti2v``):
+    stand-ins for ``unet.up_blocks[1..3]``, un-hooked and with conv + spatial + temporal injection (t = 981) / temporal only (301)."""
+    import consisti2v_spec as spec
+    from anyv2v_amd import consisti2v as c2
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "consisti2v_decoder_hooks.pt"))
+    blocks = {i: spec.fill_weights(c2.VideoLDMCrossAttnUpBlock(**spec.block_kwargs(i))).to(DEV) for i in spec.BLOCKS}
+
+    def call(blk, x, skips, temb, ehs):
+        h = lambda t: t.to(DEV).half()
+        return blk(h(x), tuple(h(s) for s in skips), h(temb), encoder_hidden_states=h(ehs)).float().cpu()
+    got = spec.run_cases(blocks, c2, call)
+    out = []
+    for i in spec.BLOCKS:
+        for case in ["nohook"] + [f"hook_t{t}" for t in spec.TS_CASES]:
+            out.append(_res(f"consisti2v up_blocks[{i}] stand-in, {case} vs the reference's own block + hooks", got[f"block{i}_{case}"],
+                            fx[f"block{i}_{case}"], 4e-3))
+        out.append(dict(name=f"consisti2v up_blocks[{i}]: a timestep outside every schedule == un-hooked (bit-equal)", err=0.0, tol=0.0,
+                        ok=bool(torch.equal(got[f"block{i}_nohook"], got[f"block{i}_hook_t101"]))))
     return out
 
 

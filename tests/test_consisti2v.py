@@ -1,0 +1,88 @@
+"""SURVEY.md 8(f) F4 -- the ConsistI2V hook family (``anyv2v_amd/consisti2v.py``) on the CPU: native decoder blocks through the op
+emulation vs the fixture produced by the REFERENCE's own ``VideoLDMCrossAttnUpBlock`` + ``consisti2v/pnp_utils.py``
+(``tests/golden/make_golden.py --consisti2v``), and -- where /root/reference exists -- the fixture vs the reference run live."""
+import os
+import warnings
+
+import pytest
+import torch
+
+import consisti2v_spec as spec
+import cpu_ops_emulation as emu
+from oracle import ref_stubs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "consisti2v_decoder_hooks.pt")
+
+
+def _native_blocks():
+    from anyv2v_amd import consisti2v as c2
+    return c2, {i: spec.fill_weights(c2.VideoLDMCrossAttnUpBlock(**spec.block_kwargs(i))) for i in spec.BLOCKS}
+
+
+def _native_call(blk, x, skips, temb, ehs):
+    with torch.no_grad():
+        return blk(x.half(), tuple(s.half() for s in skips), temb.half(), encoder_hidden_states=ehs.half()).float()
+
+
+def test_native_consisti2v_decoder_hooks_vs_reference_fixture(monkeypatch):
+    emu.install(monkeypatch)
+    c2, blocks = _native_blocks()
+    fx = torch.load(FIXTURE)
+    out = spec.run_cases(blocks, c2, _native_call)
+    for i in spec.BLOCKS:
+        # a timestep outside every schedule leaves the blocks un-hooked (bit-equal on the native path as well)
+        assert torch.equal(out[f"block{i}_nohook"], out[f"block{i}_hook_t101"])
+        for case in ["nohook"] + [f"hook_t{t}" for t in spec.TS_CASES]:
+            got, ref = out[f"block{i}_{case}"], fx[f"block{i}_{case}"]
+            assert got.shape == ref.shape
+            err = float((got - ref).abs().max() / ref.abs().max())
+            l2 = float((got - ref).norm() / ref.norm())
+            assert err < 4e-3 and l2 < 2e-3, (i, case, err, l2)   # fp16 activations / weights vs the fp32 reference
+        # the hooks do something, and only to the two injected branches
+        third = spec.B * spec.FR // 3
+        a, h = out[f"block{i}_nohook"], out[f"block{i}_hook_t981"]
+        assert torch.equal(a[:third], h[:third])
+        assert float((a[third:] - h[third:]).abs().max() / a.abs().max()) > 0.1
+
+
+def test_hook_registration_targets_match_the_reference_paths():
+    """``consisti2v/pnp_utils.py:20-28,130,228-240,356-362``: which modules get a schedule / a processor / a timestep."""
+    c2, blocks = _native_blocks()
+    model = spec.stub_model(blocks)
+    c2.register_conv_injection(model, [981])
+    c2.register_spatial_attention_pnp(model, torch.tensor([981, 961]))
+    c2.register_temp_attention_pnp(model, [981])
+    c2.register_time(model, torch.tensor(981))
+    up = model.unet.up_blocks
+    assert up[1].resnets[1].injection_schedule == frozenset([981]) and up[1].resnets[1].t == 981
+    assert up[1].resnets[0].injection_schedule is None and up[2].resnets[1].injection_schedule is None
+    for res in (1, 2, 3):
+        for blk in (0, 1, 2):
+            injected = not (res == 1 and blk == 0)    # decoder blocks 4-11: not the first block of the lowest resolution
+            for tree, cls in ((up[res].attentions, c2.HipSpaAttnProcessor), (up[res].tempo_attns, c2.HipTmpAttnProcessor)):
+                proc = tree[blk].transformer_blocks[0].attn1.processor
+                assert isinstance(proc, cls) and proc.t == 981
+                assert (proc.injection_schedule is not None) == injected
+            assert up[res].attentions[blk].transformer_blocks[0].attn2.processor.injection_schedule is None
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_fixture_is_what_the_reference_code_produces_and_keys_match():
+    warnings.filterwarnings("ignore")
+    att, blocks_mod, ublocks, pnp = ref_stubs.load_reference_consisti2v_decoder()
+    ref_blocks = {i: spec.fill_weights(ublocks.VideoLDMCrossAttnUpBlock(**spec.block_kwargs(i))).eval() for i in spec.BLOCKS}
+    c2, nat_blocks = _native_blocks()
+    for i in spec.BLOCKS:   # same module tree: state-dict keys and shapes
+        rs, ns = ref_blocks[i].state_dict(), nat_blocks[i].state_dict()
+        assert sorted(rs.keys()) == sorted(ns.keys())
+        assert all(tuple(rs[k].shape) == tuple(ns[k].shape) for k in rs)
+
+    def call(blk, x, skips, temb, ehs):
+        with torch.no_grad():
+            return blk(x, skips, temb, encoder_hidden_states=ehs)
+    out = spec.run_cases(ref_blocks, pnp, call)
+    fx = torch.load(FIXTURE)
+    for k, v in fx.items():
+        if k != "spec":
+            assert torch.allclose(out[k], v, rtol=1e-5, atol=1e-5 * float(v.abs().max())), k
