@@ -44,11 +44,12 @@ __device__ __forceinline__ float av_silu(float x) { return x / (1.0f + __expf(-x
 // v_rcp / v_exp instructions.  13 VALU ops -- the GEGLU epilogues evaluate it for every element of the [tokens, 4 dim]
 // feed-forward activations and are VALU-issue bound (profiles/r03_gemm_ws_pmc.txt).  The form has no 1 + erf cancellation: over
 // all 63 488 finite fp16 inputs 0.41 % of the fp16-rounded results differ from the correctly rounded exact value, by 1 ulp
-// (the former 0.5 x (1 + erf) arrangement of the same series: 0.72 %, up to 2 ulp; 16 ops) -- tests/test_host_logic.py.
+// (the former 0.5 x (1 + erf) arrangement of the same series: 0.72 %, up to 2 ulp; 16 ops) -- swept on the GPU by
+// tests/gpu_checks.py::check_gelu_all_inputs and, with the constants parsed from this file, on the CPU by tests/test_oracle.py.
 __device__ __forceinline__ float av_gelu(float x) {
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.0f));   // p / sqrt 2
-    float p = fmaf(0.5306027145f, t, -0.7265760135f);                      // the series' coefficients, halved
+    float p = fmaf(0.5307027145f, t, -0.7265760135f);                      // the series' coefficients, halved
     p = fmaf(p, t, 0.7107068705f);
     p = fmaf(p, t, -0.142248368f);
     p = fmaf(p, t, 0.127414796f);

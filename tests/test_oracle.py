@@ -313,3 +313,45 @@ def test_oracle_resnet_samplers_and_timestep_embedding_vs_reference_seine_blocks
     t = torch.tensor([1.0, 21.0, 501.0, 981.0])
     for dim in (320, 1280):
         torch.testing.assert_close(uo.timestep_embedding(t, dim), utl.timestep_embedding(t, dim), rtol=1e-6, atol=1e-6)
+
+
+def test_erf_gelu_series_constants_in_common_h_over_every_fp16_input():
+    """The GEMM epilogues' erf-GELU (``av_gelu``, anyv2v_amd/csrc/common.h) restated in numpy fp32 with the constants PARSED from
+    the header: over all 63 488 finite fp16 inputs the fp16-rounded result is within 1 ulp of the correctly rounded exact GELU
+    (``F.gelu`` default = exact erf, the reference's GEGLU) and differs on < 1 % of them.  (A mistyped series coefficient --
+    0.5306... for 0.5307... -- passed the 2e-3 kernel tolerance for two rounds and failed this sweep: 13.5 % off by one ulp.)"""
+    import math
+    import re
+    import numpy as np
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anyv2v_amd", "csrc", "common.h")).read()
+    body = src[src.index("float av_gelu(float x)"):]
+    body = body[:body.index("return")]
+    num = r"(-?[0-9.]+)f"
+    pt = float(re.search(r"fmaf\(" + num + r", ax, 1\.0f\)", body).group(1))
+    c = [float(v) for v in re.search(r"fmaf\(" + num + r", t, " + num + r"\)", body).groups()]
+    c += [float(v) for v in re.findall(r"fmaf\(p, t, " + num + r"\)", body)]
+    ku = float(re.search(r"x \* " + num, body).group(1))
+    assert len(c) == 5
+    x16 = np.arange(65536, dtype=np.uint16).view(np.float16)
+    x16 = x16[np.isfinite(x16)]
+    x = x16.astype(np.float32)
+    f32 = np.float32
+
+    def fma(a, b, cc):
+        return (a.astype(np.float64) * b.astype(np.float64) + np.float64(cc)).astype(np.float32)
+    ax = np.abs(x)
+    t = (1.0 / fma(np.full_like(x, pt), ax, 1.0).astype(np.float64)).astype(np.float32)
+    p = fma(np.full_like(x, c[0]), t, f32(c[1]))
+    for k in c[2:]:
+        p = fma(p, t, f32(k))
+    u = (x * f32(ku)).astype(np.float32)
+    e = np.exp2(-((u * u).astype(np.float32)).astype(np.float64)).astype(np.float32)
+    q = ((p * t).astype(np.float32) * e).astype(np.float32)
+    y = (-(ax.astype(np.float64)) * q.astype(np.float64) + np.maximum(x, 0).astype(np.float64)).astype(np.float32).astype(np.float16)
+    exact = np.array([(float(v) if v > 0 else 0.0) - 0.5 * abs(float(v)) * math.erfc(abs(float(v)) / math.sqrt(2.0)) for v in x16])
+
+    def key(h):
+        i = h.view(np.int16).astype(np.int32)
+        return np.where(i < 0, -(i & 0x7FFF), i)
+    d = np.abs(key(y) - key(exact.astype(np.float16)))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (int(d.max()), float((d > 0).mean()))
