@@ -47,7 +47,8 @@ class _Ctx:
 
     def __init__(self, B, F, H, W, device, groups):
         self.B, self.F, self.H, self.W = B, F, H, W
-        self.stats = torch.empty(ops.gn_scratch_floats(B * F, 1, groups), dtype=torch.float32, device=device)
+        # (TemporalResnetBlock keeps the reference's default of 32 groups whatever ``resnet_groups`` is, videoldm_unet_blocks.py:231)
+        self.stats = torch.empty(ops.gn_scratch_floats(B * F, 1, max(groups, 32)), dtype=torch.float32, device=device)
         self.temb_all = None
         self.emb = None
         self.context = None   # [B * L, D] text tokens, one copy per batch element
