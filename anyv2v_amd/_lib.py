@@ -59,6 +59,7 @@ SYMBOLS = {
     "anyv2v_layernorm_f16": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _VP]),
     "anyv2v_attention_f16": (C.c_int, [C.POINTER(AttnDesc), _VP]),
     "anyv2v_attention_small_f16": (C.c_int, [C.POINTER(AttnDesc), _I32, _VP]),
+    "anyv2v_attention_bias_f16": (C.c_int, [C.POINTER(AttnDesc), _I32, _VP, _VP]),
     "anyv2v_softmax_rows_f32_f16": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _F32, _VP]),
     "anyv2v_silu_f16": (C.c_int, [_VP, _VP, _I64, _VP]),
     "anyv2v_add_f16": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
@@ -68,7 +69,7 @@ SYMBOLS = {
     "anyv2v_adaptive_avgpool_f16": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "anyv2v_copy_cols_f16": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _I64, _I32, _VP]),
     "anyv2v_gather_rows_f16": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),
-    "anyv2v_rotary_f16": (C.c_int, [_VP, _I32, _I64, _I32, _I32, _I32, _I32, C.c_float, _VP]),
+    "anyv2v_rotary_f16": (C.c_int, [_VP, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "anyv2v_cfg_ddim_step_f16": (C.c_int, [_VP, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "anyv2v_ddim_step_f16": (C.c_int, [_VP, _VP, _VP, _F32, _F32, _F32, _F32, _I64, _VP]),
     "anyv2v_set_batch_hint": (C.c_int, [_I32, _I32]),

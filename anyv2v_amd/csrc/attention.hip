@@ -481,8 +481,9 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Generic reference kernel: one thread per (batch, head, query); any head_dim <= 160, any strides, optional causal mask.
-__global__ void attn_naive_kernel(const AttnK p) {
+// Generic reference kernel: one thread per (batch, head, query); any head_dim <= 160, any strides, optional causal mask, optional
+// additive score bias [heads, Sq, Sk] (fp32, added to the scaled scores: SEINE's time_rel_pos_bias, seine/models/attention.py:887).
+__global__ void attn_naive_kernel(const AttnK p, const float* __restrict__ bias) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)p.batch * p.heads * p.Sq;
     if (idx >= total) return;
@@ -504,10 +505,12 @@ __global__ void attn_naive_kernel(const AttnK p) {
     float m = -1e30f, l = 0.f;
     const float c = p.scale_log2;
     const int kend = p.causal ? (s + 1 < p.Sk ? s + 1 : p.Sk) : p.Sk;
+    const float* brow = bias ? bias + ((long long)h * p.Sq + s) * p.Sk : nullptr;
     for (int k = 0; k < kend; ++k) {
         const half_t* kp = p.K + (kbase + (long long)k * p.kv_seq) * p.ldk + h * D;
         float sc = 0.f;
         for (int d = 0; d < D; ++d) sc += q[d] * (float)kp[d];
+        if (brow) sc += brow[k] * (1.4426950408889634f / c);   // the bias in units of the raw score (c = scale log2 e)
         const float mn = fmaxf(m, sc);
         const float a = exp2f((m - mn) * c);
         const float pv = exp2f((sc - mn) * c);
@@ -663,9 +666,9 @@ static int fill(const AnyV2VAttnDesc* d, AttnK& k, int head_dim) {
     return ANYV2V_OK;
 }
 
-static int launch_naive(const AttnK& k, hipStream_t s) {
+static int launch_naive(const AttnK& k, hipStream_t s, const float* bias = nullptr) {
     const long long total = (long long)k.batch * k.heads * k.Sq;
-    hipLaunchKernelGGL(attn_naive_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, k);
+    hipLaunchKernelGGL(attn_naive_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, k, bias);
     return av_launch_status("attention_naive");
 }
 
@@ -740,4 +743,16 @@ extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_
     }
 #undef AV_SA
     return av_launch_status("small_attn_mfma");
+}
+
+// Attention with an additive score bias (fp32 [heads, Sq, Sk], added to scale * q.k before the softmax): the generic kernel.
+extern "C" int anyv2v_attention_bias_f16(const AnyV2VAttnDesc* d, int32_t head_dim, const float* bias, void* stream) {
+    AV_CHECK(head_dim > 0 && head_dim <= 160, "attention_bias: head_dim must be in 1..160");
+    AV_CHECK(bias != nullptr, "attention_bias: null bias");
+    AV_CHECK(d && d->scale > 0.f, "attention_bias: scale must be positive");
+    AttnK k;
+    int rc = fill(d, k, head_dim);
+    if (rc != ANYV2V_OK) return rc;
+    k.causal = (d->flags & 16) ? 1 : 0;
+    return launch_naive(k, (hipStream_t)stream, bias);
 }

@@ -98,16 +98,17 @@ __global__ void gather_rows_kernel(const half_t* __restrict__ X, int ldx, int xc
 
 // Rotary position embedding, in place: the pair (2 i, 2 i + 1) of columns [col0, col0 + rot_dim) of row r is rotated by the
 // angle pos(r) * theta^(-2 i / rot_dim), pos(r) = (r / rows_per_pos) % n_pos.  One thread per 4 pairs (16 bytes).
-__global__ void rotary_kernel(half_t* __restrict__ X, int ld, long long rows, int col0, int rot_dim, int rows_per_pos,
-                              int n_pos, float log2_theta) {
-    const int C8 = rot_dim >> 3;
-    const long long total = rows * C8;
+__global__ void rotary_kernel(half_t* __restrict__ X, int ld, long long rows, int col0, int rot_dim, int n_win, int win_stride,
+                              int rows_per_pos, int n_pos, float log2_theta) {
+    const int C8 = rot_dim >> 3, W8 = C8 * n_win;
+    const long long total = rows * W8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / C8;
-        const int c = (int)(i - r * C8) * 8;
+        const long long r = i / W8;
+        const int wc = (int)(i - r * W8);
+        const int win = wc / C8, c = (wc - win * C8) * 8;
         const float pos = (float)((r / rows_per_pos) % n_pos);
-        half_t* px = X + r * ld + col0 + c;
+        half_t* px = X + r * ld + col0 + win * win_stride + c;
         h8 v = *(const h8*)px;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -268,13 +269,14 @@ extern "C" int anyv2v_gather_rows_f16(const void* X, int32_t ldx, int32_t xcol0,
     return av_launch_status("gather_rows");
 }
 
-extern "C" int anyv2v_rotary_f16(void* X, int32_t ld, int64_t rows, int32_t col0, int32_t rot_dim, int32_t rows_per_pos,
-                                 int32_t n_pos, float theta, void* stream) {
-    AV_CHECK(X && rows > 0 && rot_dim > 0 && rows_per_pos > 0 && n_pos > 0 && theta > 0.f, "rotary: bad arguments");
-    AV_CHECK(rot_dim % 8 == 0 && ld % 8 == 0 && col0 % 8 == 0 && col0 + rot_dim <= ld && av_aligned16(X),
-             "rotary: the rotated column window must be 16-byte aligned and inside the row");
-    hipLaunchKernelGGL(rotary_kernel, dim3(nblk(rows * (rot_dim / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (half_t*)X, ld, (long long)rows, col0, rot_dim, rows_per_pos, n_pos, log2f(theta));
+extern "C" int anyv2v_rotary_f16(void* X, int32_t ld, int64_t rows, int32_t col0, int32_t rot_dim, int32_t n_windows,
+                                 int32_t window_stride, int32_t rows_per_pos, int32_t n_pos, float theta, void* stream) {
+    AV_CHECK(X && rows > 0 && rot_dim > 0 && n_windows > 0 && rows_per_pos > 0 && n_pos > 0 && theta > 0.f, "rotary: bad arguments");
+    AV_CHECK(rot_dim % 8 == 0 && ld % 8 == 0 && col0 % 8 == 0 && window_stride % 8 == 0 && (n_windows == 1 || window_stride >= rot_dim) &&
+                 col0 + (n_windows - 1) * window_stride + rot_dim <= ld && av_aligned16(X),
+             "rotary: the rotated column windows must be 16-byte aligned, disjoint and inside the row");
+    hipLaunchKernelGGL(rotary_kernel, dim3(nblk(rows * (rot_dim / 8) * n_windows, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)X, ld, (long long)rows, col0, rot_dim, n_windows, window_stride, rows_per_pos, n_pos, log2f(theta));
     return av_launch_status("rotary");
 }
 

@@ -212,9 +212,10 @@ def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = No
 
 
 def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_strides, kv_div=1, qk_mod=0,
-              scale=0.125, head_dim=64, naive=False, causal=False):
+              scale=0.125, head_dim=64, naive=False, causal=False, bias=None):
     """Strided multi-head attention over token matrices; see anyv2v_hip.h for the addressing.  ``causal`` (CLIP text tower)
-    and head_dim != 64 run on the small generic kernel."""
+    and head_dim != 64 run on the small generic kernel; ``bias`` (fp32 [heads, Sq, Sk], added to the scaled scores) on the
+    generic one."""
     lib = _lib.load()
     for t, n in ((q, "Q"), (k, "K"), (v, "V"), (out, "O")):
         _rowmajor(t, n)
@@ -226,7 +227,10 @@ def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_stri
     d.kv_outer, d.kv_inner, d.kv_seq = kv_strides
     d.kv_div, d.qk_mod, d.scale = kv_div, qk_mod, scale
     d.flags = (1 if (naive or FORCE_NAIVE) else 0) | ATTN_FLAGS | (16 if causal else 0)
-    if head_dim == 64 and not causal:
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and tuple(bias.shape) == (heads, Sq, Sk) and bias.device == q.device
+        _lib.check(lib.anyv2v_attention_bias_f16(C.byref(d), head_dim, _p(bias), _stream()), "anyv2v_attention_bias_f16")
+    elif head_dim == 64 and not causal:
         _lib.check(lib.anyv2v_attention_f16(C.byref(d), _stream()), "anyv2v_attention_f16")
     else:
         _lib.check(lib.anyv2v_attention_small_f16(C.byref(d), head_dim, _stream()), "anyv2v_attention_small_f16")
@@ -312,13 +316,14 @@ def gather_rows(x: torch.Tensor, xcol0: int, idx: torch.Tensor, y: torch.Tensor,
     return y
 
 
-def rotary(x: torch.Tensor, col0: int, rot_dim: int, rows_per_pos: int, n_pos: int, theta: float = 10000.0):
-    """In-place rotary position embedding of columns [col0, col0+rot_dim) (interleaved pairs); the position of row r is
-    (r // rows_per_pos) % n_pos -- see include/anyv2v_hip.h."""
+def rotary(x: torch.Tensor, col0: int, rot_dim: int, rows_per_pos: int, n_pos: int, theta: float = 10000.0, windows: int = 1,
+           window_stride: int = 0):
+    """In-place rotary position embedding of columns [col0 + w * window_stride, ... + rot_dim), w < windows (interleaved pairs);
+    the position of row r is (r // rows_per_pos) % n_pos -- see include/anyv2v_hip.h."""
     lib = _lib.load()
     _rowmajor(x, "X")
-    _lib.check(lib.anyv2v_rotary_f16(_p(x), x.stride(0), x.shape[0], col0, rot_dim, rows_per_pos, n_pos, float(theta), _stream()),
-               "anyv2v_rotary_f16")
+    _lib.check(lib.anyv2v_rotary_f16(_p(x), x.stride(0), x.shape[0], col0, rot_dim, windows, window_stride, rows_per_pos, n_pos,
+                                     float(theta), _stream()), "anyv2v_rotary_f16")
     return x
 
 

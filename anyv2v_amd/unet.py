@@ -556,6 +556,9 @@ class ResnetBlock2D(nn.Module):
         self.injection_schedule = None
         self.src_io = None  # source-feature cache, see HipAttnProcessor: ("record" | "replay", buf [Ts, Cout]) of the conv features
         self._temb_col = 0  # column of this block's time_emb_proj inside ctx.temb_all
+        # GroupNorm statistics over (channels of the group, h, w) of every frame -- the 4-D GroupNorm of diffusers' ResnetBlock2D --
+        # or over all frames of a batch element as well (SEINE's ResnetBlock3D normalises [b, c, f, h, w], seine/models/resnet.py:143,177)
+        self.norm_over_frames = False
 
     def forward(self, input_tensor, temb, scale: float = 1.0):
         """torch-style ``ResnetBlock2D.forward(input_tensor[N,Cin,H,W], temb[N,1280])`` (seam B2; the body the reference
@@ -603,11 +606,12 @@ class ResnetBlock2D(nn.Module):
         a0 = x0[:Ts]
         a1 = x1[:Ts] if x1 is not None else None
         g = self.norm1.num_groups
-        h = ops.groupnorm(a0, self.norm1.weight, self.norm1.bias, ctx.stats, HW, x1=a1, groups=g, eps=self.norm1.eps,
+        rpg = ctx.F * HW if self.norm_over_frames else HW
+        h = ops.groupnorm(a0, self.norm1.weight, self.norm1.bias, ctx.stats, rpg, x1=a1, groups=g, eps=self.norm1.eps,
                           silu=True)
         tv = ctx.temb_all[:, self._temb_col:self._temb_col + self.out_channels]
         h = self.conv1.tokens(h, H, W, rowvec=tv, rowvec_div=ctx.F * HW)
-        h = ops.groupnorm(h, self.norm2.weight, self.norm2.bias, ctx.stats, HW, groups=g, eps=self.norm2.eps, silu=True)
+        h = ops.groupnorm(h, self.norm2.weight, self.norm2.bias, ctx.stats, rpg, groups=g, eps=self.norm2.eps, silu=True)
         if self.conv_shortcut is not None:
             res = self.conv_shortcut.tokens(x0, H, W, x1=x1)
         else:

@@ -149,6 +149,10 @@ int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);
  * score row block in registers); anything else, or flags bit0: one thread per (batch, head, query).  Same addressing as above
  * with explicit head_dim; flags bit4 (16): causal mask (key j visible to query s iff j <= s). */
 int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream);
+/* The same with an additive score bias: softmax(scale * Q K^T + bias[head]) V, bias fp32 [heads, Sq, Sk] shared by all batch
+ * elements -- SEINE's TemporalAttention adds a learned relative-position bias to the temporal scores
+ * (seine/models/attention.py:815-817,870-889; seine/pnp_utils.py:386-451 is its hooked form).  Generic kernel, head_dim <= 160. */
+int anyv2v_attention_bias_f16(const AnyV2VAttnDesc* d, int32_t head_dim, const float* bias, void* stream);
 
 /* ---- elementwise / layout --------------------------------------------------------------------- */
 /* y = silu(x) (n elements) */
@@ -174,10 +178,13 @@ int anyv2v_gather_rows_f16(const void* X, int32_t ldx, int32_t xcol0, const int3
                            int64_t M, int32_t C, void* stream);
 /* Rotary position embedding in place (consisti2v/consisti2v/models/rotary_embedding.py:29-49,143-163 as called by
  * RotaryEmbAttnProcessor2_0 / ModifiedTmpAttnProcessor, videoldm_attention.py:773-777, consisti2v/pnp_utils.py:306-310):
- * columns [col0, col0+rot_dim) of row r, in interleaved pairs (2i, 2i+1), rotated by pos(r) * theta^(-2i/rot_dim) with
- * pos(r) = (r / rows_per_pos) % n_pos -- for token matrices [(b f)(h w), C]: rows_per_pos = HW, n_pos = F.  fp32 angles. */
-int anyv2v_rotary_f16(void* X, int32_t ld, int64_t rows, int32_t col0, int32_t rot_dim, int32_t rows_per_pos, int32_t n_pos,
-                      float theta, void* stream);
+ * columns [col0 + w * window_stride, ... + rot_dim) of row r for w < n_windows, in interleaved pairs (2i, 2i+1), rotated by
+ * pos(r) * theta^(-2i/rot_dim) with pos(r) = (r / rows_per_pos) % n_pos -- for token matrices [(b f)(h w), C]: rows_per_pos = HW,
+ * n_pos = F.  ConsistI2V rotates ONE window (the first half of the channels, before the head split); SEINE rotates the first 32
+ * channels of EVERY head (seine/models/attention.py:880-882, RotaryEmbedding(32) on [b, heads, f, d]): n_windows = heads,
+ * window_stride = head_dim.  fp32 angles. */
+int anyv2v_rotary_f16(void* X, int32_t ld, int64_t rows, int32_t col0, int32_t rot_dim, int32_t n_windows, int32_t window_stride,
+                      int32_t rows_per_pos, int32_t n_pos, float theta, void* stream);
 /* rows copy with column window: Y[m, ycol0 : ycol0+C] = X[m, xcol0 : xcol0+C] */
 int anyv2v_copy_cols_f16(const void* X, int32_t ldx, int32_t xcol0, void* Y, int32_t ldy, int32_t ycol0, int64_t M,
                          int32_t C, void* stream);

@@ -257,3 +257,52 @@ def load_reference_seine_blocks():
     res = _load(os.path.join(REFERENCE_ROOT, "seine", "models", "resnet.py"), "_ref_seine_resnet")
     utl = _load(os.path.join(REFERENCE_ROOT, "seine", "models", "utils.py"), "_ref_seine_utils")
     return res, utl
+
+
+def load_reference_seine_decoder():
+    """Everything SEINE's hook family touches, from the reference's own files: ``CrossAttnUpBlock3D``
+    (``seine/models/unet_blocks.py:444-575``: ``ResnetBlock3D`` + ``Transformer3DModel`` per layer, ``Upsample3D``), the attention
+    classes of ``seine/models/attention.py`` (``CrossAttention``, ``TemporalAttention`` with ``RelativePositionBias`` and the rotary
+    embedding, ``BasicTransformerBlock``, ``Transformer3DModel``) and the hook functions of ``seine/pnp_utils.py:121-458``.
+    ``rotary_embedding_torch`` (not installed) is the library the reference vendors as
+    ``consisti2v/consisti2v/models/rotary_embedding.py`` -- that file is imported in its place; diffusers' ``FeedForward`` is the
+    oracle's (unpinned, as everywhere).  Returns (attention module, unet_blocks module, resnet module, pnp_utils module,
+    RotaryEmbedding class)."""
+    import importlib
+    import torch
+    from torch import nn
+    from oracle import unet_oracle as uo
+    att_c2, _, _ = load_reference_consisti2v_models()
+    rotary_mod = sys.modules[att_c2.__name__.rsplit(".", 1)[0] + ".rotary_embedding"]
+    before = set(sys.modules)
+    install_stubs()
+    try:
+        class FeedForward(uo.FeedForward):
+            def __init__(self, dim, dropout=0.0, activation_fn="geglu", **kw):
+                super().__init__(dim, None, activation_fn)
+
+        class _Dummy(nn.Module):
+            def __init__(self, *a, **kw):
+                super().__init__()
+
+        _mod("diffusers.utils", BaseOutput=object, deprecate=lambda *a, **k: None)
+        _mod("diffusers.utils.import_utils", is_xformers_available=lambda: False)
+        _mod("diffusers.models.attention", FeedForward=FeedForward, AdaLayerNorm=_Dummy)
+        _mod("diffusers.models.modeling_utils", ModelMixin=nn.Module)
+        _mod("rotary_embedding_torch", RotaryEmbedding=rotary_mod.RotaryEmbedding)
+        pkg = types.ModuleType("_ref_seine_models")
+        pkg.__path__ = [os.path.join(REFERENCE_ROOT, "seine", "models")]
+        sys.modules["_ref_seine_models"] = pkg
+        path0 = list(sys.path)
+        att = importlib.import_module("_ref_seine_models.attention")
+        res = importlib.import_module("_ref_seine_models.resnet")
+        ublocks = importlib.import_module("_ref_seine_models.unet_blocks")
+        spec = importlib.util.spec_from_file_location("_ref_seine_pnp_utils", os.path.join(REFERENCE_ROOT, "seine", "pnp_utils.py"))
+        pnp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pnp)
+        sys.path[:] = path0   # (the reference files append their parent directory to sys.path)
+    finally:
+        for k in set(sys.modules) - before:
+            if k.split(".")[0] in ("torchvision", "diffusers", "rotary_embedding_torch"):
+                del sys.modules[k]
+    return att, ublocks, res, pnp, rotary_mod.RotaryEmbedding

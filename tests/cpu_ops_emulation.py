@@ -130,7 +130,7 @@ def softmax_rows(s, scale, out=None):
 
 
 def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_strides, kv_div=1, qk_mod=0, scale=0.125,
-              head_dim=64, naive=False, causal=False):
+              head_dim=64, naive=False, causal=False, bias=None):
     i = torch.arange(batch)
     iq = i % qk_mod if qk_mod > 0 else i
 
@@ -144,7 +144,11 @@ def attention(q, k, v, out, *, batch, heads, Sq, Sk, inner=1, q_strides, kv_stri
     Q = q.float()[rq].view(batch, Sq, heads, D).transpose(1, 2)
     K = k.float()[rk].view(batch, Sk, heads, D).transpose(1, 2)
     V = v.float()[rv].view(batch, Sk, heads, D).transpose(1, 2)
-    O = F.scaled_dot_product_attention(Q, K, V, scale=scale, is_causal=bool(causal)).transpose(1, 2).reshape(batch, Sq, heads * D)
+    if bias is not None:
+        O = F.scaled_dot_product_attention(Q, K, V, attn_mask=bias.float()[None], scale=scale)
+    else:
+        O = F.scaled_dot_product_attention(Q, K, V, scale=scale, is_causal=bool(causal))
+    O = O.transpose(1, 2).reshape(batch, Sq, heads * D)
     out[ro.reshape(-1)] = _h(O.reshape(batch * Sq, heads * D))
     return out
 
@@ -202,16 +206,18 @@ def gather_rows(x, xcol0, idx, y, ycol0, ncols):
     return y
 
 
-def rotary(x, col0, rot_dim, rows_per_pos, n_pos, theta=10000.0):
+def rotary(x, col0, rot_dim, rows_per_pos, n_pos, theta=10000.0, windows=1, window_stride=0):
     rows = x.shape[0]
     pos = ((torch.arange(rows) // rows_per_pos) % n_pos).float()
     freq = theta ** (-torch.arange(0, rot_dim, 2).float() / rot_dim)
     ang = pos[:, None] * freq[None]
     cs, sn = ang.cos(), ang.sin()
-    v = x[:, col0:col0 + rot_dim].float()
-    a, b = v[:, 0::2], v[:, 1::2]
-    out = torch.stack([a * cs - b * sn, b * cs + a * sn], -1).reshape(rows, rot_dim)
-    x[:, col0:col0 + rot_dim] = _h(out)
+    for w in range(windows):
+        c = col0 + w * window_stride
+        v = x[:, c:c + rot_dim].float()
+        a, b = v[:, 0::2], v[:, 1::2]
+        out = torch.stack([a * cs - b * sn, b * cs + a * sn], -1).reshape(rows, rot_dim)
+        x[:, c:c + rot_dim] = _h(out)
     return x
 
 

@@ -16,7 +16,8 @@
    inversion -> CFG reconstruction -> PnP edit of one synthetic clip around the oracle UNet (fp32, CPU), the reference's
    vendored inverse scheduler and toy VAE / CLIP components: the conditioning tensors its glue code built, the trajectory it
    wrote, the reconstructed and the edited latents.  The -m gpu suite runs the HIP pipeline on the same inputs against it.
-4. ``consisti2v_decoder_hooks.pt`` (``--consisti2v``): the ConsistI2V hook family -- see ``gen_consisti2v``.
+4. ``consisti2v_decoder_hooks.pt`` (``--consisti2v``) / ``seine_decoder_hooks.pt`` (``--seine``): the sibling hook families -- see
+   ``gen_consisti2v`` / ``gen_seine``.
 """
 import os
 import sys
@@ -203,8 +204,43 @@ def gen_consisti2v():
     torch.save(fx, os.path.join(HERE, "consisti2v_decoder_hooks.pt"))
 
 
+def gen_seine():
+    """``seine_decoder_hooks.pt`` (``--seine``): the reference's own ``CrossAttnUpBlock3D`` (``seine/models/unet_blocks.py:444-575``
+    with ``seine/models/attention.py`` / ``resnet.py`` below it, ``oracle.ref_stubs.load_reference_seine_decoder``) as stand-ins
+    for ``unet.up_blocks[1..3]``, the reference's own ``seine/pnp_utils.py`` hooks (conv, spatial, CROSS and temporal attention)
+    registered on them; outputs un-hooked and hooked at t = 981 (all four) / 501 (cross + temporal) / 301 (temporal only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import seine_spec as spec
+    att, ublocks, res, pnp, Rotary = ref_stubs.load_reference_seine_decoder()
+    rot = Rotary(32)   # seine/models/unet.py:185: ONE embedding object shared by every block
+    blocks = {i: spec.fill_weights(ublocks.CrossAttnUpBlock3D(rotary_emb=rot, **spec.block_kwargs(i)), spec.WEIGHT_SEED).eval()
+              for i in spec.BLOCKS}
+
+    def call(blk, x, skips, temb, ehs):
+        with torch.no_grad():
+            return blk(x, skips, temb, encoder_hidden_states=ehs, use_image_num=0).clone()
+    out = spec.run_cases(blocks, pnp, call)
+    fx = {"spec": dict(B=spec.B, FR=spec.FR, H=spec.H, W=spec.W, weight_seed=spec.WEIGHT_SEED, input_seed=spec.INPUT_SEED, pnp=spec.PNP)}
+    for i in spec.BLOCKS:
+        a = out[f"block{i}_nohook"]
+        assert torch.equal(a, out[f"block{i}_hook_t101"]), "a timestep outside every schedule must leave the block un-hooked"
+        fx[f"block{i}_nohook"] = a
+        prev = a
+        for t in reversed(spec.TS_CASES):
+            h = out[f"block{i}_hook_t{t}"]
+            fx[f"block{i}_hook_t{t}"] = h
+            print(f"block{i} t={t}: shape {tuple(h.shape)} max {float(h.abs().max()):.3f}  vs un-hooked (branches 1-2) "
+                  f"{float((h[1:] - a[1:]).abs().max() / a.abs().max()):.3f}  vs the previous case "
+                  f"{float((h[1:] - prev[1:]).abs().max() / a.abs().max()):.3f}  source branch unchanged {bool(torch.equal(h[:1], a[:1]))}")
+            prev = h
+    torch.save(fx, os.path.join(HERE, "seine_decoder_hooks.pt"))
+
+
 if __name__ == "__main__":
     assert ref_stubs.reference_available(), "needs /root/reference"
+    if "--seine" in sys.argv:
+        gen_seine()
+        sys.exit(0)
     if "--consisti2v" in sys.argv:
         gen_consisti2v()
         sys.exit(0)

@@ -2073,8 +2073,65 @@ def check_consisti2v_hooks():
     return out
 
 
+def check_seine_hooks():
+    """the SEINE hook family (``anyv2v_amd/seine.py``) on the kernels vs the fixture the REFERENCE's own
+    ``CrossAttnUpBlock3D`` + ``seine/pnp_utils.py`` produced on the CPU in fp32 (``make_golden.py --seine``): un-hooked, and with
+    conv + spatial + cross + temporal injection (t = 981) / cross + temporal (501) / temporal only (301)."""
+    import seine_spec as spec
+    from anyv2v_amd import seine as sn
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "seine_decoder_hooks.pt"))
+    blocks = {i: spec.fill_weights(sn.CrossAttnUpBlock3D(**spec.block_kwargs(i)), spec.WEIGHT_SEED).to(DEV) for i in spec.BLOCKS}
+
+    def call(blk, x, skips, temb, ehs):
+        h = lambda t: t.to(DEV).half()
+        return blk(h(x), tuple(h(s) for s in skips), h(temb), encoder_hidden_states=h(ehs)).float().cpu()
+    got = spec.run_cases(blocks, sn, call)
+    out = []
+    for i in spec.BLOCKS:
+        for case in ["nohook"] + [f"hook_t{t}" for t in spec.TS_CASES]:
+            out.append(_res(f"seine up_blocks[{i}] stand-in, {case} vs the reference's own block + hooks", got[f"block{i}_{case}"],
+                            fx[f"block{i}_{case}"], 4e-3))
+        out.append(dict(name=f"seine up_blocks[{i}]: a timestep outside every schedule == un-hooked (bit-equal)", err=0.0, tol=0.0,
+                        ok=bool(torch.equal(got[f"block{i}_nohook"], got[f"block{i}_hook_t101"]))))
+    return out
+
+
+def check_attention_bias_and_rotary_windows():
+    """``anyv2v_attention_bias_f16`` (additive score bias [heads, Sq, Sk], frame-strided sequences, qk_mod aliasing) and
+    ``anyv2v_rotary_f16`` with one window per head vs PyTorch fp32."""
+    out = []
+    B, Fr, HW, heads, D = 3, 6, 10, 3, 40
+    C = heads * D
+    qkv = rnd(B * Fr * HW, 3 * C)
+    bias = torch.randn(heads, Fr, Fr, device=DEV)
+    o = torch.zeros(B * Fr * HW, C, dtype=torch.float16, device=DEV)
+    for qk_mod in (0, B * HW // 3):
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=B * HW, heads=heads, Sq=Fr, Sk=Fr, inner=HW,
+                      q_strides=(Fr * HW, 1, HW), kv_strides=(Fr * HW, 1, HW), qk_mod=qk_mod, scale=D ** -0.5, head_dim=D, bias=bias)
+        x = qkv.float().view(B, Fr, HW, 3, heads, D).permute(3, 0, 2, 4, 1, 5)      # [3][B, HW, heads, F, D]
+        q, k, v = x[0], x[1], x[2]
+        if qk_mod:
+            q, k = q[:1].expand_as(q), k[:1].expand_as(k)
+        ref = F.scaled_dot_product_attention(q, k, v, attn_mask=bias[None, None], scale=D ** -0.5)   # [B, HW, heads, F, D]
+        ref = ref.permute(0, 3, 1, 2, 4).reshape(B * Fr * HW, C)
+        out.append(_res(f"attention + score bias, temporal view, qk_mod {qk_mod}", o, ref, KTOL))
+    xr = rnd(2 * Fr * HW, C + 16)
+    got = ops.rotary(xr.clone(), 8, 32, HW, Fr, windows=heads, window_stride=D)
+    pos = ((torch.arange(xr.shape[0], device=DEV) // HW) % Fr).float()
+    freq = 10000.0 ** (-torch.arange(0, 32, 2, device=DEV).float() / 32)
+    ang = (pos[:, None] * freq[None]).repeat_interleave(2, dim=1)
+    want = xr.float().clone()
+    for hh in range(heads):
+        c0 = 8 + hh * D
+        t = xr[:, c0:c0 + 32].float()
+        rot = torch.stack([-t[:, 1::2], t[:, 0::2]], -1).reshape(t.shape)
+        want[:, c0:c0 + 32] = t * ang.cos() + rot * ang.sin()
+    out.append(_res("rotary, one 32-channel window per head", got, want, 2e-3))
+    return out
+
+
 ALL_KERNEL_CHECKS = [check_selftest, check_gemm, check_gemm_big, check_gemm_ws, check_gemm_ws_ln, check_gemm_splitk, check_conv, check_norms, check_attention,
-                     check_attention_small_mfma, check_gelu_all_inputs, check_elementwise,
+                     check_attention_small_mfma, check_attention_bias_and_rotary_windows, check_gelu_all_inputs, check_elementwise,
                      check_full_size_properties, check_vae_kernels]
 
 
