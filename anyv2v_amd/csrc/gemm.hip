@@ -562,8 +562,12 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
 #undef AV_RB
 }
 
-template <int MF, bool GEGLU, int MODE, bool TRACE = false, bool SPLIT = false>
+// RES: the launch adds a residual (p.R != nullptr).  A separate instantiation: its epilogue holds the residual rows of the whole
+// wave tile in registers (requested right after the K loop, so that they land under the settle wait and the barrier that follow,
+// and the epilogue itself issues no load at all -- a load there makes hipcc wait for the stores of the slabs before it).
+template <int MF, bool GEGLU, int MODE, bool TRACE = false, bool SPLIT = false, bool RES = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
+    static_assert(!(RES && (GEGLU || SPLIT)), "no residual on GEGLU / split-K launches");
     constexpr int BM = 64 * MF, BN = 320;  // four wave rows of MF 16-row fragments
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int SLAB_LD = (GEGLU ? 80 : 160) + 8;          // halves; 16-byte aligned rows
@@ -664,6 +668,25 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
         }
         if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G) p.trace[(size_t)blockIdx.x * 32 + 26] = (long long)__builtin_amdgcn_s_memtime();
         // `stage` now names the buffer holding the prefetched K-tile 0 of the next tile; stage ^ 1 was just consumed
+        constexpr int OUT_W = GEGLU ? 80 : 160;       // output columns of this wave
+        constexpr int CPRW = OUT_W / 8;               // 16-byte chunks per slab row
+        constexpr int NIT = (16 * CPRW + 63) / 64;    // store iterations per slab (5, or 3 with a half-empty last one)
+        const int n_out_wave = GEGLU ? n_wave / 2 : n_wave;
+        h8 rr[RES ? MF : 1][NIT];
+        if constexpr (RES) {   // all residual rows of the wave tile (rows past M: clamped, never stored)
+            int lane_r = lane;
+            asm volatile("" : "+v"(lane_r));   // (not hoisted out of the tile loop: see lane_e below)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int c = it * 64 + lane_r;
+                    const int row = c / CPRW, cc = c - row * CPRW;
+                    int m = m_wave + mf * 16 + row;
+                    m = m < p.M ? m : p.M - 1;
+                    rr[mf][it] = *(const h8*)(p.R + (size_t)m * p.ldr + n_out_wave + cc * 8);
+                }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // settle the prefetch BEFORE the stores below enter the queue
         if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G) p.trace[(size_t)blockIdx.x * 32 + 30] = (long long)__builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();                     // every wave is done reading the consumed stage
@@ -695,33 +718,21 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
         }
         if constexpr (SPLIT) __builtin_unreachable();
         half_t* const slab = (half_t*)(smem + (stage ^ 1) * STAGE_BYTES + w * SLAB_BYTES);
-        constexpr int OUT_W = GEGLU ? 80 : 160;       // output columns of this wave
-        constexpr int CPRW = OUT_W / 8;               // 16-byte chunks per slab row
-        constexpr int NIT = (16 * CPRW + 63) / 64;    // store iterations per slab (5, or 3 with a half-empty last one)
-        const int n_out_wave = GEGLU ? n_wave / 2 : n_wave;
         // (dispatch guarantees N % 320 == 0 and act in {none, GEGLU}; rows are guarded: M need not be a multiple of BM)
         h4 bvec[10];
 #pragma unroll
         for (int nf = 0; nf < 10; ++nf)
             bvec[nf] = *(const h4*)(p.bias != nullptr ? p.bias + n_wave + nf * 16 + 4 * lq : p.zeros);
-        const bool has_res = p.R != nullptr;
-        h8 rr[2][NIT];
-        auto res_load = [&](int mf, h8 (&dst)[NIT]) {
+        if constexpr (RES) {   // they landed under the settle wait above; tell the compiler so ONCE, before the first store
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = it * 64 + lane_e;
-                const int row = c / CPRW, cc = c - row * CPRW;
-                const bool ok = (16 * CPRW % 64 == 0 || c < 16 * CPRW) && m_wave + mf * 16 + row < p.M;
-                dst[it] = *(const h8*)(ok ? p.R + (size_t)(m_wave + mf * 16 + row) * p.ldr + n_out_wave + cc * 8 : p.zeros);
-            }
-        };
-        if (has_res) res_load(0, rr[0]);
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rr[mf][it]));
+        }
         // per 16-row slab: (+bias, +temb row vector | GEGLU) -> fp16 -> LDS (turns lane-owns-4-channels into
-        // row-contiguous 16-byte chunks) -> (+residual) -> store.  The residual of slab mf+1 is requested before slab
-        // mf's round trip; the accumulators of finished slabs free the registers for it.
+        // row-contiguous 16-byte chunks) -> (+residual) -> store.
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-            if (has_res && mf + 1 < MF) res_load(mf + 1, rr[(mf + 1) & 1]);
             if constexpr (GEGLU) {
 #pragma unroll
                 for (int np = 0; np < 5; ++np) {
@@ -756,9 +767,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
                 const int row = c / CPRW, cc = c - row * CPRW;
                 const bool ok = (16 * CPRW % 64 == 0 || c < 16 * CPRW) && m_wave + mf * 16 + row < p.M;
                 h8 v = *(const h8*)(slab + (ok ? row * SLAB_LD + cc * 8 : 0));
-                if (has_res) {
-                    v = v + rr[mf & 1][it];  // fp16 add: correctly rounded, == the fp32 add + rounding of two fp16 values
-                }
+                if constexpr (RES) v = v + rr[mf][it];  // fp16 add: correctly rounded, == the fp32 add + rounding of two fp16 values
                 if (ok) *(h8*)(p.C + (size_t)(m_wave + mf * 16 + row) * p.ldc + n_out_wave + cc * 8) = v;
             }
         }
@@ -964,8 +973,12 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         if constexpr (MODE == MODE_LINEAR) {
             if (geglu)
                 hipLaunchKernelGGL((gemm_big_kernel<3, true, MODE_LINEAR>), grid, dim3(512), 0, s, k);
+            else if (d->R != nullptr)
+                hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR, false, false, true>), grid, dim3(512), 0, s, k);
             else
                 hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE_LINEAR>), grid, dim3(512), 0, s, k);
+        } else if (d->R != nullptr) {
+            hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE, false, false, true>), grid, dim3(512), 0, s, k);
         } else {
             hipLaunchKernelGGL((gemm_big_kernel<3, false, MODE>), grid, dim3(512), 0, s, k);
         }
