@@ -181,6 +181,25 @@ struct GnPlan {
     long long bps;
 };
 
+template <int U>
+__global__ void gn_apply_kernel(const half_t*, const half_t*, int, int, half_t*, const half_t*, const half_t*, const float*, int, float,
+                                float, int, int, int, int, int);
+
+// resident gn_apply blocks on the whole device for a block size (occupancy query, cached per size)
+static int gn_apply_slots(int threads) {
+    static int cache[1025];
+    if (threads < 1 || threads > 1024) return 2048;
+    if (cache[threads] == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_apply_kernel<4>, threads, 0) != hipSuccess || per_cu < 1) per_cu = 7;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            cus = 256;
+        cache[threads] = per_cu * cus;
+    }
+    return cache[threads];
+}
+
 static int gn_plan(GnPlan& pl, const void* X0, const void* X1, int32_t C0, int32_t C1, int32_t M, int32_t rows_per_group,
                    int32_t G) {
     AV_CHECK(C0 > 0 && C1 >= 0 && (C1 == 0 || X1), "groupnorm: bad C0/C1");
@@ -209,10 +228,13 @@ static int gn_plan(GnPlan& pl, const void* X0, const void* X1, int32_t C0, int32
     pl.nchunks = (rows_per_group + pl.rows_chunk - 1) / pl.rows_chunk;
     pl.lds = (size_t)pl.rpb * C * 2 * sizeof(float);
     AV_CHECK(pl.lds <= 64 * 1024, "groupnorm: LDS reduction buffer too large");
-    // ~2048 apply blocks in total, each at least 8 row-iterations per thread where the stat group is large enough
+    // Apply blocks: as many as the chip holds at once (CUs x resident blocks of this size), not more -- 2064 blocks on 1792 slots
+    // ran a second, 15 %-full round (the 64x64-level launches, profiles/r03_bench_kernel_summary.md); each block at least 8
+    // row-iterations per thread where the stat group is large enough.  (The partition has no effect on the result.)
     const long long vec_sg = (long long)rows_per_group * pl.V;
     AV_CHECK(vec_sg < (1ll << 31), "groupnorm: stat group too large (%lld vectors)", vec_sg);
-    pl.bps = (2048 + pl.nsg - 1) / pl.nsg;
+    const int slots = gn_apply_slots(pl.threads);
+    pl.bps = slots / pl.nsg;
     const long long max_bps = (rows_per_group + pl.rpb * 8 - 1) / (pl.rpb * 8);
     if (pl.bps > max_bps) pl.bps = max_bps;
     if (pl.bps < 1) pl.bps = 1;
