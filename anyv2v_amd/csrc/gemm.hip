@@ -901,7 +901,16 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         return av_launch_status("gemm_naive");
     }
     const bool glds = (d->flags & 2) != 0;
-    const int nf = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
+    // 128-row kernel tile width: 160 columns (NF = 5) where N allows it, except where 128-column tiles (NF = 4) quantise better onto
+    // the 256 CUs x 2 resident blocks -- more CUs busy when there is less than one tile per CU, or the same number of rounds with
+    // 20 % smaller tiles (flags bit11 / bit12 force NF = 4 / 5: A/B in tools/gemm_nf_ab.py).  Same arithmetic per output either way.
+    int nf = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
+    if (!geglu && nf == 5 && d->N % 128 == 0) {
+        const int mt = (av_hint_rows(d->M) + 127) / 128;
+        const int t5 = mt * (d->N / 160), t4 = mt * (d->N / 128);
+        const bool prefer4 = (t4 <= 256) || (t5 > 256 && (t5 + 511) / 512 == (t4 + 511) / 512);
+        if (((d->flags & 2048) || prefer4) && !(d->flags & 4096)) nf = 4;
+    }
     const int tilesN_small = (d->N + nf * 32 - 1) / (nf * 32);
     const int nk_all = k.taps * (k.nt0 + k.nt1);
     constexpr int BMB = 192;

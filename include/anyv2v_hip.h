@@ -65,7 +65,8 @@ typedef struct AnyV2VGemmDesc {
                             persistent 192x320 kernel (nor the weight-stationary one); bit3: always use it when the shape
                             allows; bit4: no split-K; bit9 (512): never use the weight-stationary K = 320 kernel; bit10 (1024):
                             use it whenever the shape allows (mode 0, C0 = 320 with N % 160 = 0 or C0 = 512 with N % 64 = 0 (GEGLU: 128), C1 = 0, act 0 | 3, no rowvec), also
-                            below its M >= 32768 threshold.  All other bits are ignored by the product library. */
+                            below its M >= 32768 threshold; bit11 (2048) / bit12 (4096): 128-column / 160-column tiles in the
+                            128-row kernel regardless of the fill heuristic.  All other bits are ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
     /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock.norm1/2/3 -> attn.to_q/k/v / ff.net[0].proj,
