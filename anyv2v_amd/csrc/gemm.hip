@@ -908,7 +908,11 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     if (!geglu && nf == 5 && d->N % 128 == 0) {
         const int mt = (av_hint_rows(d->M) + 127) / 128;
         const int t5 = mt * (d->N / 160), t4 = mt * (d->N / 128);
-        const bool prefer4 = (t4 <= 256) || (t5 > 256 && (t5 + 511) / 512 == (t4 + 511) / 512);
+        // (not where the launch would be split along K: the split factor is derived from the tile count, and 7 x 80 tiles spill into
+        //  a second round where 7 x 64 do not -- B = 1 8x8-level convolutions: 45 -> 59 us, profiles/r03_gemm_nf_ab.txt)
+        const int nk = k.taps * (k.nt0 + k.nt1);
+        const bool would_split = t4 < 384 && ((t4 <= 128 && nk >= 32) || nk >= 72);
+        const bool prefer4 = !would_split && ((t4 <= 256) || (t5 > 256 && (t5 + 511) / 512 == (t4 + 511) / 512));
         if (((d->flags & 2048) || prefer4) && !(d->flags & 4096)) nf = 4;
     }
     const int tilesN_small = (d->N + nf * 32 - 1) / (nf * 32);
