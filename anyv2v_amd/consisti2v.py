@@ -29,14 +29,14 @@ Performance is not tuned for this family (temporal attention at head_dim C / 8 r
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List
 
 import torch
 from torch import nn
 
 from . import ops
-from .ops import ACT_NONE, MODE_TEMPORAL
-from .unet import (Conv2d, Conv3dTemporal, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU, Upsample2D, _param,
+from .ops import MODE_TEMPORAL
+from .unet import (Conv2d, Conv3dTemporal, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU, Upsample2D,
                    pnp_on)
 
 ROTARY_THETA = 10000.0  # rotary_embedding.py:76 (freqs_for="lang")
