@@ -904,19 +904,25 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     // 128-row kernel tile width: 160 columns (NF = 5) where N allows it, except where 128-column tiles (NF = 4) quantise better onto
     // the 256 CUs x 2 resident blocks -- more CUs busy when there is less than one tile per CU, or the same number of rounds with
     // 20 % smaller tiles (flags bit11 / bit12 force NF = 4 / 5: A/B in tools/gemm_nf_ab.py).  Same arithmetic per output either way.
-    int nf = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
-    if (!geglu && nf == 5 && d->N % 128 == 0) {
-        const int mt = (av_hint_rows(d->M) + 127) / 128;
-        const int t5 = mt * (d->N / 160), t4 = mt * (d->N / 128);
-        // (not where the launch would be split along K: the split factor is derived from the tile count, and 7 x 80 tiles spill into
-        //  a second round where 7 x 64 do not -- B = 1 8x8-level convolutions: 45 -> 59 us, profiles/r03_gemm_nf_ab.txt)
-        const int nk = k.taps * (k.nt0 + k.nt1);
-        const bool would_split = t4 < 384 && ((t4 <= 128 && nk >= 32) || nk >= 72);
-        const bool prefer4 = !would_split && ((t4 <= 256) || (t5 > 256 && (t5 + 511) / 512 == (t4 + 511) / 512));
-        if (((d->flags & 2048) || prefer4) && !(d->flags & 4096)) nf = 4;
-    }
-    const int tilesN_small = (d->N + nf * 32 - 1) / (nf * 32);
+    // The width does not touch the arithmetic, so a launch picks it on its OWN rows; the split-K factor of a batch-hinted launch is
+    // the reference launch's, i.e. planned with the width the reference launch picks (nf_ref below).
     const int nk_all = k.taps * (k.nt0 + k.nt1);
+    auto choose_nf = [&](int rows) -> int {
+        int nf_ = geglu ? 4 : (d->N % 160 == 0 ? 5 : 4);
+        if (!geglu && nf_ == 5 && d->N % 128 == 0) {
+            const int mt = (rows + 127) / 128;
+            const int t5 = mt * (d->N / 160), t4 = mt * (d->N / 128);
+            // (not where the launch would be split along K: the split factor is derived from the tile count, and 7 x 80 tiles spill
+            //  into a second round where 7 x 64 do not -- B = 1 8x8-level convolutions: 45 -> 59 us, profiles/r03_gemm_nf_ab.txt)
+            const bool would_split = t4 < 384 && ((t4 <= 128 && nk_all >= 32) || nk_all >= 72);
+            const bool prefer4 = !would_split && ((t4 <= 256) || (t5 > 256 && (t5 + 511) / 512 == (t4 + 511) / 512));
+            if (((d->flags & 2048) || prefer4) && !(d->flags & 4096)) nf_ = 4;
+        }
+        return nf_;
+    };
+    const int nf = choose_nf(d->M);
+    const int nf_ref = choose_nf(av_hint_rows(d->M));
+    const int tilesN_small = (d->N + nf * 32 - 1) / (nf * 32);
     constexpr int BMB = 192;
     const bool big_ok = glds && !(d->flags & 4) && d->N % 320 == 0 && (!geglu || MODE == MODE_LINEAR) && (geglu || d->act == ACT_NONE);
     // Launch plan as a function of the row count: kernel family (persistent 192 x 320 tiles / 128-row tiles) and split-K factor.
@@ -930,7 +936,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     //    second pass costs more than the idle CUs; with 60 it pays only when fewer than a quarter of the block slots would be busy;
     //    from ~72 K-tiles on it always pays).
     struct Plan { int big, splits; };
-    auto plan = [&](int rows) -> Plan {
+    auto plan = [&](int rows, int nf_rows) -> Plan {
         const bool ws_ok = d->workspace != nullptr && d->N % 8 == 0;
         if (big_ok) {
             const int tb = ((rows + BMB - 1) / BMB) * (d->N / 320);
@@ -944,7 +950,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             }
             if (fills || (d->flags & 8)) return {1, 1};
         }
-        const int tm = ((rows + 127) / 128) * tilesN_small;
+        const int tm = ((rows + 127) / 128) * ((d->N + nf_rows * 32 - 1) / (nf_rows * 32));
         const bool split_pays = (tm <= 128 && nk_all >= 32) || nk_all >= 72;
         if (glds && !geglu && d->act != ACT_F32OUT && !(d->flags & 16) && ws_ok && tm < 384 && split_pays) {
             int sp = (512 + tm - 1) / tm;
@@ -957,9 +963,9 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     // Batch hint (anyv2v_set_batch_hint): what fixes the ARITHMETIC is the split-K factor (fp32 partial tiles summed afterwards);
     // the two kernel families accumulate every output element in the same order (tests/gpu_checks.py asserts it bit for bit).  A
     // hinted launch therefore takes the split factor of the launch it stands for and is otherwise planned on its own row count.
-    Plan use = plan(d->M);
+    Plan use = plan(d->M, nf);
     if (av_hint_rows(d->M) != d->M) {
-        const Plan ref = plan(av_hint_rows(d->M));
+        const Plan ref = plan(av_hint_rows(d->M), nf_ref);
         if (ref.splits > 1)
             use = ref;
         else if (use.splits > 1)
