@@ -53,6 +53,23 @@ def test_abi_argument_validation_without_gpu():
     assert b"shards" in lib.anyv2v_last_error()
     assert lib.anyv2v_groupnorm_partial_floats(8, 9, 32, 64) == -1 and lib.anyv2v_groupnorm_partial_floats(64, 8, 32, 64) == 8 * 32 * 2
     assert lib.anyv2v_groupnorm_partial_floats(64, 8, 32, 64) <= lib.anyv2v_groupnorm_scratch_floats(64, 8, 32)
+    # round 3: LayerNorm fold only on the weight-stationary shapes; rotary / row gather / attention bias argument checks
+    d = _lib.GemmDesc()
+    d.A0, d.W, d.C = 16, 16, 16
+    d.M, d.N, d.C0, d.lda0, d.ldc, d.flags = 64, 64, 64, 64, 64, 2
+    d.ln_c1, d.ln_eps = 16, 1e-5
+    assert lib.anyv2v_gemm_f16(ctypes.byref(d), None) != 0                # K = 64: no folded form
+    assert lib.anyv2v_rotary_f16(None, 64, 8, 0, 32, 1, 0, 4, 2, 10000.0, None) == -1
+    assert lib.anyv2v_rotary_f16(16, 64, 8, 0, 36, 1, 0, 4, 2, 10000.0, None) == -1           # rot_dim % 8
+    assert lib.anyv2v_rotary_f16(16, 64, 8, 40, 32, 1, 0, 4, 2, 10000.0, None) == -1          # window leaves the row
+    assert lib.anyv2v_rotary_f16(16, 64, 8, 0, 32, 2, 16, 4, 2, 10000.0, None) == -1          # overlapping windows
+    assert b"rotary" in lib.anyv2v_last_error()
+    assert lib.anyv2v_gather_rows_f16(16, 64, 0, None, 16, 64, 0, 8, 32, None) == -1          # null index
+    assert lib.anyv2v_gather_rows_f16(16, 64, 4, 16, 16, 64, 0, 8, 32, None) == -1            # unaligned column window
+    a = _lib.AttnDesc()
+    assert lib.anyv2v_attention_bias_f16(ctypes.byref(a), 64, None, None) == -1 and b"null bias" in lib.anyv2v_last_error()
+    assert lib.anyv2v_attention_bias_f16(ctypes.byref(a), 200, 16, None) == -1                 # head_dim > 160
+    assert lib.anyv2v_set_batch_hint(0, 1) != 0 and lib.anyv2v_set_batch_hint(3, 2) == 0 and lib.anyv2v_set_batch_hint(1, 1) == 0
     with pytest.raises(_lib.HipKernelError):
         _lib.check(-1, "x")
 
