@@ -106,6 +106,7 @@ class _StepEngine:
         # once -- the same image latents and fps, so the UNet may share their stem (exact; unet._forward_core)
         self._shared_stem_requested = bool(shared_stem)
         self.nosrc = None  # the [negative, editing]-only engine of a PnP edit (shares `sample[1:]`), built on demand
+        self.drop_src_tail = False  # set by sample_with_pnp on its three-branch engine
         self.ctx.shared_stem = bool(shared_stem and B >= 2 and os.environ.get("ANYV2V_SHARED_STEM", "1") == "1"
                                     and torch.equal(cond["image_latents"][B - 2], cond["image_latents"][B - 1])
                                     and torch.equal(cond["fps"][B - 2], cond["fps"][B - 1]))
@@ -148,10 +149,13 @@ class _StepEngine:
         return self._body_inner()
 
     def _body_inner(self):
-        vtok = self.unet._forward_core(self.ctx, self.sample)
+        # drop_src_tail: the engine's slot 0 is the PnP source branch, whose prediction the update below never reads -- the forward
+        # stops computing it behind the last hook site and returns the rows of slots [1:] (unet._forward_core)
+        vtok = self.unet._forward_core(self.ctx, self.sample, drop_source_tail=self.drop_src_tail)
         L = self.lat_slot
         lat = self.sample[L:L + 1]
-        ops.cfg_ddim_step(vtok, self.b_unc, self.b_cond, self.guidance, self.coef, lat, lat)
+        off = 1 if vtok.shape[0] != self.sample.shape[0] * self.sample.shape[2] * self.sample.shape[3] * self.sample.shape[4] else 0
+        ops.cfg_ddim_step(vtok, self.b_unc - off if self.b_unc >= 0 else self.b_unc, self.b_cond - off, self.guidance, self.coef, lat, lat)
         for s in self.dup_slots:
             self.sample[s].copy_(self.sample[L])
 
@@ -169,7 +173,7 @@ class _StepEngine:
                 with ops.batch_hint(*self.batch_hint):
                     self.unet._forward_core(self.ctx, self.sample)
             else:
-                self.unet._forward_core(self.ctx, self.sample)
+                self.unet._forward_core(self.ctx, self.sample, drop_source_tail=self.drop_src_tail)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -582,8 +586,11 @@ class I2VGenXLPipeline:
         sample = latents.repeat(nb, 1, 1, 1, 1).contiguous()
         cond = dict(encoder_hidden_states=ehs.contiguous(), fps=fps, image_latents=il_all.contiguous(),
                     image_embeddings=ie_all.contiguous())
-        eng = self._engine("pnp", sample, cond, b_unc=1 if cfg_on else -1, b_cond=nb - 1, guidance=guidance_scale,
-                           dup_slots=range(1, nb - 1), shared_stem=cfg_on)
+        # the source branch's prediction is never read (:1136,1160-1162): its forward may stop behind the last hook site (exact)
+        drop_tail = cfg_on and nb == 3 and os.environ.get("ANYV2V_DROP_SRC_TAIL", "1") == "1"
+        eng = self._engine("pnp-droptail" if drop_tail else "pnp", sample, cond, b_unc=1 if cfg_on else -1, b_cond=nb - 1,
+                           guidance=guidance_scale, dup_slots=range(1, nb - 1), shared_stem=cfg_on)
+        eng.drop_src_tail = drop_tail
         sample = eng.sample
         # source trajectory resident in HBM (in-memory hand-off from invert(), or read once from the reference's files)
         if isinstance(ddim_inv_latents_path, LatentTrajectory):

@@ -434,10 +434,13 @@ class BasicTransformerBlock(nn.Module):
         f = getattr(self, "_ln", {}).get(name)
         return f if (f is not None and proc_ok and ops.ln_gemm_supported(M, self.norm1.weight.shape[0], N, act)) else None
 
-    def run(self, ctx, x, geom: Geom, expand=None):
+    def run(self, ctx, x, geom: Geom, expand=None, shrink=None):
         """``expand`` = (full ctx, full geometry): the block was entered with the shared-stem batch (see
         ``I2VGenXLUNet._forward_core``); after self-attention the tokens are expanded to the full batch, where the
         branches start to differ (cross-attention context).
+        ``shrink`` = geometry without the first batch element: this block's self-attention is the LAST hook site of a PnP step
+        whose source-branch output nobody reads (``_forward_core(drop_source_tail=True)``); from here on only [negative, editing] are computed,
+        under the batch hint (3, 2) so that every launch makes the three-branch launch's choices (bit-equal rows).
 
         Each LayerNorm is folded into the projection that consumes it where the weight-stationary GEMM covers the shape
         (``pack``); otherwise -- other widths, small clips, a foreign processor on the seam -- it is the LayerNorm kernel."""
@@ -455,6 +458,10 @@ class BasicTransformerBlock(nn.Module):
             x = expand_shared(x, ctx)
             if after is not None:   # the stem ends here: from now on the full batch's hint
                 ops.set_batch_hint(*after)
+        if shrink is not None:
+            x = x[x.shape[0] // 3:]
+            geom = shrink
+            ops.set_batch_hint(3, 2)
         kv = ctx.kv_for(self.attn2) if self.attn2.is_cross else None
         f = self._fold("attn2", isinstance(self.attn2.processor, HipAttnProcessor), m_min(x), dim if self.attn2.is_cross else 3 * dim)
         if f is not None:
@@ -515,8 +522,14 @@ class TransformerTemporalModel(nn.Module):
                           eps=self.norm.eps, shard=shard)
         h = ops.gemm(h, self.proj_in.weight, bias=self.proj_in.bias)
         geom = Geom("temporal", ctx.B, ctx.F, HW)
-        for blk in self.transformer_blocks:
-            h = blk.run(ctx, h, geom)
+        drop = shard is None and getattr(ctx, "drop_tail_at", None) is self and not self.transformer_blocks[0].attn2.is_cross
+        for i, blk in enumerate(self.transformer_blocks):
+            if drop and i == 0:
+                h = blk.run(ctx, h, geom, shrink=Geom("temporal", ctx.B - 1, ctx.F, HW))
+                geom = Geom("temporal", ctx.B - 1, ctx.F, HW)
+                x = x[x.shape[0] // 3:]
+            else:
+                h = blk.run(ctx, h, geom)
         return ops.gemm(h, self.proj_out.weight, bias=self.proj_out.bias, residual=x)
 
 
@@ -965,9 +978,10 @@ class I2VGenXLUNet(nn.Module):
             ctx.t_buf.fill_(float(timestep))
         return self._forward_core(ctx, sample)
 
-    def _forward_core(self, ctx, sample):
+    def _forward_core(self, ctx, sample, drop_source_tail=False):
         """One UNet evaluation given a prepared clip context and ``ctx.t_buf`` (device timestep): pure function of
-        (sample, t) -- this is what the pipeline captures into a HIP graph."""
+        (sample, t) -- this is what the pipeline captures into a HIP graph.  ``drop_source_tail`` (PnP step engine only): the
+        prediction of batch element 0 is not needed -- the rows of [1:] are returned, see below."""
         cfg = self.cfg
         B, C, F, H, W = sample.shape
         fp = ctx.fp
@@ -1011,14 +1025,23 @@ class I2VGenXLUNet(nn.Module):
             x, outs, h_, w_ = blk.run(ctx, x, h_, w_, stem_ctx=stem if bi == 0 else None)
             skips.extend(outs)
         x = self.mid_block.run(ctx, x, h_, w_)
+        # PnP step whose source-branch prediction is discarded (pipeline_i2vgen_xl.py:1136,1160-1162): behind the last hook site --
+        # the self-attention of up_blocks[3].temp_attentions[2] -- the source rows are dead; the rest of the forward runs on
+        # [negative, editing] only and returns their 2 x F x HW rows (exact)
+        last = self.up_blocks[-1].temp_attentions[-1] if getattr(self.up_blocks[-1], "has_cross_attention", False) else None
+        drop = bool(drop_source_tail and B == 3 and fp is None and hint is None and last is not None)
+        ctx.drop_tail_at = last if drop else None
         for blk in self.up_blocks:
             x, h_, w_ = blk.run(ctx, x, skips, h_, w_)
+        ctx.drop_tail_at = None
         x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, H * W,
                           groups=self.conv_norm_out.num_groups, eps=self.conv_norm_out.eps, silu=True)
         vtok = torch.empty((x.shape[0], 8), dtype=torch.float16, device=x.device)
         self.conv_out.tokens(x, H, W, out=vtok)
         if fp is not None:
             vtok = fp.gather_frames(vtok, B, F, H * W)  # every rank steps the full latents (identically)
+        if drop:
+            ops.set_batch_hint(1, 1)
         return vtok
 
     def forward(self, sample, timestep, fps=None, image_latents=None, image_embeddings=None,

@@ -312,7 +312,7 @@ def executed_flops(engine, hooks_t=None):
             pnp_utils.register_time(engine.pipe, hooks_t)
         else:
             pnp_utils.clear_time(engine.pipe)
-        engine.unet._forward_core(engine.ctx, engine.sample.clone())
+        engine.unet._forward_core(engine.ctx, engine.sample.clone(), drop_source_tail=getattr(engine, "drop_src_tail", False))
         torch.cuda.synchronize()
     finally:
         ops.gemm, ops.attention = g0, a0
@@ -489,6 +489,9 @@ def main():
     pnp_utils.clear_time(pipe)   # inversion steps run hook-free (stage 1 of the reference has no hooks registered)
     e_inv = _StepEngine(pipe, s_inv, cond1, b_unc=-1, b_cond=0, guidance=1.0, dup_slots=[])
     e_pnp = _StepEngine(pipe, s_pnp, cond3, b_unc=1, b_cond=2, guidance=9.0, dup_slots=[1], shared_stem=True)
+    # as pipe.sample_with_pnp configures its three-branch engine: the source branch's prediction is never read, so its forward stops
+    # behind the last hook site (exact, bit-equal; anyv2v_amd/pipeline.py)
+    e_pnp.drop_src_tail = os.environ.get("ANYV2V_DROP_SRC_TAIL", "1") == "1"
     tt_inv = torch.tensor(ts_inv, dtype=torch.float32, device=device)[:, None].contiguous()
     tt_pnp = torch.tensor(ts_pnp, dtype=torch.float32, device=device)[:, None].expand(-1, 3).contiguous()
     cf_inv, cf_pnp = inv.coefficient_table(ts_inv, device), fwd.coefficient_table(ts_pnp, device)
@@ -557,7 +560,7 @@ def main():
                          "step_frac_executed": round(ex_t / (ms * 1e-3) / PEAK_MFMA_F16_TFLOPS, 4),
                          "what": "MFMA work per bench step (1 inversion step B=1 + 1 edit step B=3) / ms_per_step / 2500 TFLOP/s; algorithmic = the "
                                  "reference architecture's count (SURVEY 8(d)), executed = summed over the launches of one eager forward of each kind "
-                                 "(exact savings: hoisted conditioning, V-only projections, shared softmax, shared stem, source-only conv path)"}
+                                 "(exact savings: hoisted conditioning, V-only projections, shared softmax, shared stem, source-only conv path, source branch stopped behind the last hook site)"}
         traffic = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")))
         if traffic:
             try:

@@ -1363,6 +1363,16 @@ def check_loops_mini():
                                             ddim_inv_image_latents=il[:1].to(DEV)).frames
             r_skip, r_full = edit(True), edit(False)
             os.environ["ANYV2V_SRC_SKIP"] = "1"
+            # the source branch's dead tail (behind the last hook site) dropped / computed: same latents.  On the GPU bit for bit
+            # (the shortened launches run under the batch hint (3, 2)); the CPU emulation's BLAS depends on M
+            os.environ["ANYV2V_DROP_SRC_TAIL"] = "0"
+            r_tail = edit(True)
+            os.environ["ANYV2V_DROP_SRC_TAIL"] = "1"
+            if DEV == "cpu":
+                out.append(_res(f"source-branch tail dropped == computed [{tag}]", r_skip.cpu(), r_tail.cpu(), 2e-2))
+            else:
+                out.append(dict(name=f"source-branch tail dropped == computed, bit for bit [{tag}]", tol=0.0,
+                                err=float((r_skip.float() - r_tail.float()).abs().max()), ok=bool(torch.equal(r_skip, r_tail))))
             pnp_oracle.init_pnp(oracle, n_steps, 0.2, 0.4, 0.5)
             edited_o2 = pnp_oracle.pnp_loop(oracle, traj_o[T].clone(), traj_o, cond_all, n_steps, 9.0, t_idx=0)
             out.append(bound(f"sample_with_pnp early-ending schedules [{tag}] vs oracle", r_skip, edited_o2, edited_e2 if cal else None, 8e-2))
