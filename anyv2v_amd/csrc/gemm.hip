@@ -577,12 +577,44 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int G = gridDim.x;
-    const int b0 = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous
+    // Tile order.  Classic: output tiles N-fastest, dealt to the XCDs in contiguous runs of G / 8 (an XCD's 32 blocks then share
+    // A panels in its L2).  Rastered (p.rast_gm > 0; wide-N launches, G = 256): the 32 concurrent blocks of XCD x (= blockIdx & 7)
+    // cover ONE super-tile of rast_gm x rast_gn output tiles, and an XCD's consecutive super-tiles keep the same W slabs -- with
+    // N = 16 / 32 tiles the classic order makes every XCD stream the whole W (6.6 / 26 MB > its 4 MB L2) once per round.
+    const bool rast = !SPLIT && p.rast_gm > 0;
+    const int b0 = rast ? (int)blockIdx.x : (((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x);
     const int tilesM = (p.M + BM - 1) / BM;
     const int ntiles_out = tilesM * p.tilesN;
     // SPLIT: work items are (split, output tile) -- split-K for launches whose tiles alone cannot fill the CUs (a separate
     // instantiation: the extra per-item state costs registers the plain kernel does not have)
-    const int ntiles = SPLIT ? ntiles_out * p.splits : ntiles_out;
+    const int ntiles = SPLIT ? ntiles_out * p.splits : (rast ? G * ((p.rast_sm * p.rast_sn + 7) >> 3) : ntiles_out);
+    // item -> output tile; false = a hole of the rastered order (ragged M, or past the last super-tile)
+    auto decode = [&](int t, int& mt, int& nt) -> bool {
+        if (!rast) {
+            const int to = SPLIT ? t % ntiles_out : t;
+            mt = to / p.tilesN;
+            nt = to - mt * p.tilesN;
+            return true;
+        }
+        const int q = (t & 7) + 8 * (t / G), j = (t % G) >> 3;
+        int sm, sn;
+        if (p.rast_nfast) {
+            sm = q / p.rast_sn;
+            sn = q - sm * p.rast_sn;
+        } else {
+            sn = q / p.rast_sm;
+            sm = q - sn * p.rast_sm;
+        }
+        const int jm = j / p.rast_gn, jn = j - jm * p.rast_gn;
+        mt = sm * p.rast_gm + jm;
+        nt = sn * p.rast_gn + jn;
+        return q < p.rast_sm * p.rast_sn && mt < tilesM;
+    };
+    auto next_valid = [&](int t) {
+        int mt_, nt_;
+        while (t < ntiles && !decode(t, mt_, nt_)) t += G;
+        return t;
+    };
 
     const int srow0 = tid >> 3, pc = tid & 7, kc = pc ^ (srow0 & 7);
     const int ntap = p.nt0 + p.nt1;
@@ -596,8 +628,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     const size_t brow = (size_t)64 * p.Ktot;
     AGen<MODE> gen;
     auto producer_start = [&](int item) {
-        const int tile_o = SPLIT ? item % ntiles_out : item;
-        const int mt = tile_o / p.tilesN, nt = tile_o - mt * p.tilesN;
+        int mt, nt;
+        decode(item, mt, nt);
         const int kb = k_begin(item);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ri[i] = make_row<MODE>(p, i < MF ? mt * BM + srow0 + 64 * i : p.M);
@@ -621,7 +653,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     };
 
     f4 acc[MF][10];
-    int tile = b0;
+    int tile = next_valid(b0);
     if (tile >= ntiles) return;
     producer_start(tile);
     issue(0);
@@ -629,12 +661,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
     bool landed = false;
     bool rederive = false;  // producer state is not carried across an epilogue (register pressure): re-derive it  // the current tile's first K-tile was already waited for (before the previous epilogue)
     while (true) {
-        const int tile_o = SPLIT ? tile % ntiles_out : tile;
-        const int mt = tile_o / p.tilesN, nt = tile_o - mt * p.tilesN;
+        int mt, nt;
+        decode(tile, mt, nt);
         const int nk = k_end(tile) - k_begin(tile);
         const int m_wave = mt * BM + wr * MF * 16;
         const int n_wave = nt * BN + wc * 160;
-        const int next_tile = tile + G;
+        const int next_tile = next_valid(tile + G);
         const bool has_next = next_tile < ntiles;
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -986,6 +1018,22 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             return av_launch_status("gemm_big<split-K>");
         }
         const dim3 grid(tiles_big < 256 ? tiles_big : 256);
+        {   // tile order of wide-N launches (gemm_big_kernel): 8 x 4 super-tiles per XCD round when N has >= 8 tiles (the GEGLU
+            // up-projections at 640 / 1280 channels: 16 / 32 N-tiles).  flags bits 13-15: 0 auto, 1 classic order, 2..6 force
+            // rast_gm = 4, 8, 16, 32, 2; bit16: super-tiles N-fastest.  Same arithmetic per output element in every order.
+            const int code = (d->flags >> 13) & 7;
+            static const int gm_of[8] = {0, 0, 4, 8, 16, 32, 2, 0};
+            int gm = gm_of[code];
+            if (code == 0 && k.tilesN >= 8 && tiles_big >= 512) gm = 8;
+            const int tm_big = (d->M + BMB - 1) / BMB;
+            if (gm > 0 && grid.x == 256 && k.tilesN % (32 / gm) == 0) {
+                k.rast_gm = gm;
+                k.rast_gn = 32 / gm;
+                k.rast_sm = (tm_big + gm - 1) / gm;
+                k.rast_sn = k.tilesN / k.rast_gn;
+                k.rast_nfast = (d->flags >> 16) & 1;
+            }
+        }
 #ifdef ANYV2V_EXPERIMENTS  // probe build only (make experiments): phase-timestamp instantiations, tools/gemm_big_trace.py
 #include "../../tools/experiments/gemm_dispatch_big_probe.inc"
 #endif
@@ -1088,6 +1136,7 @@ extern "C" int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream) {
     k.trace = nullptr;
     k.ln_c1 = nullptr;
     k.ln_eps = 0.f;
+    k.rast_gm = k.rast_gn = k.rast_sm = k.rast_sn = k.rast_nfast = 0;
     k.vec_epi = (((uintptr_t)d->bias & 7) == 0) && (((uintptr_t)d->rowvec & 7) == 0) && (d->ldrv % 4 == 0) && (d->N % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
 

@@ -25,6 +25,9 @@ struct GemmK {
     long long* trace;  // debug (flags bit5): 32 timestamps per block, see tools/gemm_trace.py
     const float* ln_c1;  // LayerNorm fold (gemm_ws.hip): column sums of the gamma-scaled weights, or nullptr
     float ln_eps;
+    // persistent kernel, rastered tile order (0 = classic): an XCD round covers rast_gm x rast_gn output tiles; rast_sm x rast_sn
+    // super-tiles, walked M-fastest (rast_nfast = 0) or N-fastest
+    int rast_gm, rast_gn, rast_sm, rast_sn, rast_nfast;
 };
 
 struct RowInfo {

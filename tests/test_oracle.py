@@ -355,3 +355,48 @@ def test_erf_gelu_series_constants_in_common_h_over_every_fp16_input():
         return np.where(i < 0, -(i & 0x7FFF), i)
     d = np.abs(key(y) - key(exact.astype(np.float16)))
     assert d.max() <= 1 and (d > 0).mean() < 0.01, (int(d.max()), float((d > 0).mean()))
+
+
+def test_chunked_oracle_equals_plain_oracle():
+    """oracle/chunked.py (the size-safe evaluation the full-size config-5 parity rows use as their fp32 checker) changes no output
+    element: chunked == plain, un-hooked and with all three PnP hook families on, ragged chunk sizes included."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_checks import config1_inputs
+    from oracle import chunked
+    cfg = UNetConfig.mini()
+    unet = build_oracle(cfg, random_state_dict(cfg, 7))
+    B, Fr, hw = 3, 5, 8
+    inp = config1_inputs(cfg, B, Fr, hw, seed=5)
+    kw = dict(fps=inp["fps"], image_latents=inp["image_latents"], image_embeddings=inp["image_embeddings"],
+              encoder_hidden_states=inp["encoder_hidden_states"])
+
+    def both(t):
+        with torch.no_grad():
+            plain = unet(inp["sample"], t, **kw)[0]
+            chunked.enable_chunking(unet, B, Fr, frame_chunk=2, row_chunk=3)
+            try:
+                ch = unet(inp["sample"], t, **kw)[0]
+            finally:
+                chunked.disable_chunking(unet)
+            again = unet(inp["sample"], t, **kw)[0]
+        assert torch.equal(plain, again), "disable_chunking must restore the plain forward"
+        return plain, ch
+
+    plain, ch = both(981)
+    assert (plain - ch).abs().max() <= 2e-5 * plain.abs().max()
+    ts = list(range(981, 0, -20))
+    pnp_oracle.register_conv_injection(unet, ts[:10])
+    pnp_oracle.register_spatial_attention_pnp(unet, ts[:25])
+    pnp_oracle.register_temp_attention_pnp(unet, ts[:40])
+    try:
+        for t in (981, 301, 101):
+            pnp_oracle.register_time(unet, t)
+            hp, hc = both(t)
+            assert (hp - hc).abs().max() <= 2e-5 * hp.abs().max(), t
+            if t == 981:
+                assert (hp - plain).abs().max() > 1e-2 * plain.abs().max()   # the hooks are not vacuous
+    finally:
+        pnp_oracle.clear_hooks(unet)
+    with torch.no_grad():
+        assert torch.equal(unet(inp["sample"], 981, **kw)[0], plain)
