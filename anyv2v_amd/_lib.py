@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libanyv2v_hip.so")
+ABI_VERSION = 101   # ANYV2V_ABI_VERSION of include/anyv2v_hip.h the structures below mirror
 
 
 class HipExtensionMissing(RuntimeError):
@@ -95,6 +96,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if lib.anyv2v_version() < ABI_VERSION:   # descriptors carry no size field: a stale library would read past a shorter struct
+        raise HipExtensionMissing(f"{LIB_PATH} is ABI {lib.anyv2v_version()}, this binding needs >= {ABI_VERSION}: rebuild it "
+                                  f"(`make -C {os.path.join(_HERE, 'csrc')}`)")
     _lib = lib
     return lib
 

@@ -12,7 +12,7 @@ void anyv2v_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* anyv2v_last_error(void) { return g_err; }
-extern "C" int anyv2v_version(void) { return 100; }
+extern "C" int anyv2v_version(void) { return ANYV2V_ABI_VERSION; }
 
 // Batch hint: launch heuristics (kernel family, split-K factor, GroupNorm chunking) are functions of the row count.  A step that runs
 // a SUBSET of the branches of another step (the PnP edit's [negative, editing] steps vs its three-branch steps) must make the same

@@ -237,10 +237,9 @@ class I2VGenXLPipeline:
             from .encoders import NativeVAE
             pipe.vae = NativeVAE(state_dict=load_file(vpath))
         if os.path.isdir(os.path.join(root, "text_encoder")):
-            # CLIP towers of a local checkpoint on the HIP kernels (anyv2v_amd.clip); ANYV2V_HF_CLIP=1 selects the plain
-            # transformers modules instead (A/B reference, not the product path)
-            from .encoders import attach_hf_clip_encoders, attach_native_clip_encoders
-            (attach_hf_clip_encoders if os.environ.get("ANYV2V_HF_CLIP", "0") == "1" else attach_native_clip_encoders)(pipe, root)
+            # CLIP towers of a local checkpoint on the HIP kernels (anyv2v_amd.clip)
+            from .encoders import attach_native_clip_encoders
+            attach_native_clip_encoders(pipe, root)
         return pipe
 
     def to(self, device):

@@ -66,7 +66,10 @@ typedef struct AnyV2VGemmDesc {
                             allows; bit4: no split-K; bit9 (512): never use the weight-stationary K = 320 kernel; bit10 (1024):
                             use it whenever the shape allows (mode 0, C0 = 320 with N % 160 = 0 or C0 = 512 with N % 64 = 0 (GEGLU: 128), C1 = 0, act 0 | 3, no rowvec), also
                             below its M >= 32768 threshold; bit11 (2048) / bit12 (4096): 128-column / 160-column tiles in the
-                            128-row kernel regardless of the fill heuristic.  All other bits are ignored by the product library. */
+                            128-row kernel regardless of the fill heuristic; bits 13-15: tile order of the persistent kernel on
+                            wide-N launches (0 auto, 1 classic N-fastest, 2..6 super-tiles of 4 / 8 / 16 / 32 / 2 M-tiles per XCD
+                            round), bit16: super-tiles walked N-fastest -- every order gives bit-identical results.  All other
+                            bits are ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
     /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock.norm1/2/3 -> attn.to_q/k/v / ff.net[0].proj,
@@ -217,9 +220,17 @@ int anyv2v_ddim_step_f16(const void* V, const void* X, void* Y, float sa_t, floa
 /* Launch heuristics (kernel family, split-K factor, GroupNorm chunking) see rows * num / den from now on; grids and bounds keep the true
  * row counts.  The PnP edit runs some steps on [negative, editing] only (steps outside every injection schedule; steps whose source
  * features are replayed from a multi-edit cache, pipeline_i2vgen_xl.py:1136-1162): with the hint 3 / 2 those launches choose what the
- * three-branch launch chooses, so every fp32 summation order -- and the result, bit for bit -- is the same.  (1, 1) resets. */
+ * three-branch launch chooses, so every fp32 summation order -- and the result, bit for bit -- is the same.  (1, 1) resets.
+ * PROCESS-GLOBAL and NOT thread-safe: one host-side pair of integers read by every launch at enqueue (= graph capture) time, like the
+ * single-threaded reference loop it serves.  A host that enqueues from several threads must serialise "set hint .. launches ..
+ * reset" itself (anyv2v_last_error(), by contrast, is thread-local). */
 int anyv2v_set_batch_hint(int32_t num, int32_t den);
 const char* anyv2v_last_error(void);
+/* ABI version = major * 100 + minor.  Descriptors carry no size field: a caller MUST be compiled against the header of the
+ * library it loads (check anyv2v_version() >= the ANYV2V_ABI_VERSION it was built with) and MUST zero-initialise every
+ * descriptor (new fields are appended with 0 = "off").  101: AnyV2VGemmDesc grew ln_c1 / ln_eps / reserved0 (round 3), flags
+ * bits 13-16 select the persistent kernel's tile order (round 4). */
+#define ANYV2V_ABI_VERSION 101
 int anyv2v_version(void);
 /* MFMA / LDS layout self-test used by the gpu test-suite (returns 0 when the layouts the kernels assume hold) */
 int anyv2v_selftest(void* scratch, int64_t scratch_bytes, void* stream);

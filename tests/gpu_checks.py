@@ -1790,8 +1790,12 @@ def check_n1_config3_step(cfg_name="full", Fr=16, hw=64, report=None, hooked_ts=
             for n in ("o32", "o16"):
                 pnp_oracle.register_time(m[n], t)
             v32, v16, vn = run_all(3, t)
+            # (the distance between the two fp16 implementations cannot be asked to be smaller than the eager one's own error on THIS
+            #  row: at [3,4,128,64,64] eager fp16 has isolated outliers -- max-rel 2.8e-2 at rel-L2 6.7e-3 -- that the HIP path, 2.1e-3 /
+            #  2.1e-3 from fp32, does not share; profiles/r04_gputest_n1_log.txt)
+            cap_t = None if gap_cap is None else max(gap_cap, 3.0 * _rel(v16, v32)[0] + 5e-4)
             out.append(_calibrated(f"unet {cfg_name} [3,4,{Fr},{hw},{hw}] + 17 hook sites t={t} vs fp32 oracle{tag}", vn, v32, v16,
-                                   key=f"n1step:{cfg_name}:F{Fr}x{hw}:B3:t{t}", gap_cap=gap_cap))
+                                   key=f"n1step:{cfg_name}:F{Fr}x{hw}:B3:t{t}", gap_cap=cap_t))
             if plain_fp32_too and chunked:
                 i16 = sl(inp16, slice(0, 3))
                 t0 = time.time()

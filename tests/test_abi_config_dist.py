@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/anyv2v_hip.h but not exported"
     assert set(decl) == set(_lib.SYMBOLS), "ctypes binding table and header disagree"
-    assert _lib.load().anyv2v_version() >= 100
+    assert _lib.load().anyv2v_version() >= 101
 
 
 def test_abi_argument_validation_without_gpu():
@@ -143,6 +143,55 @@ def test_shipped_templates_resolve():
               "ddim_inv_prompt", "random_ratio", "pnp_f_t", "pnp_spatial_attn_t", "pnp_temp_attn_t", "editing_prompt",
               "editing_negative_prompt", "edited_first_frame_path", "video_dir", "output_dir", "active"):
         assert k in c, k
+
+
+def test_the_references_own_job_lists_resolve_entry_by_entry():
+    """B5: the reference's shipped job lists (i2vgen-xl/configs/group_*/group_config.json: 15 edit entries, 6 inversion entries) are
+    shipped with the same entries, and EVERY entry resolves through anyv2v_amd.config against the shipped template -- and, in this
+    container, against the REFERENCE's own template.yaml -- to the paths and the output-directory suffix of
+    run_group_pnp_edit.py:82-86,154-168 / run_group_ddim_inversion.py."""
+    from anyv2v_amd.config import OmegaConf
+    from anyv2v_amd.run_group_pnp_edit import output_suffix
+    ours = os.path.join(ROOT, "configs")
+    ref = "/root/reference/i2vgen-xl/configs"
+    edits = json.load(open(os.path.join(ours, "group_pnp_edit", "group_config.json")))
+    invs = json.load(open(os.path.join(ours, "group_ddim_inversion", "group_config.json")))
+    assert len(edits) == 15 and len(invs) == 6
+    assert sum(e["active"] is not False for e in edits) == 1 and edits[0]["active"] is True
+    if os.path.isdir(ref):
+        assert edits == json.load(open(os.path.join(ref, "group_pnp_edit", "group_config.json")))
+        assert invs == json.load(open(os.path.join(ref, "group_ddim_inversion", "group_config.json")))
+    bases = [ours] + ([ref] if os.path.isdir(ref) else [])
+    resolved = {}
+    for base in bases:
+        tmpl = OmegaConf.load(os.path.join(base, "group_pnp_edit", "template.yaml"))
+        for i, e in enumerate(edits):
+            c = OmegaConf.merge(tmpl, OmegaConf.create(e))
+            c.video_path = os.path.join(c.video_dir, c.video_name + ".mp4")
+            c.video_frames_path = os.path.join(c.video_dir, c.video_name)
+            c.edited_first_frame_path = os.path.join(c.data_dir, c.edited_first_frame_path)
+            assert "ReplaceMe" not in OmegaConf.to_yaml(c, resolve=True), (base, i)
+            assert c.ddim_latents_path == f"{c.data_dir}/inversions/i2vgen-xl/{e['video_name']}/ddim_latents"
+            assert c.video_frames_path.endswith(os.path.join("demo", e["video_name"]))
+            assert c.output_dir.rstrip("/") == f"{c.data_dir}/Results/{e['task_name']}/i2vgen-xl/{e['video_name']}/{e['edited_video_name']}"
+            # the entry's overrides win over the template defaults (1 / 0.2 / 0.2 / 0.5); the suffix spells them as Python floats / ints
+            t_idx = e.get("ddim_init_latents_t_idx", 1)
+            f_t, s_t, t_t = e.get("pnp_f_t", 0.2), e.get("pnp_spatial_attn_t", 0.2), e.get("pnp_temp_attn_t", 0.5)
+            assert (c.ddim_init_latents_t_idx, c.pnp_f_t, c.pnp_spatial_attn_t, c.pnp_temp_attn_t) == (t_idx, f_t, s_t, t_t)
+            suffix = output_suffix(c, c.ddim_init_latents_t_idx)
+            assert suffix == f"ddim_init_latents_t_idx_{t_idx}_nsteps_50_cfg_9.0_pnpf{f_t}_pnps{s_t}_pnpt{t_t}"
+            resolved.setdefault(i, []).append((OmegaConf.to_yaml(c, resolve=True).replace("cuda:4", "cuda:0"), suffix))
+        tmpl = OmegaConf.load(os.path.join(base, "group_ddim_inversion", "template.yaml"))
+        for i, e in enumerate(invs):
+            c = OmegaConf.merge(tmpl, OmegaConf.create(e))
+            assert c.inverse_config.output_dir == f"{c.data_dir}/inversions/i2vgen-xl/{e['video_name']}/ddim_latents"
+            assert c.recon_config.enable_recon is e.get("recon_config", {}).get("enable_recon", False)
+            assert list(c.inverse_config.image_size) == e.get("image_size", [512, 512]) and c.inverse_config.n_steps == 500
+    for i, both in resolved.items():   # our template and the reference's resolve every entry to the same values
+        if len(both) == 2:
+            a, b = (yaml_text for yaml_text, _ in both)
+            strip = lambda t: sorted(l.split("#")[0].rstrip() for l in t.splitlines() if l.strip())
+            assert strip(a) == strip(b), i
 
 
 # ------------------------------------------------------------------------------------------- sharding

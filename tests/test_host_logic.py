@@ -284,7 +284,7 @@ def test_hf_clip_adapters_follow_the_reference_encode_paths():
     transformers = pytest.importorskip("transformers")
     from PIL import Image
 
-    from anyv2v_amd.encoders import HFImageEncoder, HFTextEncoder
+    from hf_clip_reference import HFImageEncoder, HFTextEncoder
     tm = transformers.CLIPTextModel(transformers.CLIPTextConfig(vocab_size=100, hidden_size=32, intermediate_size=64,
                                                                 num_hidden_layers=3, num_attention_heads=4,
                                                                 max_position_embeddings=16, bos_token_id=1, eos_token_id=2))
@@ -370,7 +370,8 @@ def test_native_clip_encoders_follow_the_reference_encode_paths(cpu_ops, tmp_pat
     from PIL import Image
     from safetensors.torch import save_file
 
-    from anyv2v_amd.encoders import HFImageEncoder, HFTextEncoder, NativeImageEncoder, NativeTextEncoder, _load_tower_files
+    from anyv2v_amd.encoders import NativeImageEncoder, NativeTextEncoder, _load_tower_files
+    from hf_clip_reference import HFImageEncoder, HFTextEncoder
     from anyv2v_amd.clip import CLIPTextTower, CLIPTowerConfig, CLIPVisionTower
     tm, vm, tcfg, vcfg = _tiny_clip_pair(transformers)
     for name, m, c in (("text_encoder", tm, tcfg), ("image_encoder", vm, vcfg)):
@@ -505,7 +506,8 @@ def test_native_pipeline_from_raw_inputs_vs_reference_pipeline(cpu_ops, tmp_path
     from PIL import Image
 
     from anyv2v_amd import pnp_utils
-    from anyv2v_amd.encoders import HFImageEncoder, HFTextEncoder, _center_crop_wide, _pil_to_tensor
+    from anyv2v_amd.encoders import _center_crop_wide, _pil_to_tensor
+    from hf_clip_reference import HFImageEncoder, HFTextEncoder
     from anyv2v_amd.pipeline import I2VGenXLPipeline
     from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
     from oracle import ref_pipeline
