@@ -110,10 +110,11 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     return out
 
 
-def ln_gemm_supported(M: int, K: int, N: int, act: int = ACT_NONE) -> bool:
+def ln_gemm_supported(M: int, K: int, N: int, act: int = ACT_NONE, hinted: bool = True) -> bool:
     """Shapes for which ``gemm(..., ln=...)`` runs (the weight-stationary kernel, gemm_ws.hip) AND pays: the 64x64 level's row
-    counts.  Mirrors the library's own check; everything else runs ``layernorm`` + ``gemm``."""
-    if FORCE_NAIVE or not USE_GLDS or (GEMM_FLAGS & (512 | 4)) or M * _HINT[0] // _HINT[1] < 32768:
+    counts.  Mirrors the library's own check; everything else runs ``layernorm`` + ``gemm``.  ``hinted=False``: ``M`` is already a
+    canonical row count (one branch's rows) and is compared as it is, whatever batch hint is in force."""
+    if FORCE_NAIVE or not USE_GLDS or (GEMM_FLAGS & (512 | 4)) or (M * _HINT[0] // _HINT[1] if hinted else M) < 32768:
         return False
     if K == 320:
         return N % 160 == 0 and N // 160 <= 32

@@ -53,10 +53,22 @@ class SourceFeatureCache:
 
     ``signature``: what the recorded features depend on; a different one (next clip, other weights) empties the cache."""
 
-    def __init__(self):
+    def __init__(self, max_bytes: Optional[int] = None):
         self.signature = None
         self.steps: Dict[int, Dict[str, torch.Tensor]] = {}
         self.recorded_steps = self.replayed_steps = 0
+        # byte budget (``ANYV2V_SOURCE_CACHE_GB``, default 96 GB of the 288): a step that would exceed it is simply not recorded and
+        # runs as a three-branch step in every edit -- same results, no saving for that step
+        self.max_bytes = int(float(os.environ.get("ANYV2V_SOURCE_CACHE_GB", "96")) * 2 ** 30) if max_bytes is None else int(max_bytes)
+        self.skipped_steps = 0
+
+    def store(self, t, feats: Dict[str, torch.Tensor]) -> bool:
+        need = sum(v.numel() * v.element_size() for v in feats.values())
+        if self.nbytes() + need > self.max_bytes:
+            self.skipped_steps += 1
+            return False
+        self.steps.setdefault(int(t), {}).update({n: v.clone() for n, v in feats.items()})
+        return True
 
     def bind(self, signature):
         if signature != self.signature:
@@ -610,7 +622,7 @@ class I2VGenXLPipeline:
         sites = pnp_utils.injection_sites(self) if cache is not None else []
         if cache is not None:
             fp_ = lambda x: (tuple(x.shape), float(x.float().sum()), float(x.float().abs().sum()))
-            src = ("object", id(traj)) if isinstance(ddim_inv_latents_path, LatentTrajectory) else ("files", os.path.abspath(str(ddim_inv_latents_path)))
+            src = ("object", traj.serial) if isinstance(ddim_inv_latents_path, LatentTrajectory) else ("files", os.path.abspath(str(ddim_inv_latents_path)))
             cache.bind((src, tuple(ts), fp_(load_ddim_latents_at_t(ts[0], traj)), fp_(spe), fp_(sie), fp_(sil), int(target_fps),
                         self.unet._pack_gen, id(self.unet), tuple(latents.shape)))
             if not hasattr(eng, "site_bufs"):
@@ -662,8 +674,7 @@ class I2VGenXLPipeline:
                     set_io("record", names)
                     eng.step(t_table[i], coef_table[i], key=("pnp-record",) + state)
                     set_io(None, ())
-                    cache.steps.setdefault(t, {}).update({n: eng.site_bufs[n].clone() for n in names})
-                    cache.recorded_steps += 1
+                    cache.recorded_steps += bool(cache.store(t, {n: eng.site_bufs[n] for n in names}))
                 else:
                     eng.step(t_table[i], coef_table[i], key=("pnp",) + state)
             if latents_trace is not None:

@@ -430,9 +430,13 @@ class BasicTransformerBlock(nn.Module):
                 .reshape(2 * n, *t.shape[1:]).contiguous()
             self._ln["ff"] = (il(w), il(b), il(c1))
 
-    def _fold(self, name, proc_ok, M, N, act=ACT_NONE):
+    def _fold(self, name, proc_ok, M, N, act=ACT_NONE, per_branch=False):
+        """``per_branch``: ``M`` is the row count of ONE batch element -- the canonical quantity for the attention projections, whose
+        launches see one, two or three branches' rows depending on the engine (V-only thirds at injected sites, [negative, editing]
+        steps under the batch hint, the shared stem): every engine must take the same decision for the same branch, or the
+        bit-equality of the two-branch steps with the three-branch step breaks at mid sizes."""
         f = getattr(self, "_ln", {}).get(name)
-        return f if (f is not None and proc_ok and ops.ln_gemm_supported(M, self.norm1.weight.shape[0], N, act)) else None
+        return f if (f is not None and proc_ok and ops.ln_gemm_supported(M, self.norm1.weight.shape[0], N, act, hinted=not per_branch)) else None
 
     def run(self, ctx, x, geom: Geom, expand=None, shrink=None):
         """``expand`` = (full ctx, full geometry): the block was entered with the shared-stem batch (see
@@ -445,8 +449,8 @@ class BasicTransformerBlock(nn.Module):
         Each LayerNorm is folded into the projection that consumes it where the weight-stationary GEMM covers the shape
         (``pack``); otherwise -- other widths, small clips, a foreign processor on the seam -- it is the LayerNorm kernel."""
         dim = x.shape[1]
-        m_min = lambda t: t.shape[0] // 3 if t.shape[0] % 3 == 0 else t.shape[0]   # the V-only split projects thirds
-        f = self._fold("attn1", isinstance(self.attn1.processor, HipAttnProcessor), m_min(x), 3 * dim)
+        rows_b = lambda t, g: t.shape[0] // g.B   # rows of one branch: the same number in every engine that computes that branch
+        f = self._fold("attn1", isinstance(self.attn1.processor, HipAttnProcessor), rows_b(x, geom), 3 * dim, per_branch=True)
         if f is not None:
             x = self.attn1.run(ctx, None, geom, residual=x, ln_in=(x, f, self.norm1.eps))
         else:
@@ -463,7 +467,8 @@ class BasicTransformerBlock(nn.Module):
             geom = shrink
             ops.set_batch_hint(3, 2)
         kv = ctx.kv_for(self.attn2) if self.attn2.is_cross else None
-        f = self._fold("attn2", isinstance(self.attn2.processor, HipAttnProcessor), m_min(x), dim if self.attn2.is_cross else 3 * dim)
+        f = self._fold("attn2", isinstance(self.attn2.processor, HipAttnProcessor), rows_b(x, geom), dim if self.attn2.is_cross else 3 * dim,
+                       per_branch=True)
         if f is not None:
             x = self.attn2.run(ctx, None, geom, residual=x, kv=kv, ln_in=(x, f, self.norm2.eps))
         else:
@@ -1031,17 +1036,20 @@ class I2VGenXLUNet(nn.Module):
         last = self.up_blocks[-1].temp_attentions[-1] if getattr(self.up_blocks[-1], "has_cross_attention", False) else None
         drop = bool(drop_source_tail and B == 3 and fp is None and hint is None and last is not None)
         ctx.drop_tail_at = last if drop else None
-        for blk in self.up_blocks:
-            x, h_, w_ = blk.run(ctx, x, skips, h_, w_)
-        ctx.drop_tail_at = None
-        x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, H * W,
-                          groups=self.conv_norm_out.num_groups, eps=self.conv_norm_out.eps, silu=True)
-        vtok = torch.empty((x.shape[0], 8), dtype=torch.float16, device=x.device)
-        self.conv_out.tokens(x, H, W, out=vtok)
-        if fp is not None:
-            vtok = fp.gather_frames(vtok, B, F, H * W)  # every rank steps the full latents (identically)
-        if drop:
-            ops.set_batch_hint(1, 1)
+        try:   # (the last hook site switches the process-global batch hint to (3, 2): restore it on EVERY exit)
+            for blk in self.up_blocks:
+                x, h_, w_ = blk.run(ctx, x, skips, h_, w_)
+            ctx.drop_tail_at = None
+            x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, H * W,
+                              groups=self.conv_norm_out.num_groups, eps=self.conv_norm_out.eps, silu=True)
+            vtok = torch.empty((x.shape[0], 8), dtype=torch.float16, device=x.device)
+            self.conv_out.tokens(x, H, W, out=vtok)
+            if fp is not None:
+                vtok = fp.gather_frames(vtok, B, F, H * W)  # every rank steps the full latents (identically)
+        finally:
+            ctx.drop_tail_at = None
+            if drop:
+                ops.set_batch_hint(1, 1)
         return vtok
 
     def forward(self, sample, timestep, fps=None, image_latents=None, image_embeddings=None,

@@ -7,6 +7,7 @@ import logging
 import os
 import random
 import shutil
+import itertools
 import threading
 from typing import Dict, List, Optional
 
@@ -80,9 +81,12 @@ class LatentTrajectory:
     instead of the reference's blocking ``torch.save`` / ``torch.load`` round trip inside both hot loops.
     ``save`` writes the reference's on-disk format (``ddim_latents_{t}.pt``) from a background thread."""
 
+    _serials = itertools.count(1)
+
     def __init__(self):
         self._lat: Dict[int, torch.Tensor] = {}
         self._writer: Optional[threading.Thread] = None
+        self.serial = next(LatentTrajectory._serials)   # process-unique (``id()`` can be reused after the object is freed)
 
     def __setitem__(self, t, x):
         self._lat[int(t)] = x

@@ -1430,7 +1430,11 @@ def check_source_cache(cfg_name="mini", Fr=4, hw=8, n_steps=6):
     from anyv2v_amd.pipeline import I2VGenXLPipeline
     from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
     out = []
-    native, _, ocfg = build_pair(cfg_name, 1234)
+    if cfg_name == "full":   # (the full-width model without its CPU oracle: this check compares the product with itself)
+        m = full_models("full", 1234, want=("native",))
+        native, ocfg = m["native"], m["ocfg"]
+    else:
+        native, _, ocfg = build_pair(cfg_name, 1234)
     inp = config1_inputs(ocfg, 3, Fr, hw)
     g = lambda x: x.half().to(DEV)
     lat0, ehs, ie, il = g(inp["sample"][:1]), g(inp["encoder_hidden_states"]), g(inp["image_embeddings"]), g(inp["image_latents"])

@@ -571,3 +571,21 @@ def test_native_pipeline_from_raw_inputs_vs_reference_pipeline(cpu_ops, tmp_path
                               ddim_inv_latents_path=job["out_dir"], ddim_inv_prompt="", ddim_inv_1st_frame=frames[0]).frames
     pnp_utils.clear_time(pipe)
     assert close(ed, job["edit_ref"], 3e-2), "sample_with_pnp from raw inputs (reads the reference's ddim_latents_{t}.pt files)"
+
+
+def test_source_feature_cache_byte_budget_and_trajectory_serials():
+    """the multi-edit cache has a byte budget (a step that does not fit is not recorded -> it stays a three-branch step)
+    and is keyed on a process-unique trajectory serial, not on ``id()``."""
+    from anyv2v_amd.pipeline import SourceFeatureCache
+    from anyv2v_amd.utils import LatentTrajectory
+    c = SourceFeatureCache(max_bytes=3 * 1024)
+    f = {"a": torch.zeros(512, dtype=torch.float16)}          # 1 KiB per step
+    assert c.store(981, f) and c.store(961, f) and c.store(941, f)
+    assert not c.store(921, f) and c.skipped_steps == 1 and c.nbytes() == 3 * 1024
+    assert c.has(981, ["a"]) and not c.has(921, ["a"])
+    c.steps[981]["a"].fill_(1)                                 # stored tensors are copies
+    assert float(f["a"].sum()) == 0.0
+    c.bind(("other clip",))
+    assert c.nbytes() == 0 and c.store(921, f)
+    serials = [LatentTrajectory().serial for _ in range(4)]
+    assert len(set(serials)) == 4 and serials == sorted(serials)
