@@ -816,6 +816,237 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Ping-pong persistent kernel (round 4): the long-K workhorse (3x3 / temporal convolutions, FF down-projections).
+//
+// Same block tile family as gemm_big_kernel (64 MF x 320 x 64, 8 waves 4 x 2, two LDS stages filled by LDS-DMA, persistent blocks,
+// cross-tile prefetch, wave-private epilogue), different K-tile: gemm_big_kernel runs both waves of a SIMD through ONE schedule --
+// they issue their LDS-DMA pieces, stall on them and want the matrix pipe at the same moments, and a K-tile costs ~3.5 k cycles
+// against 1.9 k of MFMA work (profiles/r01_gemm_big_trace.txt, r02_gemm_dma_phase_experiment.txt).  Here a K-tile is four PHASES
+// (k-step x column half), each a read slot R (this phase's fragments by ds_read_b128, a share of the next K-tile's LDS-DMA pieces,
+// lgkmcnt(0)) and a matrix slot M (5 MF MFMAs back to back under s_setprio 1), every slot closed by s_barrier -- and waves 4-7 (the
+// SIMD partners of waves 0-3) enter the loop ONE BARRIER LATE.  From then on a SIMD always has one wave in an M slot and its partner
+// in the R slot of the following phase: the matrix pipe sees MFMA blocks back to back while all LDS / DMA issue happens beside them
+// (MI355X_MICROARCH.md "Two waves per SIMD"; cdna_hip_programming.md 5, the 8-phase template's `if (wr == 1) s_barrier`).  The code
+// is the same for both halves -- the offset is a barrier count, not a second schedule -- so hipcc sees one straight-line K-tile.
+//
+// Ordering (b = barrier index as waves 0-3 count them; waves 4-7 execute slot s between barriers s and s + 1):
+//  * RAW, LDS-DMA -> ds_read: the pieces of K-tile kt + 1 are issued in R0 / R1 of K-tile kt and waited for (vmcnt(0)) at the end
+//    of R3 of K-tile kt, BEFORE that slot's barrier, by every issuing wave; the first read of K-tile kt + 1 sits behind at least one
+//    more barrier for every reader (R0 of waves 0-3 follows their M3; waves 4-7 run later still).
+//  * WAR, ds_read -> LDS-DMA: every R slot ends with lgkmcnt(0) before its barrier; the stage that held K-tile kt - 1 is restaged from
+//    R0 of K-tile kt on, i.e. behind the barrier that closed the last R3 of K-tile kt - 1 (waves 4-7) -- all its reads have returned.
+//  * tile switch: waves 0-3 wait one extra barrier (until waves 4-7 are through their last M slot), both halves run their
+//    wave-private epilogues through the consumed stage in the same interval, one barrier, then waves 4-7 fall back by one slot
+//    again.  The next tile's first K-tile was requested during the last K-tile as usual and lies in the other stage.
+template <int MF, int MODE, bool RES>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmK p) {
+    constexpr int BM = 64 * MF, BN = 320;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int SLAB_LD = 160 + 8;                          // halves; 16-byte aligned rows
+    constexpr int SLAB_BYTES = 16 * SLAB_LD * 2;              // per wave
+    static_assert(8 * SLAB_BYTES <= STAGE_BYTES, "epilogue slabs must fit in one pipeline stage");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int grp = __builtin_amdgcn_readfirstlane(w >> 2);   // 0: waves 0-3 (lead), 1: waves 4-7 (one slot behind); an SGPR
+    const int G = gridDim.x;
+    const int b0 = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous
+    const int tilesM = (p.M + BM - 1) / BM;
+    const int ntiles = tilesM * p.tilesN;
+    const int srow0 = tid >> 3, pc = tid & 7, kc = pc ^ (srow0 & 7);
+    const int ntap = p.nt0 + p.nt1;
+    const int nk = p.taps * ntap;
+
+    // ---- producer state (the K-tile being requested: one ahead of the one being multiplied) ----
+    RowInfo ri[4];
+    const half_t* bptr;
+    const size_t brow = (size_t)64 * p.Ktot;
+    AGen<MODE> gen;
+    auto producer_start = [&](int item) {
+        const int mt = item / p.tilesN, nt = item - mt * p.tilesN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ri[i] = make_row<MODE>(p, i < MF ? mt * BM + srow0 + 64 * i : p.M);
+        bptr = p.W + (size_t)(nt * BN + srow0) * p.Ktot + kc * 8;
+        gen.start(p, ri, kc);
+    };
+    auto advance = [&]() {
+        bptr += 64;
+        gen.next(p, ri, kc, ntap);
+    };
+    auto piece = [&](int i, char* st) {   // i: constant after unrolling
+        if (i < MF)
+            glds16(gen.ap[i], st + (i * 512 + w * 64) * 16);
+        else
+            glds16(bptr + (i - MF) * brow, st + A_BYTES + ((i - MF) * 512 + w * 64) * 16);
+    };
+
+    int tile = b0;
+    if (tile >= ntiles) return;
+    producer_start(tile);
+#pragma unroll
+    for (int i = 0; i < MF + 5; ++i) piece(i, smem);
+    advance();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __builtin_amdgcn_s_barrier();         // K-tile 0 of the first tile is in stage 0 for everyone
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: waves 4-7 start one slot late
+    int stage = 0;
+    bool rederive = false;
+    f4 acc[MF][10];
+
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int c0 = ((0 * 4 + lq) ^ (l15 & 7)) * 16, c1 = ((1 * 4 + lq) ^ (l15 & 7)) * 16;
+    const int a_off = (wr * MF * 16 + l15) * 128, b_off = A_BYTES + (wc * 160 + l15) * 128;
+
+    while (true) {
+        const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+        const int m_wave = mt * BM + wr * MF * 16;
+        const int n_wave = nt * BN + wc * 160;
+        const int next_tile = tile + G;
+        const bool has_next = next_tile < ntiles;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (rederive) {
+            producer_start(tile);
+            advance();  // K-tile 0 of this tile was requested during the previous tile's last K-tile
+        }
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last = kt + 1 == nk;
+            if (last && has_next) producer_start(next_tile);  // the pieces below then fetch K-tile 0 of the next tile
+            const bool fetch = !last || has_next;
+            const unsigned sb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(smem + stage * STAGE_BYTES);
+            char* st = smem + (stage ^ 1) * STAGE_BYTES;
+            const unsigned abase[2] = {sb + a_off + c0, sb + a_off + c1};
+            const unsigned bbase[2] = {sb + b_off + c0, sb + b_off + c1};
+            h8 af[MF], bf[5];
+#define AV_PP_SLOT_END()                           \
+    __builtin_amdgcn_sched_barrier(0);             \
+    __builtin_amdgcn_s_barrier();                  \
+    __builtin_amdgcn_sched_barrier(0)
+#define AV_PP_READS(KS, NH, WITH_A)                                                              \
+    if (WITH_A) {                                                                                \
+        _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) af[mf] = lds_frag(abase[KS], mf * 2048); \
+    }                                                                                            \
+    _Pragma("unroll") for (int nf = 0; nf < 5; ++nf) bf[nf] = lds_frag(bbase[KS], ((NH) * 5 + nf) * 2048)
+#define AV_PP_MFMAS(NH)                                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
+    AV_PP_SLOT_END();                                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                                              \
+    _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                                           \
+        _Pragma("unroll") for (int nf = 0; nf < 5; ++nf)                                                                        \
+            acc[mf][(NH) * 5 + nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nf], af[mf], acc[mf][(NH) * 5 + nf], 0, 0, 0);   \
+    __builtin_amdgcn_s_setprio(0);                                                                                              \
+    AV_PP_SLOT_END()
+            // (in every R slot the DMA issue / address arithmetic comes FIRST and the asm fragment reads last, directly in front of
+            //  their wait: nothing that needs registers may sit between an asm read and its lgkmcnt -- hipcc would be free to spill
+            //  a destination that has not arrived yet, tests/test_isa_guards.py)
+            // ---- phase 0: k-step 0, columns 0..79 of the wave tile; pieces A0 .. A(MF-1), W0 of the next K-tile
+            if (fetch) {
+#pragma unroll
+                for (int i = 0; i < MF + 1; ++i) piece(i, st);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            AV_PP_READS(0, 0, true);
+            AV_PP_MFMAS(0);
+            // ---- phase 1: k-step 0, columns 80..159; pieces W1 .. W4
+            if (fetch) {
+#pragma unroll
+                for (int i = MF + 1; i < MF + 5; ++i) piece(i, st);
+                advance();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            AV_PP_READS(0, 1, false);
+            AV_PP_MFMAS(1);
+            // ---- phase 2: k-step 1, columns 0..79
+            AV_PP_READS(1, 0, true);
+            AV_PP_MFMAS(0);
+            // ---- phase 3: k-step 1, columns 80..159; the next K-tile has landed (this wave's pieces) before the slot's barrier
+            AV_PP_READS(1, 1, false);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            AV_PP_MFMAS(1);
+#undef AV_PP_READS
+#undef AV_PP_MFMAS
+            stage ^= 1;
+        }
+        // `stage` now names the buffer holding the prefetched K-tile 0 of the next tile; stage ^ 1 was just consumed
+        constexpr int CPRW = 160 / 8;                 // 16-byte chunks per slab row
+        constexpr int NIT = (16 * CPRW + 63) / 64;    // store iterations per slab (5)
+        h8 rr[RES ? 2 : 1][NIT];
+        int lane_r = lane;
+        asm volatile("" : "+v"(lane_r));              // (keeps the epilogue's address math out of the K loop's live ranges)
+        auto load_res = [&](int mf) {                 // residual rows of slab mf (rows past M: clamped, never stored)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 64 + lane_r;
+                const int row = c / CPRW, cc = c - row * CPRW;
+                int m = m_wave + mf * 16 + row;
+                m = m < p.M ? m : p.M - 1;
+                rr[mf & 1][it] = *(const h8*)(p.R + (size_t)m * p.ldr + n_wave + cc * 8);
+            }
+        };
+        if constexpr (RES) {
+            load_res(0);
+            load_res(1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0) __builtin_amdgcn_s_barrier();   // waves 4-7 are in their last M slot; their last reads were waited for two barriers ago
+        __builtin_amdgcn_sched_barrier(0);
+        rederive = true;
+
+        // ---------------- wave-private epilogue: MF slabs of 16 rows x 160 output columns through the consumed stage ----------------
+        const int l15e = lane_r & 15, lqe = lane_r >> 4;
+        half_t* const slab = (half_t*)(smem + (stage ^ 1) * STAGE_BYTES + w * SLAB_BYTES);
+        h4 bvec[10];
+#pragma unroll
+        for (int nf = 0; nf < 10; ++nf)
+            bvec[nf] = *(const h4*)(p.bias != nullptr ? p.bias + n_wave + nf * 16 + 4 * lqe : p.zeros);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const bool has_rv = p.rowvec != nullptr;
+            const int mrow = m_wave + mf * 16 + l15e;
+            const half_t* rv = has_rv ? p.rowvec + (size_t)((mrow < p.M ? mrow : 0) / p.rowvec_div) * p.ldrv + n_wave + 4 * lqe : p.zeros;
+#pragma unroll
+            for (int nf = 0; nf < 10; ++nf) {
+                h4 tv = (h4){0, 0, 0, 0};
+                if (has_rv) tv = *(const h4*)(rv + nf * 16);
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[mf][nf][r] + (float)bvec[nf][r] + (float)tv[r]);
+                *(h4*)(slab + l15e * SLAB_LD + nf * 16 + 4 * lqe) = o;
+            }
+            h8 v[NIT];
+            bool ok[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 64 + lane_r;
+                const int row = c / CPRW, cc = c - row * CPRW;
+                ok[it] = m_wave + mf * 16 + row < p.M;
+                v[it] = *(const h8*)(slab + row * SLAB_LD + cc * 8);
+                if constexpr (RES) v[it] = v[it] + rr[mf & 1][it];  // fp16 add: correctly rounded, == the fp32 add + rounding of two fp16 values
+            }
+            if constexpr (RES) {
+                if (mf + 2 < MF) load_res(mf + 2);   // requested BEFORE this slab's stores: its wait will not have to drain them
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 64 + lane_r;
+                const int row = c / CPRW, cc = c - row * CPRW;
+                if (ok[it]) *(h8*)(p.C + (size_t)(m_wave + mf * 16 + row) * p.ldc + n_wave + cc * 8) = v[it];
+            }
+        }
+        if (!has_next) break;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the slab read-backs feed the stores above; belt and braces)
+        __builtin_amdgcn_s_barrier();                  // both halves are done with the consumed stage: it may be restaged
+        if (grp == 1) __builtin_amdgcn_s_barrier();    // waves 4-7 fall one slot behind again
+        __builtin_amdgcn_sched_barrier(0);
+        tile = next_tile;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Reference-grade kernel: one thread per output element, any shape.  Used for the tiny once-per-clip
 // conditioning layers (Cin = 4/16/32 ...) and as the on-device cross-check of the MFMA kernels in the tests.
 template <int MODE>
@@ -923,6 +1154,9 @@ static const half_t* zero_line() {
     return z;
 }
 
+// K-tiles (of 64) from which the ping-pong kernel is taken by default (its tile switch costs two barriers more than gemm_big_kernel's)
+constexpr int AV_PP_MIN_KTILES = 1 << 30;   // TODO(measure): off by default until the A/B is in
+
 template <int MODE>
 static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s) {
     const bool geglu = d->act == ACT_GEGLU;
@@ -1016,6 +1250,30 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k);
             return av_launch_status("gemm_big<split-K>");
+        }
+        // Ping-pong kernel (gemm_pp_kernel) for the long-K launches: flags bit17 forces it where the shape allows, bit18 forbids it,
+        // bit19 / bit20 force 192- / 256-row tiles (default: the taller tile unless it quantises worse onto the 256 CUs).
+        if (!geglu && !(d->flags & (1 << 18)) && ((d->flags & (1 << 17)) || nk_all >= AV_PP_MIN_KTILES)) {
+            auto eff = [&](int bm) {
+                const int tb = ((d->M + bm - 1) / bm) * (d->N / 320), r = (tb + 255) / 256;
+                return (double)tb / (r * 256.0);
+            };
+            const int mf = (d->flags & (1 << 19)) ? 3 : ((d->flags & (1 << 20)) ? 4 : (eff(256) + 0.02 >= eff(192) ? 4 : 3));
+            const int tb = ((d->M + 64 * mf - 1) / (64 * mf)) * (d->N / 320);
+            const dim3 gridp(tb < 256 ? tb : 256);
+#define AV_PP(MF_)                                                                                        \
+    do {                                                                                                  \
+        if (d->R != nullptr)                                                                              \
+            hipLaunchKernelGGL((gemm_pp_kernel<MF_, MODE, true>), gridp, dim3(512), 0, s, k);             \
+        else                                                                                              \
+            hipLaunchKernelGGL((gemm_pp_kernel<MF_, MODE, false>), gridp, dim3(512), 0, s, k);            \
+    } while (0)
+            if (mf == 4)
+                AV_PP(4);
+            else
+                AV_PP(3);
+#undef AV_PP
+            return av_launch_status("gemm_pp");
         }
         const dim3 grid(tiles_big < 256 ? tiles_big : 256);
         {   // tile order of wide-N launches (gemm_big_kernel): 8 x 4 super-tiles per XCD round when N has >= 8 tiles (the GEGLU

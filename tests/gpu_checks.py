@@ -164,12 +164,14 @@ def check_gemm(variants=("reg", "glds", "naive")):
     return out
 
 
-def check_gemm_big():
+def check_gemm_big(extra=0, tag="big"):
     """Persistent 256x320 kernel (gemm_big_kernel), forced with flag bit3 on shapes small enough for the references:
-    single / multiple rounds per block, every mode, two-source K loop, bias / temb / residual / GEGLU epilogues."""
+    single / multiple rounds per block, every mode, two-source K loop, bias / temb / residual / GEGLU epilogues.
+    ``extra``: further AnyV2VGemmDesc.flags bits, e.g. bit17 (| bit19 / bit20) = the ping-pong kernel gemm_pp_kernel (192- / 256-row
+    tiles) on every non-GEGLU case -- same references, same bit-equality with the 128-row kernel."""
     out = []
     saved = ops.GEMM_FLAGS
-    ops.GEMM_FLAGS = (saved & ~4) | 8
+    ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
     try:
         for (M, N, K, res, rvd) in [(512, 320, 320, True, 0), (1024, 640, 192, False, 128), (256, 960, 64, True, 256),
                                     (256 * 41, 2560, 128, True, 0), (256 * 300, 320, 64, False, 0)]:
@@ -177,20 +179,20 @@ def check_gemm_big():
             r = rnd(M, N) if res else None
             rv = rnd(M // rvd, N) if rvd else None
             y = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r)
-            out.append(_res(f"gemm[big] M{M} N{N} K{K} res={res} rowvec={bool(rvd)}", y, _gemm_ref(a, w, bias, rv, rvd, r), KTOL))
+            out.append(_res(f"gemm[{tag}] M{M} N{N} K{K} res={res} rowvec={bool(rvd)}", y, _gemm_ref(a, w, bias, rv, rvd, r), KTOL))
             yn = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r, naive=True)
-            out.append(_res(f"gemm[big] == naive kernel M{M} N{N} K{K}", y, yn.float(), 2e-3))
+            out.append(_res(f"gemm[{tag}] == naive kernel M{M} N{N} K{K}", y, yn.float(), 2e-3))
             # the two tile-kernel families accumulate every output element in the same order: BIT-equal without split-K (what lets a
             # batch-hinted launch keep its own kernel family and only take the reference launch's split factor, gemm.hip dispatch)
             ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
             ys = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r)
-            ops.GEMM_FLAGS = (saved & ~4) | 8
-            out.append(_res(f"gemm[big] bit-equal to the 128-row kernel M{M} N{N} K{K}", y, ys.float(), 0.0))
+            ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
+            out.append(_res(f"gemm[{tag}] bit-equal to the 128-row kernel M{M} N{N} K{K}", y, ys.float(), 0.0))
         # two-source K loop (skip concat)
         a0, a1 = rnd(768, 128), rnd(768, 64)
         w = rnd(320, 192, scale=0.1)
         y = ops.gemm(a0, w, a1=a1)
-        out.append(_res("gemm[big] two-source", y, _gemm_ref(torch.cat([a0, a1], 1), w), KTOL))
+        out.append(_res(f"gemm[{tag}] two-source", y, _gemm_ref(torch.cat([a0, a1], 1), w), KTOL))
         # GEGLU, one and several rounds
         for M in (512, 256 * 70):
             dim, inner = 128, 640
@@ -201,23 +203,23 @@ def check_gemm_big():
             bp = torch.stack([bfull[:inner].view(-1, 16), bfull[inner:].view(-1, 16)], 1).reshape(-1).contiguous()
             y = ops.gemm(a, wp, bias=bp, act=ops.ACT_GEGLU)
             proj = a.float() @ wfull.float().t() + bfull.float()
-            out.append(_res(f"gemm[big] GEGLU M{M}", y, proj[:, :inner] * F.gelu(proj[:, inner:]), KTOL))
+            out.append(_res(f"gemm[{tag}] GEGLU M{M}", y, proj[:, :inner] * F.gelu(proj[:, inner:]), KTOL))
         # rastered tile order of wide-N launches (8 x 4 super-tiles per XCD round; flags bits 13-16): every order computes each
         # output tile with the same K loop -> BIT-equal to the classic order; ragged M (holes in the last super-tile row),
         # plain and GEGLU epilogues, a forced order on a launch the auto rule would leave alone
         for (M, N, K, geglu) in [(192 * 40 + 70, 2560, 128, False), (192 * 16, 5120, 64, True), (192 * 33, 2560, 64, True)]:
             a, w, bias = rnd(M, K), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
             act = ops.ACT_GEGLU if geglu else ops.ACT_NONE
-            ops.GEMM_FLAGS = ((saved & ~4) | 8) | (1 << 13)
+            ops.GEMM_FLAGS = ((saved & ~4) | 8 | extra) | (1 << 13)
             y0 = ops.gemm(a, w, bias=bias, act=act)
             yn = ops.gemm(a, w, bias=bias, act=act, naive=True)
-            out.append(_res(f"gemm[big] classic order == naive kernel M{M} N{N} K{K} geglu={geglu}", y0, yn.float(), 2e-3))
+            out.append(_res(f"gemm[{tag}] classic order == naive kernel M{M} N{N} K{K} geglu={geglu}", y0, yn.float(), 2e-3))
             for code, nfast in ((0, 0), (2, 0), (3, 0), (3, 1), (4, 0), (5, 1), (6, 0)):
-                ops.GEMM_FLAGS = ((saved & ~4) | 8) | (code << 13) | (nfast << 16)
+                ops.GEMM_FLAGS = ((saved & ~4) | 8 | extra) | (code << 13) | (nfast << 16)
                 y = ops.gemm(a, w, bias=bias, act=act)
-                out.append(_res(f"gemm[big] raster code {code} nfast {nfast} bit-equal to the classic order M{M} N{N} geglu={geglu}", y,
+                out.append(_res(f"gemm[{tag}] raster code {code} nfast {nfast} bit-equal to the classic order M{M} N{N} geglu={geglu}", y,
                                 y0.float(), 0.0))
-            ops.GEMM_FLAGS = (saved & ~4) | 8
+            ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
         # conv 3x3 (stride 1, stride 2, folded upsample) with temb row vector / residual
         n, ci, co, H, W = 8, 64, 320, 16, 16
         x, w, b = rnd(n, ci, H, W), rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
@@ -225,25 +227,25 @@ def check_gemm_big():
         y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=2 * H * W, residual=res,
                      mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0))
         ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + temb.float().repeat_interleave(2, 0)[:, :, None, None]
-        out.append(_res("conv3x3[big] s1 +bias+temb+res", y, _to_tokens(ref) + res.float(), KTOL))
+        out.append(_res(f"conv3x3[{tag}] s1 +bias+temb+res", y, _to_tokens(ref) + res.float(), KTOL))
         ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
         ys = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=2 * H * W, residual=res, mode=ops.MODE_CONV2D,
                       conv=(H, W, H, W, 1, 0))
-        ops.GEMM_FLAGS = (saved & ~4) | 8
-        out.append(_res("conv3x3[big] bit-equal to the 128-row kernel", y, ys.float(), 0.0))
+        ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
+        out.append(_res(f"conv3x3[{tag}] bit-equal to the 128-row kernel", y, ys.float(), 0.0))
         y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, H // 2, W // 2, 2, 0),
                      M=n * (H // 2) * (W // 2))
-        out.append(_res("conv3x3[big] stride 2", y, _to_tokens(F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1)), KTOL))
+        out.append(_res(f"conv3x3[{tag}] stride 2", y, _to_tokens(F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1)), KTOL))
         y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, 2 * H, 2 * W, 1, 1),
                      M=n * 4 * H * W)
         ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
-        out.append(_res("conv3x3[big] nearest-x2 folded", y, _to_tokens(ref), KTOL))
+        out.append(_res(f"conv3x3[{tag}] nearest-x2 folded", y, _to_tokens(ref), KTOL))
         # two-source conv (up-block skip concat)
         x1 = rnd(n, 128, H, W)
         w2 = rnd(co, ci + 128, 3, 3, scale=1 / math.sqrt(9 * (ci + 128)))
         y = ops.gemm(_to_tokens(x), _pack_conv(w2), a1=_to_tokens(x1), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, H, W, 1, 0))
         ref = F.conv2d(torch.cat([x, x1], 1).float(), w2.float(), b.float(), padding=1)
-        out.append(_res("conv3x3[big] two-source", y, _to_tokens(ref), KTOL))
+        out.append(_res(f"conv3x3[{tag}] two-source", y, _to_tokens(ref), KTOL))
         # temporal (3,1,1) conv with residual
         B_, Fr, HW, C = 2, 8, 64, 128
         xt = rnd(B_ * Fr * HW, C)
@@ -253,7 +255,37 @@ def check_gemm_big():
         x5 = xt.float().view(B_, Fr, HW, C).permute(0, 3, 1, 2)  # [B, C, F, HW]
         ref = F.conv1d(x5.permute(0, 3, 1, 2).reshape(B_ * HW, C, Fr), wt.float(), bt.float(), padding=1)
         ref = ref.view(B_, HW, 320, Fr).permute(0, 3, 1, 2).reshape(B_ * Fr * HW, 320) + rt.float()
-        out.append(_res("temporal conv[big] +res", y, ref, KTOL))
+        out.append(_res(f"temporal conv[{tag}] +res", y, ref, KTOL))
+        # more output tiles than CUs AND several K-tiles per tile: the persistent loop's tile switch with a live LDS-DMA pipeline
+        # (conv 3x3 + temb + residual over 72 images of 32 x 32: 288 / 384 tiles, 9 K-tiles; temporal conv: 300 / 400 tiles, 6 K-tiles)
+        n, ci, co, H, W = 72, 64, 320, 32, 32
+        x, w, b = rnd(n, ci, H, W), rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
+        temb, res = rnd(n // 8, co), rnd(n * H * W, co)
+        for r_ in (res, None):
+            y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=8 * H * W, residual=r_, mode=ops.MODE_CONV2D,
+                         conv=(H, W, H, W, 1, 0))
+            ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + temb.float().repeat_interleave(8, 0)[:, :, None, None]
+            out.append(_res(f"conv3x3[{tag}] 288+ tiles x 9 K-tiles res={r_ is not None}", y, _to_tokens(ref) + (r_.float() if r_ is not None else 0.0), KTOL))
+            ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
+            ys = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=8 * H * W, residual=r_, mode=ops.MODE_CONV2D,
+                          conv=(H, W, H, W, 1, 0))
+            ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
+            out.append(_res(f"conv3x3[{tag}] 288+ tiles bit-equal to the 128-row kernel res={r_ is not None}", y, ys.float(), 0.0))
+        B_, Fr, HW, C = 3, 16, 1600, 128
+        xt = rnd(B_ * Fr * HW, C)
+        wt, bt, rt = rnd(320, C, 3, scale=1 / math.sqrt(3 * C)), rnd(320), rnd(B_ * Fr * HW, 320)
+        y = ops.gemm(xt, wt.permute(0, 2, 1).reshape(320, 3 * C).contiguous(), bias=bt, residual=rt, mode=ops.MODE_TEMPORAL, temporal=(Fr, HW))
+        ref = F.conv1d(xt.float().view(B_, Fr, HW, C).permute(0, 2, 3, 1).reshape(B_ * HW, C, Fr), wt.float(), bt.float(), padding=1)
+        ref = ref.view(B_, HW, 320, Fr).permute(0, 3, 1, 2).reshape(B_ * Fr * HW, 320) + rt.float()
+        out.append(_res(f"temporal conv[{tag}] 300+ tiles x 6 K-tiles +res", y, ref, KTOL))
+        a, w2, bb = rnd(256 * 300 + 40, 1280), rnd(640, 1280, scale=1 / math.sqrt(1280)), rnd(640)
+        r2 = rnd(256 * 300 + 40, 640)
+        y = ops.gemm(a, w2, bias=bb, residual=r2)
+        out.append(_res(f"gemm[{tag}] FF-down shape 76840 x 640 x 1280 +res (ragged M)", y, _gemm_ref(a, w2, bb, None, 0, r2), KTOL))
+        ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
+        ys = ops.gemm(a, w2, bias=bb, residual=r2)
+        ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
+        out.append(_res(f"gemm[{tag}] FF-down shape bit-equal to the 128-row kernel", y, ys.float(), 0.0))
     finally:
         ops.GEMM_FLAGS = saved
     return out

@@ -29,6 +29,14 @@ def test_gemm_persistent_big_tile():
     _assert_all(gc.check_gemm_big())
 
 
+@pytest.mark.parametrize("rows", [192, 256])
+def test_gemm_pingpong_kernel(rows):
+    """gemm_pp_kernel (round 4: the two waves of a SIMD run the K-tile's read / matrix slots one barrier apart), forced onto every
+    non-GEGLU case of the persistent-kernel check with 192- and 256-row tiles: torch fp32 references, the naive kernel, and BIT-equality
+    with the 128-row kernel (same MFMA shape, same K order), incl. launches with more tiles than CUs and several K-tiles per tile."""
+    _assert_all(gc.check_gemm_big((1 << 17) | ((1 << 19) if rows == 192 else (1 << 20)), tag=f"pp{rows}"))
+
+
 def test_gemm_weight_stationary_k320():
     _assert_all(gc.check_gemm_ws())
 
