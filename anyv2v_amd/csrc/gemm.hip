@@ -1154,8 +1154,13 @@ static const half_t* zero_line() {
     return z;
 }
 
-// K-tiles (of 64) from which the ping-pong kernel is taken by default (its tile switch costs two barriers more than gemm_big_kernel's)
-constexpr int AV_PP_MIN_KTILES = 1 << 30;   // TODO(measure): off by default until the A/B is in
+// K-tiles (of 64) from which the ping-pong kernel would be taken by default.  Measured (profiles/r04_gemm_pp_ab_v1_*.txt, interleaved A/B
+// on the edit step's launches): its K loop is 2-6 % faster than gemm_big_kernel's from K = 5760 on (conv 960->320 @64x64 898 -> 845 us,
+// 1.21 -> 1.29 PF), equal at K = 2880, and its tile switch costs more (residual launches 10-30 % slower; temporal convolutions,
+// FF-down slower) -- the R slots, not the M slots, set the slot time (9 LDS-DMA issues per wave and K-tile).  The launches it wins sum
+// to 0.25 ms of the 106 ms step pair, so it stays OFF by default (flags bit17 selects it: tests, A/B); a second form with the next
+// tile's start-up hoisted in front of the tile-switch barrier was slower throughout (r04_gemm_pp_ab_v2_*.txt, not kept).
+constexpr int AV_PP_MIN_KTILES = 1 << 30;
 
 template <int MODE>
 static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s) {

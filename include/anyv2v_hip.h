@@ -68,8 +68,10 @@ typedef struct AnyV2VGemmDesc {
                             below its M >= 32768 threshold; bit11 (2048) / bit12 (4096): 128-column / 160-column tiles in the
                             128-row kernel regardless of the fill heuristic; bits 13-15: tile order of the persistent kernel on
                             wide-N launches (0 auto, 1 classic N-fastest, 2..6 super-tiles of 4 / 8 / 16 / 32 / 2 M-tiles per XCD
-                            round), bit16: super-tiles walked N-fastest -- every order gives bit-identical results.  All other
-                            bits are ignored by the product library. */
+                            round), bit16: super-tiles walked N-fastest -- every order gives bit-identical results; bit17: take the
+                            ping-pong persistent kernel wherever the shape allows (N % 320 = 0, no GEGLU), bit18: never take it,
+                            bit19 / bit20: its 192- / 256-row tile (bit-identical to the other tile kernels).  All other bits are
+                            ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
     /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock.norm1/2/3 -> attn.to_q/k/v / ff.net[0].proj,
