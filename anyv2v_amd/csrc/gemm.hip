@@ -1158,7 +1158,8 @@ static const half_t* zero_line() {
 // on the edit step's launches): its K loop is 2-6 % faster than gemm_big_kernel's from K = 5760 on (conv 960->320 @64x64 898 -> 845 us,
 // 1.21 -> 1.29 PF), equal at K = 2880, and its tile switch costs more (residual launches 10-30 % slower; temporal convolutions,
 // FF-down slower) -- the R slots, not the M slots, set the slot time (9 LDS-DMA issues per wave and K-tile).  The launches it wins sum
-// to 0.25 ms of the 106 ms step pair, so it stays OFF by default (flags bit17 selects it: tests, A/B); a second form with the next
+// to 0.25 ms of the 106 ms step pair (+ 0.08 ms on the inversion step's one-round launches, M = 65536 with 256-row tiles: conv 960->320
+// 322 -> 298 us, r04_gemm_pp_ab_v1_b1_*.txt), so it stays OFF by default (flags bit17 selects it: tests, A/B); a second form with the next
 // tile's start-up hoisted in front of the tile-switch barrier was slower throughout (r04_gemm_pp_ab_v2_*.txt, not kept).
 constexpr int AV_PP_MIN_KTILES = 1 << 30;
 
@@ -1242,6 +1243,33 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         else if (use.splits > 1)
             use = Plan{0, 1};
     }
+    // Ping-pong kernel (gemm_pp_kernel): flags bit17 takes it wherever the shape allows, bit18 forbids it, bit19 / bit20 force its
+    // 192- / 256-row tile (default: the taller tile unless it quantises worse onto the 256 CUs).  Not split along K (the launches
+    // that want that are too small for it), so a batch-hinted launch may only take it when its reference launch is unsplit too.
+    if (big_ok && !geglu && use.splits == 1 && !(d->flags & (1 << 18)) &&
+        ((d->flags & (1 << 17)) || (use.big && nk_all >= AV_PP_MIN_KTILES))) {
+        auto eff = [&](int bm) {
+            const int tb = ((d->M + bm - 1) / bm) * (d->N / 320), r = (tb + 255) / 256;
+            return (double)tb / (r * 256.0);
+        };
+        const int mf = (d->flags & (1 << 19)) ? 3 : ((d->flags & (1 << 20)) ? 4 : (eff(256) + 0.02 >= eff(192) ? 4 : 3));
+        const int tb = ((d->M + 64 * mf - 1) / (64 * mf)) * (d->N / 320);
+        const dim3 gridp(tb < 256 ? tb : 256);
+        k.tilesN = d->N / 320;
+#define AV_PP(MF_)                                                                                        \
+    do {                                                                                                  \
+        if (d->R != nullptr)                                                                              \
+            hipLaunchKernelGGL((gemm_pp_kernel<MF_, MODE, true>), gridp, dim3(512), 0, s, k);             \
+        else                                                                                              \
+            hipLaunchKernelGGL((gemm_pp_kernel<MF_, MODE, false>), gridp, dim3(512), 0, s, k);            \
+    } while (0)
+        if (mf == 4)
+            AV_PP(4);
+        else
+            AV_PP(3);
+#undef AV_PP
+        return av_launch_status("gemm_pp");
+    }
     if (use.big) {
         const int tiles_big = ((d->M + BMB - 1) / BMB) * (d->N / 320);
         k.tilesN = d->N / 320;
@@ -1255,30 +1283,6 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k);
             return av_launch_status("gemm_big<split-K>");
-        }
-        // Ping-pong kernel (gemm_pp_kernel) for the long-K launches: flags bit17 forces it where the shape allows, bit18 forbids it,
-        // bit19 / bit20 force 192- / 256-row tiles (default: the taller tile unless it quantises worse onto the 256 CUs).
-        if (!geglu && !(d->flags & (1 << 18)) && ((d->flags & (1 << 17)) || nk_all >= AV_PP_MIN_KTILES)) {
-            auto eff = [&](int bm) {
-                const int tb = ((d->M + bm - 1) / bm) * (d->N / 320), r = (tb + 255) / 256;
-                return (double)tb / (r * 256.0);
-            };
-            const int mf = (d->flags & (1 << 19)) ? 3 : ((d->flags & (1 << 20)) ? 4 : (eff(256) + 0.02 >= eff(192) ? 4 : 3));
-            const int tb = ((d->M + 64 * mf - 1) / (64 * mf)) * (d->N / 320);
-            const dim3 gridp(tb < 256 ? tb : 256);
-#define AV_PP(MF_)                                                                                        \
-    do {                                                                                                  \
-        if (d->R != nullptr)                                                                              \
-            hipLaunchKernelGGL((gemm_pp_kernel<MF_, MODE, true>), gridp, dim3(512), 0, s, k);             \
-        else                                                                                              \
-            hipLaunchKernelGGL((gemm_pp_kernel<MF_, MODE, false>), gridp, dim3(512), 0, s, k);            \
-    } while (0)
-            if (mf == 4)
-                AV_PP(4);
-            else
-                AV_PP(3);
-#undef AV_PP
-            return av_launch_status("gemm_pp");
         }
         const dim3 grid(tiles_big < 256 ? tiles_big : 256);
         {   // tile order of wide-N launches (gemm_big_kernel): 8 x 4 super-tiles per XCD round when N has >= 8 tiles (the GEGLU
