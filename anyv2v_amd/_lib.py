@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libanyv2v_hip.so")
-ABI_VERSION = 101   # ANYV2V_ABI_VERSION of include/anyv2v_hip.h the structures below mirror
+ABI_VERSION = 102   # ANYV2V_ABI_VERSION of include/anyv2v_hip.h the structures below mirror
 
 
 class HipExtensionMissing(RuntimeError):
@@ -36,6 +36,14 @@ class GemmDesc(C.Structure):
     ]
 
 
+class FFDesc(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("R", C.c_void_p),
+        ("Y", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("ldx", C.c_int32), ("ldr", C.c_int32),
+        ("ldy", C.c_int32), ("flags", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
@@ -52,6 +60,7 @@ class AttnDesc(C.Structure):
 _VP, _I32, _I64, _F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "anyv2v_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _VP]),
+    "anyv2v_ff_geglu_f16": (C.c_int, [C.POINTER(FFDesc), _VP]),
     "anyv2v_groupnorm_f16": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _F32, _I32, _VP]),
     "anyv2v_groupnorm_scratch_floats": (C.c_int64, [_I32, _I32, _I32]),
     "anyv2v_groupnorm_partial_floats": (C.c_int64, [_I32, _I32, _I32, _I32]),

@@ -110,6 +110,46 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     return out
 
 
+FF_FUSED = os.environ.get("ANYV2V_FF_FUSED", "1") == "1"   # A/B switch: fused feed-forward kernel (ff_fused.hip) vs GEGLU GEMM + Linear
+
+
+def ff_fused_supported(M: int, C: int, H: int) -> bool:
+    """Shapes the fused feed-forward kernel covers AND pays on: the 320-channel transformer blocks at the 64x64 level's row counts
+    (same threshold, on hinted rows, as the weight-stationary GEMMs it replaces)."""
+    return FF_FUSED and not FORCE_NAIVE and USE_GLDS and C == 320 and H == 1280 and M * _HINT[0] // _HINT[1] >= 32768
+
+
+def ff_pack_w2(w2: torch.Tensor) -> torch.Tensor:
+    """``Linear(H, C).weight`` [C, H] -> the fused kernel's layout [H / 32][C][32]: slab-major, and inside a slab of 32 hidden units
+    column 8 q + e holds hidden unit 4 q + e (e < 4) or 16 + 4 q + (e - 4) (e >= 4) -- the MFMA K-slot order in which the kernel's
+    GEGLU registers already hold the hidden values (include/anyv2v_hip.h, AnyV2VFFDesc)."""
+    C, H = w2.shape
+    assert H % 32 == 0
+    q, e = torch.arange(4).view(4, 1), torch.arange(8).view(1, 8)
+    perm = torch.where(e < 4, 4 * q + e, 16 + 4 * q + (e - 4)).reshape(32).to(w2.device)   # slot -> hidden unit of the slab
+    return w2.view(C, H // 32, 32)[:, :, perm].permute(1, 0, 2).contiguous()
+
+
+def ff_geglu(x: torch.Tensor, w1p: torch.Tensor, b1p: torch.Tensor, w2s: torch.Tensor, b2: torch.Tensor, residual=None, out=None):
+    """y = GEGLU(x W1^T + b1) W2^T + b2 (+ residual) in one kernel (``anyv2v_ff_geglu_f16``); ``w1p`` / ``b1p`` as ``GEGLU.pack``
+    interleaves them, ``w2s`` from ``ff_pack_w2``."""
+    lib = _lib.load()
+    M, Cc = x.shape
+    H = w2s.shape[0] * 32
+    assert x.dtype == torch.float16 and x.stride(1) == 1 and w1p.is_contiguous() and w2s.is_contiguous()
+    assert tuple(w1p.shape) == (2 * H, Cc) and tuple(w2s.shape) == (H // 32, Cc, 32) and b1p.numel() == 2 * H and b2.numel() == Cc
+    if out is None:
+        out = torch.empty((M, Cc), dtype=torch.float16, device=x.device)
+    d = _lib.FFDesc()
+    d.X, d.W1, d.b1, d.W2, d.b2, d.Y = _p(x), _p(w1p), _p(b1p), _p(w2s), _p(b2), _p(out)
+    d.R = _p(residual) if residual is not None else None
+    d.M, d.C, d.H = M, Cc, H
+    d.ldx, d.ldy, d.ldr = x.stride(0), out.stride(0), (residual.stride(0) if residual is not None else 0)
+    d.flags = d.reserved0 = 0
+    _lib.check(lib.anyv2v_ff_geglu_f16(C.byref(d), _stream()), "anyv2v_ff_geglu_f16")
+    return out
+
+
 def ln_gemm_supported(M: int, K: int, N: int, act: int = ACT_NONE, hinted: bool = True) -> bool:
     """Shapes for which ``gemm(..., ln=...)`` runs (the weight-stationary kernel, gemm_ws.hip) AND pays: the 64x64 level's row
     counts.  Mirrors the library's own check; everything else runs ``layernorm`` + ``gemm``.  ``hinted=False``: ``M`` is already a

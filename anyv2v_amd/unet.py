@@ -386,7 +386,16 @@ class FeedForward(nn.Module):
         act = GEGLU(dim, inner_dim) if self.geglu else GELUProj(dim, inner_dim)
         self.net = nn.ModuleList([act, Identity(), Linear(inner_dim, dim)])
 
+    def pack(self):
+        """The fused feed-forward kernel's layout of the down-projection (``ops.ff_pack_w2``), for the width it covers."""
+        lin = self.net[2]
+        self._w2s = ops.ff_pack_w2(lin.weight.data) if (self.geglu and tuple(lin.weight.shape) == (320, 1280)) else None
+
     def run(self, h, residual, ln_in=None):
+        w2s = getattr(self, "_w2s", None)
+        if ln_in is None and w2s is not None and ops.ff_fused_supported(h.shape[0], h.shape[1], w2s.shape[0] * 32):
+            # GEGLU up-projection + down-projection + residual in ONE kernel: the [tokens, 1280] hidden never reaches HBM
+            return ops.ff_geglu(h, self.net[0]._w, self.net[0]._b, w2s, self.net[2].bias, residual=residual)
         if ln_in is not None:   # LayerNorm folded into the GEGLU up-projection (BasicTransformerBlock.pack)
             x, (w_in, b_in, c1_in), ln_eps = ln_in
             g = ops.gemm(x, w_in, bias=b_in, act=ACT_GEGLU, ln=(c1_in, ln_eps))

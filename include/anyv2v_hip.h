@@ -88,6 +88,32 @@ typedef struct AnyV2VGemmDesc {
 
 int anyv2v_gemm_f16(const AnyV2VGemmDesc* d, void* stream);
 
+/* ---- fused feed-forward ----------------------------------------------------------------------
+ * Y = GEGLU(X W1^T + b1) W2^T + b2 (+ R): the FeedForward of BasicTransformerBlock (diffusers-0.26.3 `FeedForward(dim,
+ * activation_fn="geglu")` behind pipeline_i2vgen_xl.py:1146; in-tree restatement consisti2v/consisti2v/models/
+ * videoldm_transformer_blocks.py:545-563) in one kernel -- the [M, H] hidden activation never reaches HBM.  Implemented for
+ * C = 320, H = 1280 (the 64x64 level); anything else returns ANYV2V_EUNSUPPORTED and the caller runs the two GEMMs.
+ *   W1 [2 H][C], b1 [2 H]: rows interleaved [16 x h | 16 x gate] per 32 (the act = 3 packing of anyv2v_gemm_f16);
+ *   W2 [H / 32][C][32]   : slab-major; inside a slab of 32 hidden units, column 8 q + e (q = 0..3) holds hidden unit 4 q + e for
+ *                          e < 4 and 16 + 4 q + (e - 4) for e >= 4 (the MFMA K-slot order the kernel produces the hidden values in);
+ *   b2 [C]; R [M][ldr] or NULL; X [M][ldx]; Y [M][ldy].  fp32 accumulation, the hidden value rounded to fp16 once, Y = fp16(acc + b2)
+ *   then + R in fp16 (the rounding points of the unfused GEGLU GEMM + Linear pair). */
+typedef struct AnyV2VFFDesc {
+    const void* X;
+    const void* W1;
+    const void* b1;
+    const void* W2;
+    const void* b2;
+    const void* R;
+    void* Y;
+    int32_t M, C, H;
+    int32_t ldx, ldr, ldy;
+    int32_t flags;       /* reserved, 0 */
+    int32_t reserved0;
+} AnyV2VFFDesc;
+
+int anyv2v_ff_geglu_f16(const AnyV2VFFDesc* d, void* stream);
+
 /* ---- normalisation ---------------------------------------------------------------------------
  * GroupNorm over channels-last tokens, optionally fused SiLU, input = channel concat [X0 | X1].
  * Statistics are taken over `rows_per_group` consecutive rows x (C/G) channels: rows_per_group = H*W
@@ -231,8 +257,8 @@ const char* anyv2v_last_error(void);
 /* ABI version = major * 100 + minor.  Descriptors carry no size field: a caller MUST be compiled against the header of the
  * library it loads (check anyv2v_version() >= the ANYV2V_ABI_VERSION it was built with) and MUST zero-initialise every
  * descriptor (new fields are appended with 0 = "off").  101: AnyV2VGemmDesc grew ln_c1 / ln_eps / reserved0 (round 3), flags
- * bits 13-16 select the persistent kernel's tile order (round 4). */
-#define ANYV2V_ABI_VERSION 101
+ * bits 13-16 select the persistent kernel's tile order (round 4).  102: anyv2v_ff_geglu_f16. */
+#define ANYV2V_ABI_VERSION 102
 int anyv2v_version(void);
 /* MFMA / LDS layout self-test used by the gpu test-suite (returns 0 when the layouts the kernels assume hold) */
 int anyv2v_selftest(void* scratch, int64_t scratch_bytes, void* stream);

@@ -249,11 +249,31 @@ def ddim_step(v, x, sa_t, sb_t, sa_p, sb_p, out=None):
     return y
 
 
+def ff_geglu(x, w1p, b1p, w2s, b2, residual=None, out=None):
+    """include/anyv2v_hip.h, AnyV2VFFDesc: W1 / b1 rows interleaved [16 h | 16 gate] per 32; W2 slab-major [H / 32][C][32] with the
+    slab's hidden units in MFMA slot order (column 8 q + e -> unit 4 q + e for e < 4, 16 + 4 q + e - 4 otherwise)."""
+    T, Cc = x.shape
+    H = w2s.shape[0] * 32
+    proj = (x.float() @ w1p.float().t() + b1p.float()).view(T, H // 16, 2, 16)
+    hidden = _h(proj[:, :, 0] * F.gelu(proj[:, :, 1])).float().reshape(T, H)      # one rounding, like the GEGLU GEMM's output
+    q, e = torch.arange(4).view(4, 1), torch.arange(8).view(1, 8)
+    perm = torch.where(e < 4, 4 * q + e, 16 + 4 * q + (e - 4)).reshape(32)
+    w2 = torch.empty(Cc, H // 32, 32)
+    w2[:, :, perm] = w2s.float().permute(1, 0, 2)                                 # slot order -> unit order
+    y = _h(hidden @ w2.reshape(Cc, H).t() + b2.float())
+    if residual is not None:
+        y = _h(y.float() + residual.float())
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def install(monkeypatch=None):
     """Replace every function of ``anyv2v_amd.ops`` with the emulation (tests only)."""
     from anyv2v_amd import ops
     names = ["gemm", "groupnorm", "layernorm", "softmax_rows", "attention", "silu", "add", "timestep_embedding", "ncfhw_to_tokens",
-             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "gather_rows", "rotary", "cfg_ddim_step", "ddim_step"]
+             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "gather_rows", "rotary", "cfg_ddim_step", "ddim_step", "ff_geglu"]
     g = globals()
     for n in names:
         if monkeypatch is not None:

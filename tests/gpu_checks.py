@@ -405,6 +405,32 @@ def check_gemm_ws_ln():
     return out
 
 
+def check_ff_fused():
+    """anyv2v_ff_geglu_f16 (ff_fused.hip): GEGLU up-projection + down-projection (+ residual) of the 320-channel blocks in one kernel vs
+    torch fp32 on the un-packed weights (hidden rounded to fp16 once, as the unfused GEGLU GEMM stores it), and vs the unfused pair of
+    GEMMs; one strip, ragged tails, more strips than the 1024 pair slots (several rounds: the weight rings wrap), with / without residual."""
+    out = []
+    C, H = 320, 1280
+    w1, b1 = rnd(2 * H, C, scale=1 / math.sqrt(C)), rnd(2 * H, scale=0.1)
+    w2, b2 = rnd(C, H, scale=1 / math.sqrt(H)), rnd(C, scale=0.1)
+    w1p, b1p = _geglu_pack(w1, b1, H)
+    w2s = ops.ff_pack_w2(w2)
+    for M, res in [(32, False), (32 * 5 + 7, True), (128 * 256, True), (128 * 256 * 2 + 32 * 3 + 5, True), (196608, False)]:
+        x = rnd(M, C)
+        r = rnd(M, C) if res else None
+        y = ops.ff_geglu(x, w1p, b1p, w2s, b2, residual=r)
+        proj = x.float() @ w1.float().t() + b1.float()
+        hid = (proj[:, :H] * F.gelu(proj[:, H:])).half().float()
+        ref = (hid @ w2.float().t() + b2.float()).half().float()
+        if res:
+            ref = ref + r.float()
+        out.append(_res(f"ff_fused M{M} res={res} vs torch fp32", y, ref, KTOL))
+        g = ops.gemm(x, w1p, bias=b1p, act=ops.ACT_GEGLU)
+        yu = ops.gemm(g, w2, bias=b2, residual=r)
+        out.append(_res(f"ff_fused M{M} res={res} vs the unfused GEGLU GEMM + Linear", y, yu.float(), KTOL))
+    return out
+
+
 def check_gemm_splitk():
     """Split-K path (launches that cannot fill the chip and have >= 16 K-tiles; fp32 partial tiles + a second pass that
     sums them in split order): against torch, against the unsplit kernel (flag bit4), and bit-reproducibility.

@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/anyv2v_hip.h but not exported"
     assert set(decl) == set(_lib.SYMBOLS), "ctypes binding table and header disagree"
-    assert _lib.load().anyv2v_version() >= 101
+    assert _lib.load().anyv2v_version() >= 102
 
 
 def test_abi_argument_validation_without_gpu():
@@ -69,6 +69,15 @@ def test_abi_argument_validation_without_gpu():
     a = _lib.AttnDesc()
     assert lib.anyv2v_attention_bias_f16(ctypes.byref(a), 64, None, None) == -1 and b"null bias" in lib.anyv2v_last_error()
     assert lib.anyv2v_attention_bias_f16(ctypes.byref(a), 200, 16, None) == -1                 # head_dim > 160
+    # round 4: fused feed-forward -- null pointers, unsupported width (the caller then runs the two GEMMs), alignment
+    assert lib.anyv2v_ff_geglu_f16(None, None) == -1
+    f = _lib.FFDesc()
+    assert lib.anyv2v_ff_geglu_f16(ctypes.byref(f), None) == -1 and b"null X" in lib.anyv2v_last_error()
+    f.X = f.W1 = f.b1 = f.W2 = f.b2 = f.Y = 16
+    f.M, f.C, f.H, f.ldx, f.ldy = 64, 640, 2560, 640, 640
+    assert lib.anyv2v_ff_geglu_f16(ctypes.byref(f), None) == -2 and b"only C = 320" in lib.anyv2v_last_error()
+    f.C, f.H, f.ldx, f.ldy = 320, 1280, 324, 320
+    assert lib.anyv2v_ff_geglu_f16(ctypes.byref(f), None) == -1 and b"ldx" in lib.anyv2v_last_error()
     assert lib.anyv2v_set_batch_hint(0, 1) != 0 and lib.anyv2v_set_batch_hint(3, 2) == 0 and lib.anyv2v_set_batch_hint(1, 1) == 0
     with pytest.raises(_lib.HipKernelError):
         _lib.check(-1, "x")

@@ -16,7 +16,7 @@ def _assert_all(results):
 
 def test_hip_library_loaded_and_mfma_layouts():
     from anyv2v_amd import _lib
-    assert _lib.load().anyv2v_version() >= 101
+    assert _lib.load().anyv2v_version() >= 102
     _assert_all(gc.check_selftest())
 
 
@@ -35,6 +35,10 @@ def test_gemm_pingpong_kernel(rows):
     non-GEGLU case of the persistent-kernel check with 192- and 256-row tiles: torch fp32 references, the naive kernel, and BIT-equality
     with the 128-row kernel (same MFMA shape, same K order), incl. launches with more tiles than CUs and several K-tiles per tile."""
     _assert_all(gc.check_gemm_big((1 << 17) | ((1 << 19) if rows == 192 else (1 << 20)), tag=f"pp{rows}"))
+
+
+def test_fused_feed_forward_c320():
+    _assert_all(gc.check_ff_fused())
 
 
 def test_gemm_weight_stationary_k320():

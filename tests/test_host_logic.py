@@ -589,3 +589,37 @@ def test_source_feature_cache_byte_budget_and_trajectory_serials():
     assert c.nbytes() == 0 and c.store(921, f)
     serials = [LatentTrajectory().serial for _ in range(4)]
     assert len(set(serials)) == 4 and serials == sorted(serials)
+
+
+def test_fused_feed_forward_packing_and_dispatch(monkeypatch):
+    """The fused feed-forward contract (AnyV2VFFDesc): ``ops.ff_pack_w2`` + the interleaved GEGLU packing reproduce
+    Linear(GEGLU(x)) -- checked against plain torch on the un-packed weights through the op emulation -- and ``FeedForward.run``
+    takes the fused op exactly for the 320-channel blocks at the 64x64 level's (hinted) row counts."""
+    import torch.nn.functional as F
+    from anyv2v_amd import ops
+    from anyv2v_amd.unet import FeedForward
+    emu.install(monkeypatch)
+    torch.manual_seed(3)
+    ff = FeedForward(320)
+    for prm in ff.parameters():
+        prm.data = (torch.randn_like(prm.data.float()) * 0.05).half()
+    ff.net[0].pack()
+    ff.pack()
+    assert tuple(ff._w2s.shape) == (40, 320, 32)
+    x, res = (torch.randn(70, 320) * 0.5).half(), torch.randn(70, 320).half()
+    proj = x.float() @ ff.net[0].proj.weight.float().t() + ff.net[0].proj.bias.float()
+    hid = (proj[:, :1280] * F.gelu(proj[:, 1280:])).half().float()
+    ref = (hid @ ff.net[2].weight.float().t() + ff.net[2].bias.float()).half().float() + res.float()
+    y = ops.ff_geglu(x, ff.net[0]._w, ff.net[0]._b, ff._w2s, ff.net[2].bias, residual=res)
+    assert (y.float() - ref).abs().max() <= 2e-3 * ref.abs().max()
+    calls = []
+    monkeypatch.setattr(ops, "ff_geglu", lambda *a, **k: calls.append(a[0].shape[0]) or emu.ff_geglu(*a, **k))
+    ff.run(x, res)
+    assert calls == []                                  # 70 rows: the two GEMMs
+    monkeypatch.setattr(ops, "_HINT", [32768, 70])      # as if the launch stood for >= 32768 rows
+    ff.run(x, res)
+    assert calls == [70]
+    wide = FeedForward(640)
+    wide.net[0].pack()
+    wide.pack()
+    assert wide._w2s is None
