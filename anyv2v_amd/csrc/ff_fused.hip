@@ -53,10 +53,17 @@ __device__ __forceinline__ h4 ffr64(unsigned addr) {
     return v;
 }
 __device__ __forceinline__ void ffw64(unsigned addr, h4 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+#ifdef ANYV2V_EXPERIMENTS
+__device__ long long g_ff_trace[2 * 8 * 16];   // [wave 0 | wave 4 of block 0][step 4..11 of round 1][stamp]
+#endif
 #define FF_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 }  // namespace
 
-template <bool RES>
+// KO (probe build only, tools/ff_fused_ab.py): 1 = no LDS-DMA (stale weights), 2 = GEGLU replaced by h * gate, 3 = no phase-B MFMAs,
+// 4 = no phase-A MFMAs, 5 = no step barrier (races; timing only), 6 = no exchange, 7 = s_memtime stamps per phase.
+// VAR: bit0 = fragment rings one step deeper (measured: no gain -- the step is bound by instruction ISSUE of the two SIMD partners
+// together, not by LDS latency), bit1 = s_setprio 1 around the MFMA loops (-2.5 %, default).  profiles/r04_ff_fused_ab_v1.txt
+template <bool RES, int KO = 0, int VAR = 2>
 __global__ __launch_bounds__(512) void ff_fused_c320_kernel(const FFK p) {
     __shared__ __attribute__((aligned(16))) char smem[FF_LDS];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -155,12 +162,24 @@ __global__ __launch_bounds__(512) void ff_fused_c320_kernel(const FFK p) {
             for (int ks = 0; ks < 10; ++ks) asm volatile("" : "+v"(xf[rf][ks]));   // complete BEFORE the loop (no vmcnt(0) inside it)
 
         for (int j = 0; j <= FF_NSLAB; ++j) {
+#ifdef ANYV2V_EXPERIMENTS
+            auto stamp = [&](int k) {
+                if constexpr (KO == 7) {
+                    if (blockIdx.x == 0 && rd == 1 && j >= 4 && j < 12 && (w & 3) == 0 && lane == 0)
+                        g_ff_trace[((w >> 2) * 8 + (j - 4)) * 16 + k] = (long long)__builtin_amdgcn_s_memtime();
+                }
+            };
+#else
+            auto stamp = [&](int) {};
+#endif
+            stamp(0);
             // ---- the next slabs: W1(j + 1) (wrapping to the next round's slab 0) and W2(j), one step ahead of their use
-            if (j < FF_NSLAB) {
+            if (j < FF_NSLAB && KO != 1) {
                 if (j + 1 < FF_NSLAB || rd + 1 < rounds) dma_w1(j + 1 < FF_NSLAB ? j + 1 : 0, (j + 1) & 1);
                 dma_w2(j, j & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            stamp(1);
             int lane_j = lane;
             asm volatile("" : "+v"(lane_j));   // (address constants are NOT carried across the loop: the kernel sits at 256 VGPRs)
             const Addr ad = make_addr(lane_j);
@@ -173,50 +192,69 @@ __global__ __launch_bounds__(512) void ff_fused_c320_kernel(const FFK p) {
                 for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) acc[rf][c] = (f4){0.f, 0.f, 0.f, 0.f};
-                h8 wf[2][2];   // ring over k-steps: the fragments of step ks + 1 are requested before step ks multiplies
+                constexpr int D1 = (VAR & 1) ? 2 : 1;   // k-steps of read-ahead
+                h8 wf[D1 + 1][2];   // ring over k-steps: the fragments of step ks + D1 are requested before step ks multiplies
                 const unsigned wb0 = wb + ad.w1c0, wb1 = wb + ad.w1c1;
 #define FF_RD_KS(KS)                                                                     \
     do {                                                                                 \
-        wf[(KS) & 1][0] = ffr128(((KS) & 1) ? wb1 : wb0, ((KS) >> 1) * (64 * 128));          \
-        wf[(KS) & 1][1] = ffr128(((KS) & 1) ? wb1 : wb0, ((KS) >> 1) * (64 * 128) + 2048);   \
+        wf[(KS) % (D1 + 1)][0] = ffr128(((KS) & 1) ? wb1 : wb0, ((KS) >> 1) * (64 * 128));          \
+        wf[(KS) % (D1 + 1)][1] = ffr128(((KS) & 1) ? wb1 : wb0, ((KS) >> 1) * (64 * 128) + 2048);   \
     } while (0)
                 FF_RD_KS(0);
+                if constexpr (D1 == 2) FF_RD_KS(1);
+                if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < 10; ++ks) {
-                    if (ks + 1 < 10) FF_RD_KS(ks + 1);
+                    if (ks + D1 < 10) FF_RD_KS(ks + D1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ks + 1 < 10)
+                    if (ks + 2 < 10 && D1 == 2)
+                        FF_LGKM(4);
+                    else if (ks + 1 < 10)
                         FF_LGKM(2);
                     else
                         FF_LGKM(0);
 #pragma unroll
                     for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
-                        for (int c = 0; c < 2; ++c)
-                            acc[rf][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks & 1][c], xf[rf][ks], acc[rf][c], 0, 0, 0);
+                        for (int c = 0; c < 2; ++c) {
+                            if constexpr (KO == 4)
+                                asm volatile("" ::"v"(wf[ks % (D1 + 1)][c]), "v"(xf[rf][ks]));
+                            else
+                                acc[rf][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks % (D1 + 1)][c], xf[rf][ks], acc[rf][c], 0, 0, 0);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef FF_RD_KS
+                if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);
+                stamp(2);
 #pragma unroll
                 for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        hown[rf][r] = (half_t)((acc[rf][0][r] + (float)bh[r]) * av_gelu(acc[rf][1][r] + (float)bg[r]));
+                        hown[rf][r] = KO == 2 ? (half_t)((acc[rf][0][r] + (float)bh[r]) * (acc[rf][1][r] + (float)bg[r]))
+                                              : (half_t)((acc[rf][0][r] + (float)bh[r]) * av_gelu(acc[rf][1][r] + (float)bg[r]));
                 ffw64(lds0 + ad.xw_own + (j & 1) * FF_X_BYTES, hown[0]);
                 ffw64(lds0 + ad.xw_own + (j & 1) * FF_X_BYTES + 512, hown[1]);
+                stamp(3);
             };
             auto phase_b = [&](int jb) {   // slab jb: own halves from registers (hprev), the partner's from LDS
+                stamp(4);
                 const unsigned wb = lds0 + W2B + (jb & 1) * FF_W2_BYTES;
                 const unsigned xa = lds0 + ad.xw_par + (jb & 1) * FF_X_BYTES;
                 h4 hp[2];
-                hp[0] = ffr64(xa);
-                hp[1] = ffr64(xa + 512);
-                h8 wf[3];
+                hp[0] = KO == 6 ? hprev[0] : ffr64(xa);
+                hp[1] = KO == 6 ? hprev[1] : ffr64(xa + 512);
+                constexpr int D2 = (VAR & 1) ? 3 : 2;   // fragments of read-ahead
+                h8 wf[D2 + 1];
                 const unsigned wbl = wb + ad.w2off;
                 wf[0] = ffr128(wbl, 0);
                 wf[1] = ffr128(wbl, 1024);
+                if constexpr (D2 == 3) wf[2] = ffr128(wbl, 2048);
                 __builtin_amdgcn_sched_barrier(0);
-                FF_LGKM(2);   // the partner's halves (older than the two weight fragments)
+                if constexpr (D2 == 3)
+                    FF_LGKM(3);
+                else
+                    FF_LGKM(2);   // the partner's halves (older than the weight fragments)
                 h8 hb[2];
 #pragma unroll
                 for (int rf = 0; rf < 2; ++rf)
@@ -225,21 +263,30 @@ __global__ __launch_bounds__(512) void ff_fused_c320_kernel(const FFK p) {
                         hb[rf][e] = half_ ? hp[rf][e] : hprev[rf][e];        // slots 0..3: hidden 4 lq + e   (wave a's half)
                         hb[rf][4 + e] = half_ ? hprev[rf][e] : hp[rf][e];    // slots 4..7: hidden 16 + 4 lq + e (wave b's half)
                     }
+                if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int nf = 0; nf < 10; ++nf) {
-                    if (nf + 2 < 10) wf[(nf + 2) % 3] = ffr128(wbl, (nf + 2) * 1024);
+                    if (nf + D2 < 10) wf[(nf + D2) % (D2 + 1)] = ffr128(wbl, (nf + D2) * 1024);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (nf + 2 < 10)
+                    if (nf + 3 < 10 && D2 == 3)
+                        FF_LGKM(3);
+                    else if (nf + 2 < 10)
                         FF_LGKM(2);
                     else if (nf + 1 < 10)
                         FF_LGKM(1);
                     else
                         FF_LGKM(0);
 #pragma unroll
-                    for (int rf = 0; rf < 2; ++rf)
-                        yacc[rf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nf % 3], hb[rf], yacc[rf][nf], 0, 0, 0);
+                    for (int rf = 0; rf < 2; ++rf) {
+                        if constexpr (KO == 3)
+                            asm volatile("" ::"v"(wf[nf % (D2 + 1)]), "v"(hb[rf]));
+                        else
+                            yacc[rf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nf % (D2 + 1)], hb[rf], yacc[rf][nf], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);
+                stamp(5);
             };
             // ONE code sequence for both halves of the block; what differs is where the step's barrier sits.  Waves 0-3: A(j), B(j - 1),
             // barrier.  Waves 4-7 (their SIMD partners): A(j), barrier, B(j).  Between two barriers a SIMD therefore holds one wave in
@@ -247,8 +294,11 @@ __global__ __launch_bounds__(512) void ff_fused_c320_kernel(const FFK p) {
             // half, so the exchange stays consistent).  (Two inlined copies of the phases in opposite order cost 40 spilled VGPRs.)
             auto step_sync = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(6);
                 __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): this step's DMA pieces and exchange writes are complete
-                __builtin_amdgcn_s_barrier();
+                stamp(7);
+                if constexpr (KO != 5) __builtin_amdgcn_s_barrier();
+                stamp(8);
                 __builtin_amdgcn_sched_barrier(0);
             };
             if (j < FF_NSLAB) phase_a();
@@ -307,9 +357,29 @@ extern "C" int anyv2v_ff_geglu_f16(const AnyV2VFFDesc* d, void* stream) {
     k.nstrips = (d->M + 31) / 32;
     const int blocks = (k.nstrips + 3) / 4;
     const dim3 grid(blocks < 256 ? blocks : 256);
+#ifdef ANYV2V_EXPERIMENTS   // probe build only: knock-outs selected by flags bits 0-2 (results are wrong by construction)
+    switch (d->flags & 7) {
+#define AV_FF_KO(n) case n: hipLaunchKernelGGL((ff_fused_c320_kernel<true, n>), grid, dim3(512), 0, (hipStream_t)stream, k); return av_launch_status("ff_fused<KO>");
+        AV_FF_KO(1) AV_FF_KO(2) AV_FF_KO(3) AV_FF_KO(4) AV_FF_KO(5) AV_FF_KO(6) AV_FF_KO(7)
+#undef AV_FF_KO
+        default: break;
+    }
+    switch ((d->flags >> 3) & 3) {   // variants (correct results): bit3 deeper fragment rings, bit4 s_setprio 1 around the MFMA loops
+#define AV_FF_VAR(n) case (n == 0 ? 2 : n): hipLaunchKernelGGL((ff_fused_c320_kernel<true, 0, n>), grid, dim3(512), 0, (hipStream_t)stream, k); return av_launch_status("ff_fused<VAR>");
+        AV_FF_VAR(1) AV_FF_VAR(0) AV_FF_VAR(3)
+#undef AV_FF_VAR
+        default: break;
+    }
+#endif
     if (d->R != nullptr)
         hipLaunchKernelGGL(ff_fused_c320_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, k);
     else
         hipLaunchKernelGGL(ff_fused_c320_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, k);
     return av_launch_status("ff_fused_c320");
 }
+
+#ifdef ANYV2V_EXPERIMENTS
+extern "C" int anyv2v_ff_trace_read(void* host_dst) {   // probe build only (flags & 7 == 7 fills it)
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_ff_trace), sizeof(long long) * 2 * 8 * 16);
+}
+#endif
