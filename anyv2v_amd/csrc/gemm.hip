@@ -14,6 +14,7 @@
 //   gemm_mfma_kernel  : 128 x NF*32 x 64, 4 waves 2x2, 2 LDS stages (register- or LDS-DMA-staged), 2 blocks/CU.
 //   gemm_big_kernel   : 256 x 320 x 64, 8 waves 4x2 (wave tile 64 x 160), 2 LDS stages by LDS-DMA, persistent
 //                       blocks with cross-tile prefetch and a wave-private epilogue -- the large-M workhorse.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -1207,6 +1208,9 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     //  * 128-row kernel split-K for launches that cannot fill the chip (512 block slots) and have a long K loop (with 20 K-tiles the
     //    second pass costs more than the idle CUs; with 60 it pays only when fewer than a quarter of the block slots would be busy;
     //    from ~72 K-tiles on it always pays).
+    // (the workspace test uses the PLANNED row count as well: a batch-hinted launch must reproduce the decision of the launch it
+    //  stands for -- its own, smaller partial tiles could fit where the reference launch's do not, and the two would then split
+    //  differently: seen at 16 f x 256^2, tests/test_gpu_parity.py::test_two_branch_steps_bit_equal_at_a_mid_size_full_width)
     struct Plan { int big, splits; };
     auto plan = [&](int rows, int nf_rows) -> Plan {
         const bool ws_ok = d->workspace != nullptr && d->N % 8 == 0;
@@ -1218,7 +1222,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
                 int sp = 256 / tb;
                 if (sp > 8) sp = 8;
                 if (sp > nk_all / 12) sp = nk_all / 12;
-                if (sp >= 2 && tb * sp >= 224 && (size_t)sp * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {1, sp};
+                if (sp >= 2 && tb * sp >= 224 && (size_t)sp * rows * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {1, sp};
             }
             if (fills || (d->flags & 8)) return {1, 1};
         }
@@ -1228,7 +1232,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             int sp = (512 + tm - 1) / tm;
             if (sp > 8) sp = 8;
             if (sp > nk_all / 8) sp = nk_all / 8;
-            if (sp >= 2 && (size_t)sp * d->M * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {0, sp};
+            if (sp >= 2 && (size_t)sp * rows * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {0, sp};
         }
         return {0, 1};
     };
@@ -1269,6 +1273,12 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             AV_PP(3);
 #undef AV_PP
         return av_launch_status("gemm_pp");
+    }
+    {   // ANYV2V_GEMM_LOG=1: one line per launch plan on stderr (diagnostics: which launches split, and how, under a batch hint)
+        static const bool log_on = getenv("ANYV2V_GEMM_LOG") != nullptr;
+        if (log_on)
+            fprintf(stderr, "gemm-plan mode %d M %d (hinted %d) N %d K %d act %d res %d big %d splits %d\n", MODE, d->M, av_hint_rows(d->M), d->N,
+                    k.Ktot, d->act, d->R != nullptr, use.big, use.splits);
     }
     if (use.big) {
         const int tiles_big = ((d->M + BMB - 1) / BMB) * (d->N / 320);

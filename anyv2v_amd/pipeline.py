@@ -55,19 +55,19 @@ class SourceFeatureCache:
 
     def __init__(self, max_bytes: Optional[int] = None):
         self.signature = None
-        self.steps: Dict[int, Dict[str, torch.Tensor]] = {}
+        self.steps: Dict[tuple, Dict[str, torch.Tensor]] = {}   # (t, injection state) -> site -> features
         self.recorded_steps = self.replayed_steps = 0
         # byte budget (``ANYV2V_SOURCE_CACHE_GB``, default 96 GB of the 288): a step that would exceed it is simply not recorded and
         # runs as a three-branch step in every edit -- same results, no saving for that step
         self.max_bytes = int(float(os.environ.get("ANYV2V_SOURCE_CACHE_GB", "96")) * 2 ** 30) if max_bytes is None else int(max_bytes)
         self.skipped_steps = 0
 
-    def store(self, t, feats: Dict[str, torch.Tensor]) -> bool:
+    def store(self, t, state, feats: Dict[str, torch.Tensor]) -> bool:
         need = sum(v.numel() * v.element_size() for v in feats.values())
         if self.nbytes() + need > self.max_bytes:
             self.skipped_steps += 1
             return False
-        self.steps.setdefault(int(t), {}).update({n: v.clone() for n, v in feats.items()})
+        self.steps[(int(t), tuple(state))] = {n: v.clone() for n, v in feats.items()}
         return True
 
     def bind(self, signature):
@@ -75,9 +75,12 @@ class SourceFeatureCache:
             self.steps.clear()
             self.signature = signature
 
-    def has(self, t, names) -> bool:
-        d = self.steps.get(int(t))
-        return d is not None and all(n in d for n in names)
+    def has(self, t, state) -> bool:
+        """Features of step ``t`` recorded under exactly this injection ``state`` (which sites are on).  The same state, not a
+        superset: the source branch's own arithmetic depends on it at the rounding level (on a conv-injection step its main path
+        runs as a one-branch launch with its own split-K plan, at an injected attention site its Q | K | V come from a one-branch
+        projection), so only a same-state record reproduces the uncached edit bit for bit."""
+        return (int(t), tuple(state)) in self.steps
 
     def nbytes(self) -> int:
         return sum(v.numel() * v.element_size() for d in self.steps.values() for v in d.values())
@@ -652,7 +655,7 @@ class I2VGenXLPipeline:
                                                 dup_slots=[0], shared_stem=True, batch_hint=(3, 2))
                     eng_nosrc, nosrc_bound = eng.nosrc, True
                 eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-nosrc",))
-            elif cache is not None and cache.has(t, [n for (n, _, _), on in zip(sites, state) if on]):
+            elif cache is not None and cache.has(t, state):
                 # replay: the source features of this step are in HBM -- [negative, editing] only
                 names = [n for (n, _, _), on in zip(sites, state) if on]
                 if not nosrc_bound:
@@ -662,7 +665,7 @@ class I2VGenXLPipeline:
                                                 dup_slots=[0], shared_stem=True, batch_hint=(3, 2))
                     eng_nosrc, nosrc_bound = eng.nosrc, True
                 for n in names:
-                    eng.site_bufs[n].copy_(cache.steps[t][n], non_blocking=True)
+                    eng.site_bufs[n].copy_(cache.steps[(int(t), state)][n], non_blocking=True)
                 set_io("replay", names)
                 eng_nosrc.step(t_table[i, 1:], coef_table[i], key=("pnp-replay",) + state)
                 set_io(None, ())
@@ -674,7 +677,7 @@ class I2VGenXLPipeline:
                     set_io("record", names)
                     eng.step(t_table[i], coef_table[i], key=("pnp-record",) + state)
                     set_io(None, ())
-                    cache.recorded_steps += bool(cache.store(t, {n: eng.site_bufs[n] for n in names}))
+                    cache.recorded_steps += bool(cache.store(t, state, {n: eng.site_bufs[n] for n in names}))
                 else:
                     eng.step(t_table[i], coef_table[i], key=("pnp",) + state)
             if latents_trace is not None:

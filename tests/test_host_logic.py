@@ -580,13 +580,15 @@ def test_source_feature_cache_byte_budget_and_trajectory_serials():
     from anyv2v_amd.utils import LatentTrajectory
     c = SourceFeatureCache(max_bytes=3 * 1024)
     f = {"a": torch.zeros(512, dtype=torch.float16)}          # 1 KiB per step
-    assert c.store(981, f) and c.store(961, f) and c.store(941, f)
-    assert not c.store(921, f) and c.skipped_steps == 1 and c.nbytes() == 3 * 1024
-    assert c.has(981, ["a"]) and not c.has(921, ["a"])
-    c.steps[981]["a"].fill_(1)                                 # stored tensors are copies
+    st = (True, False)
+    assert c.store(981, st, f) and c.store(961, st, f) and c.store(941, st, f)
+    assert not c.store(921, st, f) and c.skipped_steps == 1 and c.nbytes() == 3 * 1024
+    assert c.has(981, st) and not c.has(921, st)
+    assert not c.has(981, (True, True))                        # another injection state of the same step: not replayable
+    c.steps[(981, st)]["a"].fill_(1)                           # stored tensors are copies
     assert float(f["a"].sum()) == 0.0
     c.bind(("other clip",))
-    assert c.nbytes() == 0 and c.store(921, f)
+    assert c.nbytes() == 0 and c.store(921, st, f)
     serials = [LatentTrajectory().serial for _ in range(4)]
     assert len(set(serials)) == 4 and serials == sorted(serials)
 
