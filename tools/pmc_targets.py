@@ -39,5 +39,20 @@ for Nn, act in ((2560, ops.ACT_GEGLU), (960, ops.ACT_NONE)):
     oo = torch.empty(M, Nn // 2 if act == ops.ACT_GEGLU else Nn, dtype=torch.float16, device="cuda")
     for _ in range(reps):
         ops.gemm(xa, ww, bias=bb, act=act, out=oo)
+# round 4: the rastered GEGLU launches of the persistent kernel (640 / 1280 channels) and the fused feed-forward kernel (320 channels)
+for (Mg, Ng, Kg) in ((49152, 5120, 640), (12288, 10240, 1280)):
+    xg = torch.randn(Mg, Kg, device="cuda").half()
+    wg = (torch.randn(Ng, Kg, device="cuda") / Kg ** 0.5).half()
+    bg = torch.zeros(Ng, dtype=torch.float16, device="cuda")
+    og = torch.empty(Mg, Ng // 2, dtype=torch.float16, device="cuda")
+    for _ in range(reps):
+        ops.gemm(xg, wg, bias=bg, act=ops.ACT_GEGLU, out=og)
+w1 = (torch.randn(2560, 320, device="cuda") / 320 ** 0.5).half()
+b1 = torch.zeros(2560, dtype=torch.float16, device="cuda")
+w2s = ops.ff_pack_w2((torch.randn(320, 1280, device="cuda") / 1280 ** 0.5).half())
+b2 = torch.zeros(320, dtype=torch.float16, device="cuda")
+yo = torch.empty(M, 320, dtype=torch.float16, device="cuda")
+for _ in range(reps):
+    ops.ff_geglu(xa, w1, b1, w2s, b2, residual=xa, out=yo)
 torch.cuda.synchronize()
 print("done")
