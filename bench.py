@@ -161,6 +161,31 @@ def roofline_gemm_ws(device):
             "algorithmic_bytes_per_launch": M * K * 2 + N * K * 2 + M * (N // 2) * 2, "context": SUSTAINED_NOTE_16}
 
 
+def roofline_ff(device):
+    """The fused feed-forward launch of the edit step's 64x64 level (ff_fused.hip): GEGLU up-projection 320 -> 2 x 1280, down-projection
+    1280 -> 320 and the residual in ONE kernel; 2 M (2 H C + H C) FLOP, algorithmic bytes = x in, residual in, y out + the weights
+    (the [M, 1280] hidden activation never reaches HBM)."""
+    from anyv2v_amd import ops
+    M, C, H = 196608, 320, 1280
+    x = torch.randn(M, C, device=device).to(torch.float16)
+    r = torch.randn(M, C, device=device).to(torch.float16)
+    w1 = (torch.randn(2 * H, C, device=device) / C ** 0.5).to(torch.float16)
+    b1 = torch.zeros(2 * H, dtype=torch.float16, device=device)
+    w2s = ops.ff_pack_w2((torch.randn(C, H, device=device) / H ** 0.5).to(torch.float16))
+    b2 = torch.zeros(C, dtype=torch.float16, device=device)
+    out = torch.empty(M, C, dtype=torch.float16, device=device)
+    fn = lambda: ops.ff_geglu(x, w1, b1, w2s, b2, residual=r, out=out)
+    ms = measure_kernel(fn)
+    flops = 2.0 * M * (2 * H * C + H * C)
+    ach = flops / (ms * 1e-3) / 1e12
+    traffic, src = measured_traffic("ff_fused_c320_kernel<true")
+    return {"bound": "mfma", "kernel": "ff_fused_c320_kernel (feed-forward of the 320-channel blocks: GEGLU up-projection + down-projection + "
+                                       "residual, 196608 tokens; weights streamed by LDS-DMA, hidden activation in registers)",
+            "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": 3 * M * C * 2 + 3 * H * C * 2, "context": SUSTAINED_NOTE_16}
+
+
 def effective_cpus() -> int:
     """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU box shows 256 hardware
     threads but runs under a 16-CPU cgroup quota; 256 torch threads there get CFS-throttled to a crawl."""
@@ -306,7 +331,15 @@ def executed_flops(engine, hooks_t=None):
         acc["launches"] += 1
         return a0(q, k, v, out, **kw)
 
-    ops.gemm, ops.attention = gemm, attention
+    f0 = ops.ff_geglu
+
+    def ff_geglu(x, w1p, b1p, w2s, b2, **kw):   # fused feed-forward: up-projection (both GEGLU halves) + down-projection
+        H = w2s.shape[0] * 32
+        acc["gemm"] += 2.0 * x.shape[0] * (2 * H * x.shape[1] + H * x.shape[1])
+        acc["launches"] += 1
+        return f0(x, w1p, b1p, w2s, b2, **kw)
+
+    ops.gemm, ops.attention, ops.ff_geglu = gemm, attention, ff_geglu
     try:
         if hooks_t is not None:
             pnp_utils.register_time(engine.pipe, hooks_t)
@@ -315,7 +348,7 @@ def executed_flops(engine, hooks_t=None):
         engine.unet._forward_core(engine.ctx, engine.sample.clone(), drop_source_tail=getattr(engine, "drop_src_tail", False))
         torch.cuda.synchronize()
     finally:
-        ops.gemm, ops.attention = g0, a0
+        ops.gemm, ops.attention, ops.ff_geglu = g0, a0, f0
     return acc
 
 
@@ -572,6 +605,7 @@ def main():
             line["roofline_pnp"] = roofline_spatial_attention(device, pnp=True)
             line["roofline_gemm"] = roofline_conv(device)
             line["roofline_gemm_ws"] = roofline_gemm_ws(device)
+            line["roofline_ff"] = roofline_ff(device)
         if world == 1 and not args.no_clip:
             del e_inv, e_pnp
             torch.cuda.empty_cache()

@@ -80,11 +80,20 @@ def main():
         return ((batch, heads, Sq, Sk, d, f"qk_mod{kw.get('qk_mod', 0)}", f"kv_div{kw.get('kv_div', 1)}"),
                 4.0 * batch * heads * Sq * Sk * d, 2 * batch * heads * d * (2 * Sq + 2 * Sk / kw.get("kv_div", 1)))
 
+    def ff_key(x, w1p, b1p, w2s, b2, residual=None, out=None):
+        M, C = x.shape
+        H = w2s.shape[0] * 32
+        return ((M, C, H, "res" if residual is not None else ""), 2.0 * M * (2 * H * C + H * C),
+                (M * C * (3 if residual is not None else 2) + 3 * H * C) * 2.0)
+
+    saved_ff = ops.ff_geglu
+    ops.ff_geglu = rec("ff_fused", ops.ff_geglu, ff_key)
     saved = (ops.gemm, ops.groupnorm, ops.layernorm, ops.attention)
     ops.gemm, ops.groupnorm = rec("gemm", ops.gemm, gemm_key), rec("groupnorm", ops.groupnorm, gn_key)
     ops.layernorm, ops.attention = rec("layernorm", ops.layernorm, ln_key), rec("attention", ops.attention, attn_key)
     pipe.unet(sample, t, **cond)
     ops.gemm, ops.groupnorm, ops.layernorm, ops.attention = saved
+    ops.ff_geglu = saved_ff
     torch.cuda.synchronize()
 
     # whole-forward eager time for reference
