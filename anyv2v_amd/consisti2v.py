@@ -29,6 +29,7 @@ Performance is not tuned for this family (temporal attention at head_dim C / 8 r
 """
 from __future__ import annotations
 
+import types
 from typing import Dict, List
 
 import torch
@@ -36,8 +37,8 @@ from torch import nn
 
 from . import ops
 from .ops import MODE_TEMPORAL
-from .unet import (Conv2d, Conv3dTemporal, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU, Upsample2D,
-                   pnp_on)
+from .unet import (Conv2d, Conv3dTemporal, Downsample2D, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU,
+                   Upsample2D, pnp_on)
 
 ROTARY_THETA = 10000.0  # rotary_embedding.py:76 (freqs_for="lang")
 
@@ -54,6 +55,10 @@ class _Ctx:
         self.context = None   # [B * L, D] text tokens, one copy per batch element
         self.L = 0
         self._idx: Dict[tuple, torch.Tensor] = {}
+
+    def set_hw(self, H, W):
+        """The block stack moves to another resolution level (index tensors are cached per (B, F, H, W))."""
+        self.H, self.W = H, W
 
 
 def _first_frame_index(B, F, HW, device):
@@ -332,8 +337,33 @@ class TemporalResnetBlock(nn.Module):
         return ops.gemm(h, self._w2, bias=self._b2, mode=MODE_TEMPORAL, temporal=(ctx.F, HW), residual=x)
 
 
+# ------------------------------------------------------------------------------------------------- blocks
+class _BlockBase(nn.Module):
+    """What every block of the UNet shares: packing, and ``enter`` -- one GEMM for the time-embedding projections of all its ResNets."""
+
+    def pack(self):
+        for m in self.modules():
+            if m is not self and hasattr(m, "pack"):
+                m.pack()
+        col = 0
+        for r in self.resnets:
+            r._temb_col = col
+            col += r.out_channels
+        self._w_temb = torch.cat([r.time_emb_proj.weight.data for r in self.resnets], 0).contiguous()
+        self._b_temb = torch.cat([r.time_emb_proj.bias.data for r in self.resnets], 0).contiguous()
+        self._packed = True
+
+    def enter(self, ctx):
+        ctx.temb_all = ops.gemm(ops.silu(ctx.emb), self._w_temb, bias=self._b_temb)
+
+
+def _no_conv2d(mode):
+    if mode == "conv2d":
+        raise NotImplementedError("first_frame_condition_mode='conv2d' is not built (the released ConsistI2V model uses 'concat')")
+
+
 # ------------------------------------------------------------------------------------------------- the decoder block
-class VideoLDMCrossAttnUpBlock(nn.Module):
+class VideoLDMCrossAttnUpBlock(_BlockBase):
     """``videoldm_unet_blocks.py:548-745`` with the released model's options (temporal layers on, rotary temporal position
     embedding, ``first_frame_condition_mode`` "concat" or "none"; the "conv2d" mode is not built).  Constructor argument names are
     the reference's."""
@@ -370,18 +400,6 @@ class VideoLDMCrossAttnUpBlock(nn.Module):
         self._packed = False
         self._w_temb = self._b_temb = None
 
-    def pack(self):
-        for m in self.modules():
-            if m is not self and hasattr(m, "pack"):
-                m.pack()
-        col = 0
-        for r in self.resnets:   # one GEMM for the time-embedding projections of the block's resnets
-            r._temb_col = col
-            col += r.out_channels
-        self._w_temb = torch.cat([r.time_emb_proj.weight.data for r in self.resnets], 0).contiguous()
-        self._b_temb = torch.cat([r.time_emb_proj.bias.data for r in self.resnets], 0).contiguous()
-        self._packed = True
-
     def load_state_dict(self, sd, strict=True, **kw):
         out = super().load_state_dict(sd, strict=strict, **kw)   # (weights are converted to the parameters' fp16; alpha / freqs stay fp32)
         self._packed = False
@@ -396,6 +414,7 @@ class VideoLDMCrossAttnUpBlock(nn.Module):
             x = tattn.run(ctx, x)
         if self.upsamplers is not None:
             x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
+            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
         return x
 
     def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, **unused):
@@ -414,13 +433,296 @@ class VideoLDMCrossAttnUpBlock(nn.Module):
             return t.to(torch.float16).permute(0, 2, 3, 1).reshape(N * H * W, t.shape[1]).contiguous()
         emb = temb.to(torch.float16).view(B, F, -1)[:, 0].contiguous()
         ctx.emb = emb
-        ctx.temb_all = ops.gemm(ops.silu(emb), self._w_temb, bias=self._b_temb)
+        self.enter(ctx)
         ehs = encoder_hidden_states.to(torch.float16)[::F]
         ctx.L = ehs.shape[1]
         ctx.context = ehs.reshape(B * ctx.L, -1).contiguous()
         y = self.run(ctx, tok(hidden_states), [tok(s) for s in res_hidden_states_tuple])
         Ho, Wo = (2 * H, 2 * W) if self.upsamplers is not None else (H, W)
         return y.view(N, Ho, Wo, -1).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------- the other blocks of the UNet
+class VideoLDMCrossAttnDownBlock(_BlockBase):
+    """``videoldm_unet_blocks.py:343-545``: per layer ResnetBlock2D -> TemporalResnetBlock -> spatial transformer (+ first frame) ->
+    temporal transformer; stride-2 ``Downsample2D`` behind the last layer.  Every layer's output is a skip."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32, num_attention_heads=1,
+                 cross_attention_dim=1280, add_downsample=True, use_linear_projection=False, use_temporal=True,
+                 augment_temporal_attention=False, n_frames=8, n_temp_heads=8, first_frame_condition_mode="none", rotary_emb=False,
+                 transformer_layers_per_block=1, **unused):
+        super().__init__()
+        _no_conv2d(first_frame_condition_mode)
+        assert use_temporal and rotary_emb
+        self.first_frame_condition_mode, self.has_cross_attention, self.n_frames = first_frame_condition_mode, True, n_frames
+        self.resnets, self.attentions = nn.ModuleList(), nn.ModuleList()
+        self.conv3ds, self.tempo_attns = nn.ModuleList(), nn.ModuleList()
+        for i in range(num_layers):
+            self.resnets.append(ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels, resnet_groups, resnet_eps))
+            self.attentions.append(Transformer2DConditionModel(num_attention_heads, out_channels // num_attention_heads, out_channels,
+                                                               cross_attention_dim, resnet_groups, n_frames,
+                                                               use_linear_projection=use_linear_projection,
+                                                               num_layers=transformer_layers_per_block))
+            self.conv3ds.append(TemporalResnetBlock(out_channels))
+            self.tempo_attns.append(Transformer2DConditionModel(n_temp_heads, out_channels // n_temp_heads, out_channels,
+                                                                cross_attention_dim, resnet_groups, n_frames, is_temporal=True,
+                                                                augment_temporal_attention=augment_temporal_attention,
+                                                                use_linear_projection=use_linear_projection,
+                                                                num_layers=transformer_layers_per_block))
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def run(self, ctx, x):
+        cond = self.first_frame_condition_mode not in ("none", "input_only")
+        outs = []
+        for resnet, conv3d, attn, tattn in zip(self.resnets, self.conv3ds, self.attentions, self.tempo_attns):
+            x = resnet.run(ctx, x, None, ctx.H, ctx.W)
+            x = conv3d.run(ctx, x)
+            x = attn.run(ctx, x, condition_on_first_frame=cond)
+            x = tattn.run(ctx, x)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
+            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            outs.append(x)
+        return x, outs
+
+
+class VideoLDMDownBlock(_BlockBase):
+    """``videoldm_unet_blocks.py:947-1052`` (diffusers ``DownBlock2D`` + a TemporalResnetBlock per layer; no attention)."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32, add_downsample=True,
+                 use_temporal=True, n_frames=8, first_frame_condition_mode="none", **unused):
+        super().__init__()
+        _no_conv2d(first_frame_condition_mode)
+        assert use_temporal
+        self.has_cross_attention, self.n_frames = False, n_frames
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels, resnet_groups,
+                                                    resnet_eps) for i in range(num_layers)])
+        self.conv3ds = nn.ModuleList([TemporalResnetBlock(out_channels) for _ in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def run(self, ctx, x):
+        outs = []
+        for resnet, conv3d in zip(self.resnets, self.conv3ds):
+            x = conv3d.run(ctx, resnet.run(ctx, x, None, ctx.H, ctx.W))
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
+            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            outs.append(x)
+        return x, outs
+
+
+class VideoLDMUNetMidBlock2DCrossAttn(_BlockBase):
+    """``videoldm_unet_blocks.py:748-945``: resnet, temporal resnet, then per layer spatial transformer -> resnet -> temporal resnet
+    (no temporal transformer in the middle)."""
+
+    def __init__(self, in_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32, num_attention_heads=1,
+                 cross_attention_dim=1280, use_linear_projection=False, use_temporal=True, n_frames=8, first_frame_condition_mode="none",
+                 transformer_layers_per_block=1, **unused):
+        super().__init__()
+        _no_conv2d(first_frame_condition_mode)
+        assert use_temporal
+        self.first_frame_condition_mode, self.has_cross_attention, self.n_frames = first_frame_condition_mode, True, n_frames
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_channels, in_channels, temb_channels, resnet_groups, resnet_eps)
+                                      for _ in range(num_layers + 1)])
+        self.conv3ds = nn.ModuleList([TemporalResnetBlock(in_channels) for _ in range(num_layers + 1)])
+        self.attentions = nn.ModuleList([Transformer2DConditionModel(num_attention_heads, in_channels // num_attention_heads, in_channels,
+                                                                     cross_attention_dim, resnet_groups, n_frames,
+                                                                     use_linear_projection=use_linear_projection,
+                                                                     num_layers=transformer_layers_per_block) for _ in range(num_layers)])
+
+    def run(self, ctx, x):
+        cond = self.first_frame_condition_mode not in ("none", "input_only")
+        x = self.conv3ds[0].run(ctx, self.resnets[0].run(ctx, x, None, ctx.H, ctx.W))
+        for attn, resnet, conv3d in zip(self.attentions, self.resnets[1:], self.conv3ds[1:]):
+            x = attn.run(ctx, x, condition_on_first_frame=cond)
+            x = conv3d.run(ctx, resnet.run(ctx, x, None, ctx.H, ctx.W))
+        return x
+
+
+class VideoLDMUpBlock(_BlockBase):
+    """``videoldm_unet_blocks.py:1054-1158`` (diffusers ``UpBlock2D`` + a TemporalResnetBlock per layer; no attention)."""
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
+                 add_upsample=True, use_temporal=True, n_frames=8, first_frame_condition_mode="none", **unused):
+        super().__init__()
+        _no_conv2d(first_frame_condition_mode)
+        assert use_temporal
+        self.has_cross_attention, self.n_frames = False, n_frames
+        self.resnets = nn.ModuleList()
+        for i in range(num_layers):
+            skip = in_channels if i == num_layers - 1 else out_channels
+            rin = prev_output_channel if i == 0 else out_channels
+            self.resnets.append(ResnetBlock2D(rin + skip, out_channels, temb_channels, resnet_groups, resnet_eps))
+        self.conv3ds = nn.ModuleList([TemporalResnetBlock(out_channels) for _ in range(num_layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def run(self, ctx, x, skips: List[torch.Tensor]):
+        for resnet, conv3d in zip(self.resnets, self.conv3ds):
+            x = conv3d.run(ctx, resnet.run(ctx, x, skips.pop(), ctx.H, ctx.W))
+        if self.upsamplers is not None:
+            x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
+            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------- the UNet
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class TimestepEmbedding(nn.Module):
+    """diffusers ``TimestepEmbedding(in, dim, act_fn="silu")``: Linear -> SiLU -> Linear (``videoldm_unet.py:226-246``)."""
+
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = Linear(in_channels, time_embed_dim)
+        self.linear_2 = Linear(time_embed_dim, time_embed_dim)
+
+    def run(self, x):
+        return ops.gemm(ops.gemm(x, self.linear_1.weight, bias=self.linear_1.bias, act=ops.ACT_SILU), self.linear_2.weight,
+                        bias=self.linear_2.bias)
+
+
+class VideoLDMUNet3DConditionModel(nn.Module):
+    """``consisti2v/consisti2v/models/videoldm_unet.py:68-1064`` on the HIP kernels, for the configuration family of the released
+    ConsistI2V model: temporal layers on, rotary temporal position embedding, ``first_frame_condition_mode`` "concat" (or "none"),
+    optional frame-stride conditioning, positional time embedding, no class / addition embeddings.  Module tree and state-dict
+    keys are the reference's (``tests/test_consisti2v.py`` loads the reference model's own state dict strictly).
+
+    ``forward(sample [B,C,F',h,w], timestep, encoder_hidden_states [B,L,D], first_frame_latents [B,C,1,h,w], frame_stride)`` as in
+    the reference (``:687-1026``): with first-frame conditioning the clean first-frame latent is prepended as frame 0 (F = F' + 1 =
+    ``n_frames``), every spatial self-attention also attends to frame 0, every augmented temporal self-attention to its 3 x 3
+    neighbourhood in frame 0, and frame 0 of the prediction is dropped."""
+
+    def __init__(self, sample_size=None, in_channels=4, out_channels=4, flip_sin_to_cos=True, freq_shift=0,
+                 down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                 mid_block_type="UNetMidBlock2DCrossAttn",
+                 up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+                 block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=1280,
+                 transformer_layers_per_block=1, attention_head_dim=8, use_linear_projection=False, use_temporal=True, n_frames=8,
+                 n_temp_heads=8, first_frame_condition_mode="none", augment_temporal_attention=False, temp_pos_embedding="sinusoidal",
+                 use_frame_stride_condition=False, **unused):
+        super().__init__()
+        if not use_temporal or temp_pos_embedding != "rotary" or not flip_sin_to_cos or freq_shift != 0 or mid_block_type != "UNetMidBlock2DCrossAttn":
+            raise NotImplementedError("native VideoLDMUNet3DConditionModel: use_temporal=True, temp_pos_embedding='rotary', flip_sin_to_cos=True, "
+                                      "freq_shift=0, mid_block_type='UNetMidBlock2DCrossAttn' only")
+        _no_conv2d(first_frame_condition_mode)
+        nb = len(block_out_channels)
+        tup = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v,) * nb
+        heads, lpb, tlpb, cad = tup(attention_head_dim), tup(layers_per_block), tup(transformer_layers_per_block), tup(cross_attention_dim)
+        self.config = _Cfg(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels, n_frames=n_frames,
+                           first_frame_condition_mode=first_frame_condition_mode, cross_attention_dim=cross_attention_dim,
+                           block_out_channels=tuple(block_out_channels), use_frame_stride_condition=use_frame_stride_condition)
+        boc = block_out_channels
+        ted = boc[0] * 4
+        self.groups = norm_num_groups
+        self.conv_in = Conv2d(in_channels, boc[0], 3, padding=1, pad_cin_to=64)
+        self.time_embedding = TimestepEmbedding(boc[0], ted)
+        self.use_frame_stride_condition = use_frame_stride_condition
+        if use_frame_stride_condition:
+            self.frame_stride_embedding = TimestepEmbedding(boc[0], ted)
+        common = dict(temb_channels=ted, resnet_eps=norm_eps, resnet_groups=norm_num_groups, use_linear_projection=use_linear_projection,
+                      use_temporal=True, augment_temporal_attention=augment_temporal_attention, n_frames=n_frames, n_temp_heads=n_temp_heads,
+                      first_frame_condition_mode=first_frame_condition_mode, rotary_emb=True)
+        self.down_blocks = nn.ModuleList()
+        out = boc[0]
+        for i, typ in enumerate(down_block_types):
+            cin, out = out, boc[i]
+            kw = dict(in_channels=cin, out_channels=out, num_layers=lpb[i], add_downsample=i != nb - 1, **common)
+            if typ == "CrossAttnDownBlock2D":
+                self.down_blocks.append(VideoLDMCrossAttnDownBlock(num_attention_heads=heads[i], cross_attention_dim=cad[i],
+                                                                   transformer_layers_per_block=tlpb[i], **kw))
+            elif typ == "DownBlock2D":
+                self.down_blocks.append(VideoLDMDownBlock(**kw))
+            else:
+                raise NotImplementedError(typ)
+        self.mid_block = VideoLDMUNetMidBlock2DCrossAttn(in_channels=boc[-1], num_attention_heads=heads[-1], cross_attention_dim=cad[-1],
+                                                         transformer_layers_per_block=tlpb[-1], **common)
+        self.up_blocks = nn.ModuleList()
+        rboc, rheads, rlpb, rtlpb, rcad = boc[::-1], heads[::-1], lpb[::-1], tlpb[::-1], cad[::-1]
+        out = rboc[0]
+        for i, typ in enumerate(up_block_types):
+            prev, out = out, rboc[i]
+            cin = rboc[min(i + 1, nb - 1)]
+            kw = dict(in_channels=cin, out_channels=out, prev_output_channel=prev, num_layers=rlpb[i] + 1, add_upsample=i != nb - 1, **common)
+            if typ == "CrossAttnUpBlock2D":
+                self.up_blocks.append(VideoLDMCrossAttnUpBlock(num_attention_heads=rheads[i], cross_attention_dim=rcad[i],
+                                                               transformer_layers_per_block=rtlpb[i], **kw))
+            elif typ == "UpBlock2D":
+                self.up_blocks.append(VideoLDMUpBlock(**kw))
+            else:
+                raise NotImplementedError(typ)
+        self.conv_norm_out = GroupNorm(norm_num_groups, boc[0], norm_eps)
+        self.conv_act = SiLU()
+        self.conv_out = Conv2d(boc[0], out_channels, 3, padding=1)
+        self._packed = False
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def pack(self):
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            blk.pack()
+        self.conv_in.pack()
+        self.conv_out.pack()
+        self._packed = True
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._packed = False
+        return out
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states=None, first_frame_latents=None, frame_stride=None, return_dict=True, **unused):
+        if not self._packed:
+            self.pack()
+        dev = sample.device
+        cfgd = self.config
+        if cfgd.first_frame_condition_mode != "none":
+            assert first_frame_latents is not None
+            sample = torch.cat([first_frame_latents.to(sample.dtype), sample], dim=2)
+        B, C, F, H, W = sample.shape
+        ctx = _Ctx(B, F, H, W, dev, self.groups)
+        c0 = cfgd.block_out_channels[0]
+        t = torch.as_tensor(timestep, device=dev).reshape(-1).float().expand(B).contiguous()
+        emb = self.time_embedding.run(ops.timestep_embedding(t, c0))
+        if self.use_frame_stride_condition:
+            fs = torch.as_tensor(frame_stride, device=dev).reshape(-1).float().expand(B).contiguous()
+            emb = ops.add(emb, self.frame_stride_embedding.run(ops.timestep_embedding(fs, c0)))
+        ctx.emb = emb
+        ehs = encoder_hidden_states.to(torch.float16)
+        ctx.L = ehs.shape[1]
+        ctx.context = ehs.reshape(B * ctx.L, -1).contiguous()
+        xin = torch.zeros((B * F * H * W, 64), dtype=torch.float16, device=dev)
+        ops.ncfhw_to_tokens(sample.to(torch.float16).contiguous(), xin, col0=0)
+        x = self.conv_in.tokens(xin, H, W)
+        skips = [x]
+        for blk in self.down_blocks:
+            blk.enter(ctx)
+            x, outs = blk.run(ctx, x)
+            skips.extend(outs)
+        self.mid_block.enter(ctx)
+        x = self.mid_block.run(ctx, x)
+        for blk in self.up_blocks:
+            blk.enter(ctx)
+            x = blk.run(ctx, x, skips)
+        x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, H * W, groups=self.groups,
+                          eps=self.conv_norm_out.eps, silu=True)
+        vtok = torch.empty((x.shape[0], 8), dtype=torch.float16, device=dev)
+        self.conv_out.tokens(x, H, W, out=vtok)
+        out = ops.tokens_to_ncfhw(vtok, B, cfgd.out_channels, F, H, W)
+        if cfgd.first_frame_condition_mode != "none":
+            out = out[:, :, 1:]
+        if not return_dict:
+            return (out,)
+        return types.SimpleNamespace(sample=out)
 
 
 # ------------------------------------------------------------------------------------------------- hook registration

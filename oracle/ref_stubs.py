@@ -111,7 +111,7 @@ def load_reference_inverse_scheduler():
     return _load(os.path.join(REFERENCE_ROOT, "consisti2v", "ddim_inverse_scheduler.py"), "_ref_ddim_inverse")
 
 
-def load_reference_consisti2v_models(attention_base=None, package="_ref_consisti2v_models"):
+def load_reference_consisti2v_models(attention_base=None, package="_ref_consisti2v_models", with_unet=False):
     """The reference's in-tree restatements of the diffusers building blocks, verbatim:
     ``consisti2v/consisti2v/models/videoldm_attention.py`` (``ConditionalAttention`` -- diffusers' ``Attention`` constructor,
     head reshapes and score arithmetic), ``videoldm_transformer_blocks.py`` (``BasicConditionalTransformerBlock`` /
@@ -197,8 +197,47 @@ def load_reference_consisti2v_models(attention_base=None, package="_ref_consisti
              GatedSelfAttentionDense=_Dummy)
         _mod("diffusers.models.modeling_utils", ModelMixin=nn.Module)
         _mod("diffusers.models.transformer_2d", Transformer2DModelOutput=Transformer2DModelOutput)
-        _mod("diffusers.models.unet_2d_blocks", DownBlock2D=_Dummy, UpBlock2D=_Dummy)
-        _mod("diffusers.models.resnet", ResnetBlock2D=ResnetBlock2D, Downsample2D=uo.Downsample2D, Upsample2D=Upsample2D)
+        class Downsample2D(uo.Downsample2D):   # diffusers signature (use_conv=True, stride-2 3x3 conv, padding 1, name "op" -> key `conv`)
+            def __init__(self, channels, use_conv=True, out_channels=None, padding=1, name="conv", **kw):
+                assert use_conv and padding == 1 and (out_channels is None or out_channels == channels)
+                super().__init__(channels)
+
+            def forward(self, x, scale=1.0):
+                return super().forward(x)
+
+        class DownBlock2D(nn.Module):   # diffusers DownBlock2D as VideoLDMDownBlock uses it: positional constructor, resnets + downsamplers
+            def __init__(self, in_channels, out_channels, temb_channels, dropout=0.0, num_layers=1, resnet_eps=1e-6,
+                         resnet_time_scale_shift="default", resnet_act_fn="swish", resnet_groups=32, resnet_pre_norm=True,
+                         output_scale_factor=1.0, add_downsample=True, downsample_padding=1):
+                super().__init__()
+                self.resnets = nn.ModuleList([
+                    ResnetBlock2D(in_channels=in_channels if i == 0 else out_channels, out_channels=out_channels, temb_channels=temb_channels,
+                                  eps=resnet_eps, groups=resnet_groups, dropout=dropout, time_embedding_norm=resnet_time_scale_shift,
+                                  non_linearity=resnet_act_fn, output_scale_factor=output_scale_factor, pre_norm=resnet_pre_norm)
+                    for i in range(num_layers)])
+                self.downsamplers = nn.ModuleList([Downsample2D(out_channels, use_conv=True, out_channels=out_channels,
+                                                                padding=downsample_padding, name="op")]) if add_downsample else None
+                self.gradient_checkpointing = False
+
+        class UpBlock2D(nn.Module):
+            def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, dropout=0.0, num_layers=1, resnet_eps=1e-6,
+                         resnet_time_scale_shift="default", resnet_act_fn="swish", resnet_groups=32, resnet_pre_norm=True,
+                         output_scale_factor=1.0, add_upsample=True):
+                super().__init__()
+                self.resnets = nn.ModuleList()
+                for i in range(num_layers):
+                    res_skip = in_channels if i == num_layers - 1 else out_channels
+                    res_in = prev_output_channel if i == 0 else out_channels
+                    self.resnets.append(ResnetBlock2D(in_channels=res_in + res_skip, out_channels=out_channels, temb_channels=temb_channels,
+                                                      eps=resnet_eps, groups=resnet_groups, dropout=dropout,
+                                                      time_embedding_norm=resnet_time_scale_shift, non_linearity=resnet_act_fn,
+                                                      output_scale_factor=output_scale_factor, pre_norm=resnet_pre_norm))
+                self.upsamplers = nn.ModuleList([Upsample2D(out_channels, use_conv=True, out_channels=out_channels)]) if add_upsample else None
+                self.gradient_checkpointing = False
+
+        _mod("diffusers.models.unet_2d_blocks", DownBlock2D=DownBlock2D, UpBlock2D=UpBlock2D, UNetMidBlock2DCrossAttn=_Dummy,
+             UNetMidBlock2DSimpleCrossAttn=_Dummy)
+        _mod("diffusers.models.resnet", ResnetBlock2D=ResnetBlock2D, Downsample2D=Downsample2D, Upsample2D=Upsample2D)
         _mod("diffusers.models.dual_transformer_2d", DualTransformer2DModel=_Dummy)
         _mod("diffusers.models.activations", get_activation=lambda name: nn.SiLU())
         import typing
@@ -212,11 +251,100 @@ def load_reference_consisti2v_models(attention_base=None, package="_ref_consisti
         att = importlib.import_module(package + ".videoldm_attention")
         blocks = importlib.import_module(package + ".videoldm_transformer_blocks")
         ublocks = importlib.import_module(package + ".videoldm_unet_blocks")
+        if with_unet:
+            _install_unet_stubs(nn, _Dummy, _Logger)
+            ublocks.unet = importlib.import_module(package + ".videoldm_unet")
     finally:
         for k in set(sys.modules) - before:
             if k.split(".")[0] in ("torchvision", "diffusers", "beartype"):
                 del sys.modules[k]
     return att, blocks, ublocks
+
+
+def _install_unet_stubs(nn, _Dummy, _Logger):
+    """What ``consisti2v/consisti2v/models/videoldm_unet.py:1-62`` imports from diffusers beyond the block files' needs.  The two
+    embedding classes are restated from the published diffusers-0.21 code (``Timesteps`` = sinusoidal embedding with
+    ``flip_sin_to_cos`` / ``downscale_freq_shift``; ``TimestepEmbedding`` = Linear -> act -> Linear); everything else is only
+    referenced by name."""
+    import math
+    import torch
+
+    class Timesteps(nn.Module):
+        def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift):
+            super().__init__()
+            self.num_channels, self.flip_sin_to_cos, self.downscale_freq_shift = num_channels, flip_sin_to_cos, downscale_freq_shift
+
+        def forward(self, timesteps):
+            half = self.num_channels // 2
+            exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / (half - self.downscale_freq_shift)
+            emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+            emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+            if self.flip_sin_to_cos:
+                emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+            return emb
+
+    class TimestepEmbedding(nn.Module):
+        def __init__(self, in_channels, time_embed_dim, act_fn="silu", out_dim=None, post_act_fn=None, cond_proj_dim=None):
+            super().__init__()
+            assert post_act_fn is None and cond_proj_dim is None and act_fn in ("silu", "swish")
+            self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+            self.act = nn.SiLU()
+            self.linear_2 = nn.Linear(time_embed_dim, out_dim or time_embed_dim)
+
+        def forward(self, sample, condition=None):
+            return self.linear_2(self.act(self.linear_1(sample)))
+
+    class UNet2DConditionOutput:
+        def __init__(self, sample):
+            self.sample = sample
+
+    emb = _mod("diffusers.models.embeddings", ImagePositionalEmbeddings=_Dummy, PatchEmbed=_Dummy, Timesteps=Timesteps,
+               TimestepEmbedding=TimestepEmbedding)
+    for n in ("GaussianFourierProjection", "ImageHintTimeEmbedding", "ImageProjection", "ImageTimeEmbedding", "PositionNet",
+              "TextImageProjection", "TextImageTimeEmbedding", "TextTimeEmbedding"):
+        setattr(emb, n, _Dummy)
+    ap = sys.modules["diffusers.models.attention_processor"]
+    ap.ADDED_KV_ATTENTION_PROCESSORS, ap.CROSS_ATTENTION_PROCESSORS = (), ()
+    _mod("diffusers.loaders", UNet2DConditionLoadersMixin=type("UNet2DConditionLoadersMixin", (), {}))
+    sys.modules["diffusers.models"].ModelMixin = nn.Module
+    _mod("diffusers.models.unet_2d_condition", UNet2DConditionOutput=UNet2DConditionOutput)
+    mu = sys.modules["diffusers.models.modeling_utils"]
+    mu.load_state_dict = mu.load_model_dict_into_meta = None
+    du = sys.modules["diffusers.utils"]
+    for n in ("CONFIG_NAME", "DIFFUSERS_CACHE", "FLAX_WEIGHTS_NAME", "HF_HUB_OFFLINE", "SAFETENSORS_WEIGHTS_NAME", "WEIGHTS_NAME",
+              "_add_variant", "_get_model_file"):
+        setattr(du, n, None)
+    du.is_accelerate_available = lambda: False
+    sys.modules["diffusers"].__version__ = "0.21.2"
+
+
+def load_reference_consisti2v_unet():
+    """The reference's WHOLE ``VideoLDMUNet3DConditionModel`` (``consisti2v/consisti2v/models/videoldm_unet.py:68-1064``: conv_in, time +
+    frame-stride embeddings, the four encoder blocks, the mid block, the four decoder blocks, conv_out, the first-frame "concat"
+    conditioning of ``forward``), imported verbatim on top of the block files of ``load_reference_consisti2v_decoder`` -- with the
+    reference's own in-tree ``ConditionalAttention`` as the base class of ``TemporalConditionalAttention`` -- and the hook functions
+    of ``consisti2v/pnp_utils.py``.  Returns (unet module, unet-blocks module, pnp_utils module)."""
+    att1, _, _ = load_reference_consisti2v_models()
+    att, blocks, ublocks = load_reference_consisti2v_models(attention_base=att1.ConditionalAttention,
+                                                            package="_ref_consisti2v_models_full", with_unet=True)
+    from oracle import unet_oracle as uo
+    before = set(sys.modules)
+    install_stubs()
+    try:
+        _mod("diffusers.models.resnet", Upsample2D=uo.Upsample2D, Downsample2D=uo.Downsample2D)
+        _mod("diffusers.models.attention_processor", AttnProcessor2_0=uo.AttnProcessor2_0, Attention=att.ConditionalAttention)
+        _mod("consisti2v")
+        _mod("consisti2v.models")
+        sys.modules["consisti2v.models.videoldm_attention"] = att
+        spec = importlib.util.spec_from_file_location("_ref_consisti2v_pnp_utils_full",
+                                                      os.path.join(REFERENCE_ROOT, "consisti2v", "pnp_utils.py"))
+        pnp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pnp)
+    finally:
+        for k in set(sys.modules) - before:
+            if k.split(".")[0] in ("torchvision", "diffusers", "consisti2v"):
+                del sys.modules[k]
+    return ublocks.unet, ublocks, pnp
 
 
 def load_reference_consisti2v_decoder():

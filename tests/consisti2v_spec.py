@@ -89,3 +89,41 @@ def run_cases(blocks, pnp_module, call, log=None):
         for i, blk in blocks.items():
             out[f"block{i}_hook_t{t}"] = call(blk, *block_inputs(i))
     return out
+
+
+# ------------------------------------------------------------------------------------------------- the whole UNet (consisti2v_unet.pt)
+# VideoLDMUNet3DConditionModel with the released model's options at toy width: 4 levels (the hooks index up_blocks[1..3]), 2 layers
+# per block, first-frame conditioning by concatenation, augmented rotary temporal attention, frame-stride conditioning.
+UNET_CFG = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64), layers_per_block=2, norm_num_groups=8,
+                cross_attention_dim=48, attention_head_dim=(2, 4, 4, 4), use_linear_projection=True, use_temporal=True, n_frames=4,
+                n_temp_heads=2, first_frame_condition_mode="concat", augment_temporal_attention=True, temp_pos_embedding="rotary",
+                use_frame_stride_condition=True)
+UNET_H, UNET_W, UNET_T, UNET_STRIDE = 8, 16, 981, 3
+
+
+def unet_inputs(seed=INPUT_SEED):
+    """[source, negative, editing] x (n_frames - 1) noisy frames, the clean first-frame latent, text tokens."""
+    g = torch.Generator().manual_seed(seed + 77)
+    r = lambda *s: torch.randn(*s, generator=g).half().float()
+    nf = UNET_CFG["n_frames"] - 1
+    sample = r(B, UNET_CFG["in_channels"], nf, UNET_H, UNET_W)
+    first = r(1, UNET_CFG["in_channels"], 1, UNET_H, UNET_W).repeat(B, 1, 1, 1, 1)   # the same clip's first frame in every branch
+    ehs = r(B, TOKENS, UNET_CFG["cross_attention_dim"])
+    return sample, first, ehs
+
+
+def run_unet_cases(unet, pnp_module, call):
+    """``call(unet, sample, t, ehs, first, frame_stride)`` -> prediction; un-hooked, then hooked at each timestep of TS_CASES (+ 101)."""
+    out = {}
+    sample, first, ehs = unet_inputs()
+    out["unet_nohook"] = call(unet, sample, UNET_T, ehs, first, UNET_STRIDE)
+    out["unet_nohook_t101"] = call(unet, sample, 101, ehs, first, UNET_STRIDE)
+    model = types.SimpleNamespace(unet=unet)
+    conv_s, spa_s, tmp_s = schedules()
+    pnp_module.register_conv_injection(model, conv_s)
+    pnp_module.register_spatial_attention_pnp(model, spa_s)
+    pnp_module.register_temp_attention_pnp(model, tmp_s)
+    for t in TS_CASES + (101,):
+        pnp_module.register_time(model, t)
+        out[f"unet_hook_t{t}"] = call(unet, sample, t, ehs, first, UNET_STRIDE)
+    return out

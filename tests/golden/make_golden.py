@@ -204,6 +204,36 @@ def gen_consisti2v():
     torch.save(fx, os.path.join(HERE, "consisti2v_decoder_hooks.pt"))
 
 
+def gen_consisti2v_unet():
+    """``consisti2v_unet.pt`` (``--consisti2v-unet``): the reference's own ``VideoLDMUNet3DConditionModel``
+    (``consisti2v/consisti2v/models/videoldm_unet.py``, every block from the reference's files, see
+    ``oracle.ref_stubs.load_reference_consisti2v_unet``) at toy width, predictions un-hooked and with the reference's own
+    ``consisti2v/pnp_utils.py`` hooks registered on ``unet.up_blocks[1..3]`` at t = 981 / 301 (t = 101: checked un-hooked)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import consisti2v_spec as spec
+    unet_mod, ublocks, pnp = ref_stubs.load_reference_consisti2v_unet()
+    unet = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).eval()
+
+    def call(u, sample, t, ehs, first, stride):
+        with torch.no_grad():
+            return u(sample, t, encoder_hidden_states=ehs, first_frame_latents=first, frame_stride=stride).sample.clone()
+    out = spec.run_unet_cases(unet, pnp, call)
+    a = out["unet_nohook"]
+    fx = {"spec": dict(cfg=spec.UNET_CFG, H=spec.UNET_H, W=spec.UNET_W, t=spec.UNET_T, frame_stride=spec.UNET_STRIDE,
+                       weight_seed=spec.WEIGHT_SEED, input_seed=spec.INPUT_SEED, pnp=spec.PNP,
+                       n_params=sum(p.numel() for p in unet.parameters())), "unet_nohook": a}
+    assert torch.equal(out["unet_nohook_t101"], out["unet_hook_t101"]), "a timestep outside every schedule must leave the UNet un-hooked"
+    for t in spec.TS_CASES:
+        h = out[f"unet_hook_t{t}"]
+        fx[f"unet_hook_t{t}"] = h
+        print(f"unet t={t}: shape {tuple(h.shape)} max {float(h.abs().max()):.3f}  source branch max {float(h[:1].abs().max()):.3f}  "
+              f"editing vs source {float((h[2] - h[0]).abs().max()):.3f}")
+    print(f"un-hooked: max {float(a.abs().max()):.3f}; hooked t=981 vs un-hooked at t=981, branches 1-2: "
+          f"{float((out['unet_hook_t981'][1:] - a[1:]).abs().max() / a.abs().max()):.3f}; source branch equal "
+          f"{bool(torch.equal(out['unet_hook_t981'][:1], a[:1]))}")
+    torch.save(fx, os.path.join(HERE, "consisti2v_unet.pt"))
+
+
 def gen_seine():
     """``seine_decoder_hooks.pt`` (``--seine``): the reference's own ``CrossAttnUpBlock3D`` (``seine/models/unet_blocks.py:444-575``
     with ``seine/models/attention.py`` / ``resnet.py`` below it, ``oracle.ref_stubs.load_reference_seine_decoder``) as stand-ins
@@ -243,6 +273,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--consisti2v" in sys.argv:
         gen_consisti2v()
+    if "--consisti2v-unet" in sys.argv:
+        gen_consisti2v_unet()
         sys.exit(0)
     if "--pipeline" in sys.argv:
         gen_ref_pipeline("mini")

@@ -2218,6 +2218,28 @@ def check_consisti2v_hooks():
     return out
 
 
+def check_consisti2v_unet():
+    """The whole ConsistI2V UNet (``anyv2v_amd/consisti2v.py:VideoLDMUNet3DConditionModel``) on the kernels vs the fixture the
+    REFERENCE's own ``VideoLDMUNet3DConditionModel`` + ``consisti2v/pnp_utils.py`` produced on the CPU in fp32
+    (``make_golden.py --consisti2v-unet``): toy width, every block type, first-frame concatenation, frame-stride conditioning."""
+    import consisti2v_spec as spec
+    from anyv2v_amd import consisti2v as c2
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "consisti2v_unet.pt"))
+    unet = spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).to(DEV)
+
+    def call(u, sample, t, ehs, first, stride):
+        h = lambda v: v.to(DEV).half()
+        return u(h(sample), t, encoder_hidden_states=h(ehs), first_frame_latents=h(first), frame_stride=stride).sample.float().cpu()
+    got = spec.run_unet_cases(unet, c2, call)
+    out = []
+    for case in ["nohook"] + [f"hook_t{t}" for t in spec.TS_CASES]:
+        out.append(_res(f"consisti2v whole UNet (toy width), {case} vs the reference's own UNet + hooks", got[f"unet_{case}"],
+                        fx[f"unet_{case}"], 8e-3))
+    out.append(dict(name="consisti2v whole UNet: a timestep outside every schedule == un-hooked (bit-equal)", err=0.0, tol=0.0,
+                    ok=bool(torch.equal(got["unet_nohook_t101"], got["unet_hook_t101"]))))
+    return out
+
+
 def check_seine_hooks():
     """the SEINE hook family (``anyv2v_amd/seine.py``) on the kernels vs the fixture the REFERENCE's own
     ``CrossAttnUpBlock3D`` + ``seine/pnp_utils.py`` produced on the CPU in fp32 (``make_golden.py --seine``): un-hooked, and with

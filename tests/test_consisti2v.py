@@ -86,3 +86,55 @@ def test_fixture_is_what_the_reference_code_produces_and_keys_match():
     for k, v in fx.items():
         if k != "spec":
             assert torch.allclose(out[k], v, rtol=1e-5, atol=1e-5 * float(v.abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------- the whole UNet
+UNET_FIXTURE = os.path.join(HERE, "golden", "consisti2v_unet.pt")
+
+
+def _native_unet():
+    from anyv2v_amd import consisti2v as c2
+    return c2, spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG))
+
+
+def _native_unet_call(u, sample, t, ehs, first, stride):
+    return u(sample.half(), t, encoder_hidden_states=ehs.half(), first_frame_latents=first.half(), frame_stride=stride).sample.float()
+
+
+def test_native_consisti2v_unet_vs_reference_fixture(monkeypatch):
+    """``VideoLDMUNet3DConditionModel.forward`` (``videoldm_unet.py:687-1026``) un-hooked and under the PnP hooks."""
+    emu.install(monkeypatch)
+    c2, unet = _native_unet()
+    fx = torch.load(UNET_FIXTURE)
+    out = spec.run_unet_cases(unet, c2, _native_unet_call)
+    assert torch.equal(out["unet_nohook_t101"], out["unet_hook_t101"])
+    for case in ["nohook"] + [f"hook_t{t}" for t in spec.TS_CASES]:
+        got, ref = out[f"unet_{case}"], fx[f"unet_{case}"]
+        assert got.shape == ref.shape == (spec.B, 4, spec.UNET_CFG["n_frames"] - 1, spec.UNET_H, spec.UNET_W)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        l2 = float((got - ref).norm() / ref.norm())
+        assert err < 8e-3 and l2 < 4e-3, (case, err, l2)   # fp16 activations / weights through ~60 layers vs the fp32 reference
+    a, h = out["unet_nohook"], out["unet_hook_t981"]
+    assert torch.equal(a[:1], h[:1])                         # the source branch never sees the hooks
+    assert float((a[1:] - h[1:]).abs().max() / a.abs().max()) > 0.05
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_unet_fixture_is_what_the_reference_code_produces_and_keys_match():
+    warnings.filterwarnings("ignore")
+    unet_mod, ublocks, pnp = ref_stubs.load_reference_consisti2v_unet()
+    ref = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).eval()
+    c2, nat = _native_unet()
+    rs, ns = ref.state_dict(), nat.state_dict()
+    assert sorted(rs.keys()) == sorted(ns.keys())
+    assert all(tuple(rs[k].shape) == tuple(ns[k].shape) for k in rs)
+    nat.load_state_dict(rs, strict=True)                     # a reference checkpoint loads unchanged
+
+    def call(u, sample, t, ehs, first, stride):
+        with torch.no_grad():
+            return u(sample, t, encoder_hidden_states=ehs, first_frame_latents=first, frame_stride=stride).sample
+    out = spec.run_unet_cases(ref, pnp, call)
+    fx = torch.load(UNET_FIXTURE)
+    for k, v in fx.items():
+        if k != "spec":
+            assert torch.allclose(out[k], v, rtol=1e-5, atol=1e-5 * float(v.abs().max())), k
