@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libanyv2v_hip.so")
-ABI_VERSION = 102   # ANYV2V_ABI_VERSION of include/anyv2v_hip.h the structures below mirror
+ABI_VERSION = 103   # ANYV2V_ABI_VERSION of include/anyv2v_hip.h the structures below mirror
 
 
 class HipExtensionMissing(RuntimeError):
@@ -82,6 +82,7 @@ SYMBOLS = {
     "anyv2v_rotary_f16": (C.c_int, [_VP, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "anyv2v_cfg_ddim_step_f16": (C.c_int, [_VP, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "anyv2v_ddim_step_f16": (C.c_int, [_VP, _VP, _VP, _F32, _F32, _F32, _F32, _I64, _VP]),
+    "anyv2v_guided_step_f16": (C.c_int, [_VP, _I64, _I32, _I32, _I32, _F32, _F32, _I32, _F32, _F32, _F32, _F32, _VP, _VP, _VP]),
     "anyv2v_set_batch_hint": (C.c_int, [_I32, _I32]),
     "anyv2v_last_error": (C.c_char_p, []),
     "anyv2v_version": (C.c_int, []),

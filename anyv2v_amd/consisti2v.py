@@ -749,6 +749,16 @@ def register_time(model, t):
             setattr(model.unet.up_blocks[res].tempo_attns[block].transformer_blocks[0].attn1.processor, "t", t)
 
 
+def clear_time(model):
+    """No hook fires until the next ``register_time`` (inversion and plain sampling run on a hook-free UNet in the reference: its
+    two stages are separate processes)."""
+    model.unet.up_blocks[1].resnets[1].t = None
+    for res, blocks in _UP_RES.items():
+        for block in blocks:
+            model.unet.up_blocks[res].attentions[block].transformer_blocks[0].attn1.processor.t = None
+            model.unet.up_blocks[res].tempo_attns[block].transformer_blocks[0].attn1.processor.t = None
+
+
 def register_conv_injection(model, injection_schedule):
     """``consisti2v/pnp_utils.py:39-128``: the native ``ResnetBlock2D.run`` holds the injection (source branch's conv features
     into the other two branches); only the schedule is attached."""

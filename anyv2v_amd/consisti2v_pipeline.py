@@ -1,0 +1,482 @@
+"""``ConditionalVideoEditingPipeline`` of the ConsistI2V backend (``consisti2v/consisti2v/pipelines/pipeline_video_editing.py:128-1579``)
+on the HIP kernels: ``encode_vae_video`` (``:1226-1258``), ``invert`` (``:715-968``), ``__call__`` (DDIM reconstruction / sampling from
+a stored latent, ``:469-711``) and ``sample_with_pnp`` (``:1261-1576``) with the reference's argument names, defaults and file
+formats, around ``anyv2v_amd.consisti2v.VideoLDMUNet3DConditionModel`` and the hook functions of ``anyv2v_amd.consisti2v``.
+
+What one denoising step is here: one UNet forward over all branches ([source | negative, editing] for PnP), then ONE elementwise
+kernel for guidance + scheduler step (``anyv2v_guided_step_f16``).  Pre-processing mirrors the reference's torchvision chains on
+torch tensors: ``ToTensor -> Resize(height) [shorter edge, bilinear, no antialias] -> CenterCrop -> Normalize(0.5, 0.5)`` for
+``encode_vae_video`` / ``invert`` (``:788-793,1233-1238``) and ``ToTensor -> Resize((height, width)) -> Normalize`` for ``__call__`` /
+``sample_with_pnp`` (``:541-547,1351-1357``).
+
+Kept from the reference because a drop-in must produce the same numbers:
+
+* ``sample_with_pnp`` builds the SOURCE branch's first-frame latent from the EDITED first frame (``:1426`` appends ``first_frame``,
+  the last tensor of the loop above it, not the image it just opened), encoded a second time (a second posterior sample);
+* frame 0 of the start latents is the "noisy first frame" of the image-unconditional branch and otherwise dropped (``:1478-1480``):
+  the UNet denoises ``video_length - 1`` frames and sees the clean first-frame latent as frame 0.
+
+Not built (the AnyV2V runners never enable them): ``use_frameinit`` (FFT noise re-initialisation, ``frameinit_utils.py``),
+``camera_motion``, ``guidance_rescale > 0``, ``eta > 0``, several clips per call, PnP with image guidance or without text guidance
+(the reference's hooks split the batch in three: ``consisti2v/pnp_utils.py:96,188,296``).
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import consisti2v as c2
+from . import ops
+from .schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMInverseScheduler, DDIMScheduler
+from .utils import LatentTrajectory, load_ddim_latents_at_t
+
+logger = logging.getLogger(__name__)
+
+# The released ``TIGER-Lab/ConsistI2V`` ``unet/config.json`` is not in the reference tree (``run_pnp_edit.py:52-55`` downloads it).
+# This is the Stable-Diffusion-2.1-base layout ConsistI2V extends, with the video options its inference code reads
+# (``videoldm_unet.py:96-147``); a local ``unet/config.json`` overrides it.
+CONSISTI2V_UNET_CONFIG = dict(
+    sample_size=32, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, norm_num_groups=32,
+    cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20), use_linear_projection=True, use_temporal=True, n_frames=16,
+    n_temp_heads=8, first_frame_condition_mode="concat", augment_temporal_attention=True, temp_pos_embedding="rotary",
+    use_frame_stride_condition=True)
+
+
+class AnimationPipelineOutput:
+    def __init__(self, videos):
+        self.videos = videos
+
+
+# ------------------------------------------------------------------------------------------------- pre-processing
+def _to_tensor(img: Image.Image) -> torch.Tensor:
+    return torch.from_numpy(np.asarray(img.convert("RGB"), dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+
+
+def _resize(x: torch.Tensor, size) -> torch.Tensor:
+    """torchvision ``Resize(size, antialias=None)`` of a tensor image: bilinear, ``align_corners=False``, no antialiasing; an int
+    matches the shorter edge and scales the longer one to ``int(size * long / short)``."""
+    H, W = x.shape[-2:]
+    if isinstance(size, int):
+        short, long = (H, W) if H <= W else (W, H)
+        new_long = int(size * long / short)
+        size = (size, new_long) if H <= W else (new_long, size)
+    size = tuple(int(s) for s in size)
+    if size == (H, W):
+        return x
+    return torch.nn.functional.interpolate(x[None], size=size, mode="bilinear", align_corners=False, antialias=False)[0]
+
+
+def _center_crop(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    H, W = x.shape[-2:]
+    if H < h or W < w:
+        raise ValueError(f"frame of {H} x {W} is smaller than the {h} x {w} crop")
+    top, left = int(round((H - h) / 2.0)), int(round((W - w) / 2.0))
+    return x[..., top:top + h, left:left + w]
+
+
+def frame_to_pixels(img: Image.Image, height: int, width: int, crop: bool) -> torch.Tensor:
+    """[1, 3, height, width] in [-1, 1].  ``crop``: the ``Resize(height) + CenterCrop`` chain; else ``Resize((height, width))``."""
+    x = _to_tensor(img)
+    x = _center_crop(_resize(x, height), height, width) if crop else _resize(x, (height, width))
+    return ((x - 0.5) / 0.5)[None]
+
+
+# ------------------------------------------------------------------------------------------------- the pipeline
+class ConditionalVideoEditingPipeline:
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet: Optional[c2.VideoLDMUNet3DConditionModel] = None, scheduler=None):
+        self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
+        self.vae_scale_factor = 8
+        self._device = torch.device("cpu")
+        self.freq_filter = None
+
+    # ------------------------------------------------------------------ construction / plumbing
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.float16, unet_config: Optional[dict] = None,
+                        random_init_seed: Optional[int] = None, **kw):
+        """``<path>/unet/config.json`` + ``diffusion_pytorch_model.safetensors`` (the reference's key naming), ``<path>/vae``,
+        ``<path>/text_encoder`` + ``tokenizer`` and ``<path>/scheduler/scheduler_config.json`` when a local copy exists.  There is no
+        network here: for the hub id without a local copy, random weights of the configured architecture are used when
+        ``random_init_seed`` (or ANYV2V_RANDOM_INIT_SEED) is given, with the synthetic VAE / text encoder."""
+        import json
+        if torch_dtype != torch.float16:
+            raise ValueError("the HIP kernels compute in fp16 (fp32 accumulate); torch_dtype must be torch.float16")
+        root = str(pretrained_model_name_or_path)
+        cfg_json = os.path.join(root, "unet", "config.json")
+        cfg = dict(CONSISTI2V_UNET_CONFIG)
+        if unet_config is not None:
+            cfg = dict(unet_config)
+        elif os.path.isfile(cfg_json):
+            with open(cfg_json) as f:
+                cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        unet = c2.VideoLDMUNet3DConditionModel(**cfg)
+        wpath = os.path.join(root, "unet", "diffusion_pytorch_model.safetensors")
+        if os.path.isfile(wpath):
+            from safetensors.torch import load_file
+            unet.load_state_dict(load_file(wpath), strict=True)
+        else:
+            seed = random_init_seed
+            if seed is None and os.environ.get("ANYV2V_RANDOM_INIT_SEED") is not None:
+                seed = int(os.environ["ANYV2V_RANDOM_INIT_SEED"])
+            if seed is None:
+                raise FileNotFoundError(f"no UNet weights under {root!r} (expected unet/diffusion_pytorch_model.safetensors) and no network; "
+                                        "pass random_init_seed= (or ANYV2V_RANDOM_INIT_SEED) to run with random weights")
+            init_random_weights_(unet, seed)
+        pipe = cls(unet=unet, scheduler=DDIMScheduler.from_pretrained(root, subfolder="scheduler", **_sched_defaults(root)))
+        vpath = os.path.join(root, "vae", "diffusion_pytorch_model.safetensors")
+        if os.path.isfile(vpath):
+            from safetensors.torch import load_file
+
+            from .encoders import NativeVAE
+            pipe.vae = NativeVAE(state_dict=load_file(vpath))
+        if os.path.isdir(os.path.join(root, "text_encoder")):
+            from .encoders import attach_native_clip_encoders
+            attach_native_clip_encoders(pipe, root)
+        if pipe.vae is None or pipe.text_encoder is None:
+            from .encoders import SyntheticTextEncoder, SyntheticVAE
+            pipe.vae = pipe.vae or SyntheticVAE()
+            pipe.text_encoder = pipe.text_encoder or SyntheticTextEncoder(dim=int(_first(cfg["cross_attention_dim"])))
+        return pipe
+
+    def to(self, device):
+        self._device = torch.device(device)
+        self.unet.to(self._device)
+        for m in (self.vae, self.text_encoder):
+            if m is not None and hasattr(m, "to"):
+                m.to(self._device)
+        return self
+
+    def register_modules(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def _execution_device(self):
+        return self._device
+
+    def progress_bar(self, iterable=None, total=None):
+        return iterable
+
+    # ------------------------------------------------------------------ checks / encoders
+    def check_inputs(self, prompt, height, width, callback_steps=1, first_frame_paths=None):
+        """``pipeline_video_editing.py:390-406``."""
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if first_frame_paths is not None and (not isinstance(prompt, str) and not isinstance(first_frame_paths, list)):
+            raise ValueError(f"`first_frame_paths` has to be of type `str` or `list` but is {type(first_frame_paths)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0)):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+
+    @staticmethod
+    def _one(x, what):
+        if isinstance(x, (list, tuple)):
+            if len(x) != 1:
+                raise NotImplementedError(f"one clip per call: got {len(x)} {what}")
+            return x[0]
+        return x
+
+    @staticmethod
+    def _guidance_mode(guidance_scale_txt, guidance_scale_img):
+        """``:770-775``: None / "text" ([uncond, text]) / "both" ([uncond, image, image + text])."""
+        mode = None
+        if guidance_scale_txt > 1.0:
+            mode = "text"
+        if guidance_scale_img > 1.0:
+            mode = "both"
+        return mode
+
+    def _encode_prompt(self, prompt, device, num_videos_per_prompt, do_classifier_free_guidance, negative_prompt):
+        """``:261-351``: last hidden state of the text encoder (final LayerNorm applied), rows [uncond (, uncond), text]."""
+        if num_videos_per_prompt != 1:
+            raise NotImplementedError("num_videos_per_prompt > 1")
+        prompt = self._one(prompt, "prompts")
+        te = self.text_encoder.encode(prompt, device, None).to(torch.float16)
+        if do_classifier_free_guidance:
+            neg = "" if negative_prompt is None else self._one(negative_prompt, "negative prompts")
+            if not isinstance(neg, str):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(neg)} != {type(prompt)}.")
+            ue = self.text_encoder.encode(neg, device, None).to(torch.float16)
+            te = torch.cat([ue, te] if do_classifier_free_guidance == "text" else [ue, ue, te])
+        return te
+
+    def _first_frame_latent(self, path_or_image, height, width, crop, device):
+        """One first-frame image -> sampled, scaled VAE latent [1, 4, h, w] (``:796-833``)."""
+        img = path_or_image if isinstance(path_or_image, Image.Image) else Image.open(path_or_image).convert("RGB")
+        return self.vae.encode_pixels(frame_to_pixels(img, height, width, crop), device)
+
+    def encode_vae_video(self, video: List[Image.Image], device, height: int = 576, width: int = 1024):
+        """``:1226-1258``: every frame encoded on its own (one posterior sample per frame) -> [1, 4, F, h, w]."""
+        lat = [self.vae.encode_pixels(frame_to_pixels(f, height, width, True), device)[0] for f in video]
+        return torch.stack(lat).permute(1, 0, 2, 3)[None].contiguous()
+
+    def decode_latents(self, latents, first_frames=None):
+        """``:353-371``: frame-by-frame decode -> float32 numpy [b, c, f, H, W] in [0, 1]."""
+        video = self.vae.decode_video(latents.to(torch.float16), decode_chunk_size=1)    # [1, 3, F, H, W] in [-1, 1]
+        if first_frames is not None:
+            video = torch.cat([first_frames.unsqueeze(2).to(video), video], dim=2)
+        return (video / 2 + 0.5).clamp(0, 1).detach().cpu().float().numpy()
+
+    def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator, latents=None,
+                        noise_sampling_method="vanilla", noise_alpha=1.0):
+        """``:408-466`` (one generator; the noise is drawn on the host so that a seed means the same latents on any device)."""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            if isinstance(generator, list):
+                raise NotImplementedError("a list of generators")
+            r = lambda s: torch.randn(s, generator=generator, dtype=torch.float32)
+            a2 = noise_alpha ** 2
+            if noise_sampling_method == "vanilla":
+                latents = r(shape)
+            elif noise_sampling_method == "pyoco_mixed":
+                base = r(shape[:2] + (1,) + shape[3:]) * math.sqrt(a2 / (1 + a2))
+                latents = base + r(shape) * math.sqrt(1 / (1 + a2))
+            elif noise_sampling_method == "pyoco_progressive":
+                latents = r(shape)
+                ind = r(shape) * math.sqrt(1 / (1 + a2))
+                for j in range(1, video_length):
+                    latents[:, :, j] = latents[:, :, j - 1] * math.sqrt(a2 / (1 + a2)) + ind[:, :, j]
+            else:
+                raise ValueError(noise_sampling_method)
+        elif tuple(latents.shape) != shape:
+            raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
+        return latents.to(device=device, dtype=dtype) * self.scheduler.init_noise_sigma
+
+    # ------------------------------------------------------------------ the loop
+    def _common(self, prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt, eta,
+                guidance_rescale, use_frameinit, camera_motion):
+        if first_frame_paths is not None and first_frames is not None:
+            raise ValueError("Only one of `first_frame_paths` and `first_frames` can be passed.")
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps, first_frame_paths)
+        if use_frameinit or camera_motion is not None or guidance_rescale > 0.0 or eta != 0.0 or num_videos_per_prompt != 1:
+            raise NotImplementedError("use_frameinit / camera_motion / guidance_rescale / eta / num_videos_per_prompt are not built "
+                                      "(the AnyV2V runners leave them off)")
+        if first_frames is not None:
+            raise NotImplementedError("pass the first frame as a path or PIL image (first_frame_paths)")
+        if latents is not None and latents.shape[0] != 1:
+            raise NotImplementedError(f"one clip per call: latents batch {latents.shape[0]}")
+        return height, width
+
+    def _denoise(self, latents, ff_input, text_embeddings, timesteps, frame_stride, branches, g_img, g_txt, source=None, on_step=None):
+        """``latents`` [1, C, F - 1, h, w]; ``ff_input`` [nb, C, 1, h, w]; ``branches`` = (b_unc, b_img, b_txt) of the guided rows;
+        ``source(t)`` -> the source branch's latents at t (PnP: row 0 of the batch)."""
+        n_guided = ff_input.shape[0] - (1 if source is not None else 0)
+        latents = latents.to(torch.float16).contiguous()
+        ehs = text_embeddings.contiguous()
+        ff = ff_input.to(torch.float16).contiguous()
+        pred = self.scheduler.prediction
+        for t in timesteps:
+            t = int(t)
+            rows = [latents] * n_guided
+            if source is not None:
+                rows = [source(t)] + rows
+                c2.register_time(self, t)
+            x = self.scheduler.scale_model_input(torch.cat(rows) if len(rows) > 1 else latents, t)
+            e = self.unet(x, t, encoder_hidden_states=ehs, first_frame_latents=ff, frame_stride=frame_stride).sample.contiguous()
+            latents = ops.guided_step(e, latents, self.scheduler.coefficients(t), b_unc=branches[0], b_img=branches[1], b_txt=branches[2],
+                                      g_img=g_img, g_txt=g_txt, prediction=pred)
+            if on_step is not None:
+                on_step(t, latents)
+        return latents
+
+    @staticmethod
+    def _branches(mode, offset=0):
+        if mode is None:
+            return (-1, -1, offset)
+        if mode == "text":
+            return (offset, -1, offset + 1)
+        return (offset, offset + 1, offset + 2)
+
+    def _ff_rows(self, mode, clean, noisy):
+        """First-frame latent of every guided branch (``:896-903``): the image-unconditional branch of "both" sees the NOISY one."""
+        if mode is None:
+            return [clean]
+        if mode == "text":
+            return [clean, clean]
+        return [noisy, clean, clean]
+
+    def _finish(self, latents, first_frame_latents, output_type, return_dict):
+        latents = torch.cat([first_frame_latents.unsqueeze(2).to(latents), latents], dim=2)
+        if output_type == "latent":      # (extension: the reference returns latents from ``invert`` only)
+            return AnimationPipelineOutput(videos=latents)
+        video = self.decode_latents(latents)
+        if output_type == "tensor":
+            video = torch.from_numpy(video)
+        if not return_dict:
+            return video
+        return AnimationPipelineOutput(videos=video)
+
+    # ------------------------------------------------------------------ ``__call__`` (:469-711)
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale_txt: float = 7.5, guidance_scale_img: float = 2.0,
+                 negative_prompt=None, num_videos_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "tensor", return_dict: bool = True, callback=None,
+                 callback_steps: Optional[int] = 1, first_frame_paths=None, first_frames=None, noise_sampling_method: str = "vanilla",
+                 noise_alpha: float = 1.0, guidance_rescale: float = 0.0, frame_stride: Optional[int] = None, use_frameinit: bool = False,
+                 frameinit_noise_level: int = 999, camera_motion: str = None, ddim_init_latents_t_idx: Optional[int] = 0, **kwargs):
+        height, width = self._common(prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt,
+                                     eta, guidance_rescale, use_frameinit, camera_motion)
+        device = self._execution_device
+        mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
+        c2.clear_time(self)
+        text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, mode, negative_prompt)
+        if first_frame_paths is None:
+            raise NotImplementedError("sampling without a first frame (first_frame_condition_mode 'none')")
+        clean = self._first_frame_latent(self._one(first_frame_paths, "first frames"), height, width, False, device)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]
+        latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
+                                       noise_sampling_method, noise_alpha)
+        noisy, latents = latents[:, :, 0], latents[:, :, 1:]
+        ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
+        latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode),
+                                guidance_scale_img, guidance_scale_txt,
+                                on_step=(lambda t, x: callback(t, t, x)) if callback is not None else None)
+        return self._finish(latents, clean, output_type, return_dict)
+
+    # ------------------------------------------------------------------ ``invert`` (:715-968)
+    @torch.no_grad()
+    def invert(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None, width: Optional[int] = None,
+               num_inference_steps: int = 50, guidance_scale_txt: float = 7.5, guidance_scale_img: float = 2.0, negative_prompt=None,
+               num_videos_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+               output_type: Optional[str] = "tensor", return_dict: bool = True, callback=None, callback_steps: Optional[int] = 1,
+               first_frame_paths=None, first_frames=None, noise_sampling_method: str = "pyoco_mixed", noise_alpha: float = 1.0,
+               guidance_rescale: float = 0.0, frame_stride: Optional[int] = None, use_frameinit: bool = False,
+               frameinit_noise_level: int = 999, camera_motion: str = None, output_dir: Optional[str] = None,
+               return_trajectory: bool = False, background_save: bool = False, **kwargs):
+        """With ``self.scheduler`` an inverse scheduler: clean video latents -> noise, every step's latents (the clean first-frame
+        latent as frame 0) written to ``output_dir/ddim_latents_{t}.pt``.  ``videos``: [1, n_steps, C, F, h, w], noisiest first."""
+        height, width = self._common(prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt,
+                                     eta, guidance_rescale, use_frameinit, camera_motion)
+        device = self._execution_device
+        mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
+        c2.clear_time(self)
+        text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, mode, negative_prompt)
+        if first_frame_paths is None:
+            raise NotImplementedError("inversion without a first frame (first_frame_condition_mode 'none')")
+        clean = self._first_frame_latent(self._one(first_frame_paths, "first frames"), height, width, True, device)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
+                                       noise_sampling_method, noise_alpha)
+        noisy, latents = latents[:, :, 0], latents[:, :, 1:]
+        ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
+        traj = LatentTrajectory()
+        first = clean.unsqueeze(2).to(torch.float16)
+
+        def keep(t, x):
+            traj[t] = torch.cat([first, x], dim=2)
+            if callback is not None:
+                callback(t, t, x)
+        latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode),
+                                guidance_scale_img, guidance_scale_txt, on_step=keep)
+        ts = [int(t) for t in self.scheduler.timesteps]
+        if output_dir is not None:
+            traj.save(output_dir, background=background_save)
+            logger.info(f"saved noisy latents for {len(ts)} timesteps to {output_dir}")
+        self._last_trajectory = traj
+        if return_trajectory:
+            return traj
+        inverted = torch.stack([traj[t] for t in reversed(ts)], 1)
+        if output_type == "latent":
+            return AnimationPipelineOutput(videos=inverted)
+        video = self.decode_latents(latents)
+        if output_type == "tensor":
+            video = torch.from_numpy(video)
+        if not return_dict:
+            return video
+        return AnimationPipelineOutput(videos=video)
+
+    # ------------------------------------------------------------------ ``sample_with_pnp`` (:1261-1576)
+    @torch.no_grad()
+    def sample_with_pnp(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None,
+                        width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale_txt: float = 7.5,
+                        guidance_scale_img: float = 2.0, negative_prompt=None, num_videos_per_prompt: Optional[int] = 1, eta: float = 0.0,
+                        generator=None, latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "tensor",
+                        return_dict: bool = True, callback=None, callback_steps: Optional[int] = 1, first_frame_paths=None,
+                        first_frames=None, noise_sampling_method: str = "vanilla", noise_alpha: float = 1.0, guidance_rescale: float = 0.0,
+                        frame_stride: Optional[int] = None, use_frameinit: bool = False, frameinit_noise_level: int = 999,
+                        camera_motion: str = None, ddim_init_latents_t_idx: Optional[int] = 0, ddim_inv_latents_path=None,
+                        ddim_inv_prompt: Union[str, List[str]] = None, ddim_inv_1st_frame_path=None, **kwargs):
+        """Batch rows [source (inversion prompt, stored latents at t) | negative, editing]; the hooks registered with
+        ``anyv2v_amd.consisti2v.register_*`` copy the source row's features into the other two on their schedules."""
+        height, width = self._common(prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt,
+                                     eta, guidance_rescale, use_frameinit, camera_motion)
+        device = self._execution_device
+        mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
+        if mode != "text":
+            raise NotImplementedError("sample_with_pnp needs text guidance only (guidance_scale_txt > 1, guidance_scale_img <= 1): the hooks "
+                                      "split the batch in [source, negative, editing] (consisti2v/pnp_utils.py:96,188,296)")
+        text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, mode, negative_prompt)
+        src_embeds = self._encode_prompt(ddim_inv_prompt, device, num_videos_per_prompt, None, None)
+        text_embeddings = torch.cat([src_embeds, text_embeddings])
+        if first_frame_paths is None or ddim_inv_1st_frame_path is None:
+            raise ValueError("sample_with_pnp needs first_frame_paths (the edited first frame) and ddim_inv_1st_frame_path")
+        edited = self._one(first_frame_paths, "first frames")
+        clean = self._first_frame_latent(edited, height, width, False, device)
+        # the reference opens ddim_inv_1st_frame_path and then encodes the EDITED frame again (:1426): a second posterior sample of it
+        self._one(ddim_inv_1st_frame_path, "inversion first frames")
+        src_first = self._first_frame_latent(edited, height, width, False, device)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]
+        latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
+                                       noise_sampling_method, noise_alpha)
+        noisy, latents = latents[:, :, 0], latents[:, :, 1:]
+        ff = torch.cat([src_first] + self._ff_rows(mode, clean, noisy)).unsqueeze(2)
+
+        def source(t):
+            return load_ddim_latents_at_t(t, ddim_inv_latents_path).to(device=device, dtype=torch.float16)[:, :, 1:]
+        try:
+            latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode, 1),
+                                    guidance_scale_img, guidance_scale_txt, source=source,
+                                    on_step=(lambda t, x: callback(t, t, x)) if callback is not None else None)
+        finally:
+            c2.clear_time(self)
+        return self._finish(latents, clean, output_type, return_dict)
+
+
+def _first(v):
+    return v[0] if isinstance(v, (list, tuple)) else v
+
+
+def _sched_defaults(root):
+    """The ConsistI2V scheduler configuration unless a local ``scheduler_config.json`` says otherwise."""
+    return {} if os.path.isfile(os.path.join(root, "scheduler", "scheduler_config.json")) else dict(CONSISTI2V_SCHEDULER_CONFIG)
+
+
+def inverse_scheduler_from_pretrained(root, subfolder="scheduler"):
+    return DDIMInverseScheduler.from_pretrained(str(root), subfolder=subfolder, **_sched_defaults(str(root)))
+
+
+def init_random_weights_(unet: c2.VideoLDMUNet3DConditionModel, seed: int):
+    """Deterministic weights of a plausible scale for runs without a checkpoint (1 / sqrt(fan_in); norms near identity; blend
+    factors 0.5 so that the temporal layers take part)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = unet.state_dict()
+    new = {}
+    for name in sorted(sd):
+        v = sd[name]
+        if name.endswith("freqs"):
+            new[name] = v.clone()
+        elif name.endswith("alpha"):
+            new[name] = torch.full_like(v, 0.5)
+        elif v.dim() >= 2:
+            new[name] = torch.randn(v.shape, generator=g) * (1.0 / v[0].numel() ** 0.5)
+        elif "norm" in name and name.endswith("weight"):
+            new[name] = torch.ones_like(v)
+        else:
+            new[name] = torch.zeros_like(v)
+    unet.load_state_dict(new)
+    return unet

@@ -158,6 +158,41 @@ __global__ void ddim_step_kernel(const half_t* __restrict__ V, const half_t* __r
     }
 }
 
+// Guidance + DDIM step on same-layout tensors (the ConsistI2V loop): E holds the UNet's prediction of every branch, n elements each.
+//   e = e_unc + g_img * (e_img - e_unc) + g_txt * (e_txt - e_img)      (b_img < 0: e_unc + g_txt * (e_txt - e_unc); b_unc < 0: e_txt)
+// each guidance operation rounded to fp16 like the reference's fp16 tensors; the step in fp32.
+__global__ void guided_step_kernel(const half_t* __restrict__ E, long long n, int b_unc, int b_img, int b_txt, float g_img, float g_txt,
+                                   int pred, float sa_t, float sb_t, float sa_p, float sb_p, const half_t* __restrict__ X,
+                                   half_t* __restrict__ Y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float e = (float)E[(long long)b_txt * n + i];
+        if (b_unc >= 0) {
+            const float eu = (float)E[(long long)b_unc * n + i];
+            if (b_img >= 0) {
+                const float ei = (float)E[(long long)b_img * n + i];
+                const float a = (float)(half_t)(g_img * (float)(half_t)(ei - eu));
+                const float b = (float)(half_t)(g_txt * (float)(half_t)(e - ei));
+                e = (float)(half_t)((float)(half_t)(eu + a) + b);
+            } else {
+                e = (float)(half_t)(eu + (float)(half_t)(g_txt * (float)(half_t)(e - eu)));
+            }
+        }
+        const float x = (float)X[i];
+        float x0, eps;
+        if (pred == 0) {          // v_prediction
+            x0 = sa_t * x - sb_t * e;
+            eps = sa_t * e + sb_t * x;
+        } else if (pred == 1) {   // epsilon
+            x0 = (x - sb_t * e) / sa_t;
+            eps = e;
+        } else {                  // sample
+            x0 = e;
+            eps = (x - sa_t * e) / sb_t;
+        }
+        Y[i] = (half_t)(sa_p * x0 + sb_p * eps);
+    }
+}
+
 static inline unsigned nblk(long long n, int t, long long cap = 65535) {
     long long b = (n + t - 1) / t;
     if (b < 1) b = 1;
@@ -305,6 +340,17 @@ extern "C" int anyv2v_ddim_step_f16(const void* V, const void* X, void* Y, float
     hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const half_t*)V,
                        (const half_t*)X, (half_t*)Y, sa_t, sb_t, sa_p, sb_p, (long long)n);
     return av_launch_status("ddim_step");
+}
+
+extern "C" int anyv2v_guided_step_f16(const void* E, int64_t n, int32_t b_unc, int32_t b_img, int32_t b_txt, float g_img, float g_txt,
+                                      int32_t prediction, float sa_t, float sb_t, float sa_p, float sb_p, const void* X, void* Y,
+                                      void* stream) {
+    AV_CHECK(E && X && Y && n > 0 && b_txt >= 0 && prediction >= 0 && prediction <= 2 && (b_img < 0 || b_unc >= 0),
+             "guided_step: bad arguments");
+    AV_CHECK(!(prediction == 1 && sa_t == 0.f) && !(prediction == 2 && sb_t == 0.f), "guided_step: this prediction type is singular at this alpha");
+    hipLaunchKernelGGL(guided_step_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const half_t*)E, (long long)n,
+                       b_unc, b_img, b_txt, g_img, g_txt, prediction, sa_t, sb_t, sa_p, sb_p, (const half_t*)X, (half_t*)Y);
+    return av_launch_status("guided_step");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -73,6 +73,10 @@ class SyntheticVAE:
         x = F.avg_pool2d(x, 8)
         return torch.einsum("oc,nchw->nohw", self.mix, x) * (self.config.scaling_factor * 4.0)
 
+    def encode_pixels(self, x, device):
+        """[n, 3, H, W] in [-1, 1] -> scaled latents [n, 4, H/8, W/8] fp16 (callers that pre-process frames their own way)."""
+        return self._enc(x.float().cpu()).to(device=device, dtype=torch.float16)
+
     def encode_image(self, image, device, height, width):
         x = _pil_to_tensor(_center_crop_wide(image, (width, height)))
         return self._enc(x).to(device=device, dtype=torch.float16)
@@ -122,6 +126,10 @@ class NativeVAE:
         mean, logvar = self.model.encode_moments(x)
         z = mean + torch.exp(0.5 * logvar) * torch.randn_like(mean) if self.sample_posterior else mean
         return z * self.config.scaling_factor
+
+    def encode_pixels(self, x, device):
+        """[n, 3, H, W] in [-1, 1] -> sampled, scaled latents [n, 4, H/8, W/8] fp16."""
+        return self._encode(x.to(device), device).to(torch.float16)
 
     def encode_image(self, image, device, height, width):
         x = _pil_batch_to_device([_center_crop_wide(image, (width, height))], device)

@@ -392,6 +392,24 @@ def ddim_step(v: torch.Tensor, x: torch.Tensor, sa_t: float, sb_t: float, sa_p: 
     return out
 
 
+PRED_V, PRED_EPSILON, PRED_SAMPLE = 0, 1, 2
+
+
+def guided_step(e: torch.Tensor, x: torch.Tensor, coef, *, b_txt: int, b_unc: int = -1, b_img: int = -1, g_txt: float = 1.0,
+                g_img: float = 1.0, prediction: int = PRED_V, out=None):
+    """e: [nb, ...] the UNet's prediction of every branch; x: one branch's latents; coef = (sa_t, sb_t, sa_p, sb_p)."""
+    lib = _lib.load()
+    assert e.is_contiguous() and x.is_contiguous() and e.dtype == x.dtype == torch.float16
+    n = x.numel()
+    assert e.numel() % n == 0 and max(b_txt, b_unc, b_img) < e.numel() // n
+    if out is None:
+        out = torch.empty_like(x)
+    sa_t, sb_t, sa_p, sb_p = (float(c) for c in coef)
+    _lib.check(lib.anyv2v_guided_step_f16(_p(e), n, b_unc, b_img, b_txt, float(g_img), float(g_txt), int(prediction), sa_t, sb_t, sa_p,
+                                          sb_p, _p(x), _p(out), _stream()), "anyv2v_guided_step_f16")
+    return out
+
+
 _HINT = [1, 1]   # mirrored for the host-side decisions (ln_gemm_supported)
 
 

@@ -27,6 +27,18 @@ I2VGEN_XL_SCHEDULER_CONFIG = dict(  # i2vgen-xl/demo.ipynb:1208-1226
     timestep_spacing="leading", rescale_betas_zero_snr=True)
 
 
+# The ConsistI2V release's ``scheduler/scheduler_config.json`` is not in the reference tree (``run_pnp_edit.py:58-61`` downloads it).
+# What the tree pins: ``configs/pipeline_256/pnp_edit.yaml:27`` quotes timesteps 981 / 921 / 801 / 581 for indices 0 / 3 / 9 / 20 of
+# 50 steps = "leading" spacing with steps_offset 1.  The rest is the Stable-Diffusion-1.x noise schedule ConsistI2V was trained on
+# (linear betas 0.00085 .. 0.012, epsilon prediction, no terminal-SNR rescale); a local ``scheduler_config.json`` overrides it.
+CONSISTI2V_SCHEDULER_CONFIG = dict(
+    num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", trained_betas=None, clip_sample=False,
+    clip_sample_range=1.0, set_alpha_to_one=True, steps_offset=1, prediction_type="epsilon", thresholding=False,
+    dynamic_thresholding_ratio=0.995, sample_max_value=1.0, timestep_spacing="leading", rescale_betas_zero_snr=False)
+
+_PREDICTION = {"v_prediction": ops.PRED_V, "epsilon": ops.PRED_EPSILON, "sample": ops.PRED_SAMPLE}
+
+
 def _cosine_betas(n: int, max_beta: float = 0.999) -> torch.Tensor:
     t = np.arange(n + 1, dtype=np.float64) / n
     abar = np.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
@@ -76,8 +88,9 @@ class _DDIMBase:
         self.initial_alpha_cumprod = self.final_alpha_cumprod
         self.num_inference_steps = None
         self.timesteps = torch.arange(n - 1, -1, -1, dtype=torch.int64)
-        if cfg["prediction_type"] != "v_prediction" or cfg["clip_sample"] or cfg["thresholding"]:
-            raise NotImplementedError("only the I2VGen-XL configuration (v_prediction, no clipping) is implemented")
+        if cfg["prediction_type"] not in _PREDICTION or cfg["clip_sample"] or cfg["thresholding"]:
+            raise NotImplementedError("prediction_type in ('v_prediction', 'epsilon', 'sample') without clipping / thresholding only")
+        self.prediction = _PREDICTION[cfg["prediction_type"]]
 
     @classmethod
     def from_pretrained(cls, repo, subfolder=None, **kw):
@@ -121,7 +134,12 @@ class _DDIMBase:
         if eta != 0.0:
             raise NotImplementedError("eta > 0 (stochastic DDIM) is not used by AnyV2V and not implemented")
         sa_t, sb_t, sa_p, sb_p = self.coefficients(int(timestep))
-        prev = ops.ddim_step(model_output, sample, sa_t, sb_t, sa_p, sb_p)
+        if self.prediction == ops.PRED_V:
+            prev = ops.ddim_step(model_output, sample, sa_t, sb_t, sa_p, sb_p)
+        else:
+            x = sample.to(torch.float16).contiguous()
+            prev = ops.guided_step(model_output.to(torch.float16).contiguous().view(1, -1), x, (sa_t, sb_t, sa_p, sb_p), b_txt=0,
+                                   prediction=self.prediction)
         if not return_dict:
             return (prev,)
         return SchedulerOutput(prev)

@@ -244,6 +244,15 @@ int anyv2v_cfg_ddim_step_f16(const void* Vtok, int32_t ldv, int32_t b_unc, int32
 int anyv2v_ddim_step_f16(const void* V, const void* X, void* Y, float sa_t, float sb_t, float sa_p, float sb_p,
                          int64_t n, void* stream);
 
+/* Guidance combine + DDIM / inverse-DDIM step (eta = 0) on same-layout tensors, any prediction type: the loop body of the
+ * ConsistI2V pipeline (consisti2v/consisti2v/pipelines/pipeline_video_editing.py:921-937 invert, :1539-1555 sample_with_pnp, :676-692
+ * __call__; scheduler arithmetic consisti2v/ddim_inverse_scheduler.py:329-369).  E: the UNet's prediction of every branch, `n`
+ * contiguous elements per branch; branch indices b_unc / b_img / b_txt:
+ *   e = e[b_unc] + g_img (e[b_img] - e[b_unc]) + g_txt (e[b_txt] - e[b_img])    "both";   b_img < 0: e[b_unc] + g_txt (e[b_txt] - e[b_unc]);
+ *   b_unc < 0: e[b_txt] (no guidance).   prediction: 0 v_prediction, 1 epsilon, 2 sample.   X / Y: `n` elements; Y may alias X. */
+int anyv2v_guided_step_f16(const void* E, int64_t n, int32_t b_unc, int32_t b_img, int32_t b_txt, float g_img, float g_txt,
+                           int32_t prediction, float sa_t, float sb_t, float sa_p, float sb_p, const void* X, void* Y, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 /* Launch heuristics (kernel family, split-K factor, GroupNorm chunking) see rows * num / den from now on; grids and bounds keep the true
  * row counts.  The PnP edit runs some steps on [negative, editing] only (steps outside every injection schedule; steps whose source
@@ -257,8 +266,8 @@ const char* anyv2v_last_error(void);
 /* ABI version = major * 100 + minor.  Descriptors carry no size field: a caller MUST be compiled against the header of the
  * library it loads (check anyv2v_version() >= the ANYV2V_ABI_VERSION it was built with) and MUST zero-initialise every
  * descriptor (new fields are appended with 0 = "off").  101: AnyV2VGemmDesc grew ln_c1 / ln_eps / reserved0 (round 3), flags
- * bits 13-16 select the persistent kernel's tile order (round 4).  102: anyv2v_ff_geglu_f16. */
-#define ANYV2V_ABI_VERSION 102
+ * bits 13-16 select the persistent kernel's tile order (round 4).  102: anyv2v_ff_geglu_f16.  103: anyv2v_guided_step_f16. */
+#define ANYV2V_ABI_VERSION 103
 int anyv2v_version(void);
 /* MFMA / LDS layout self-test used by the gpu test-suite (returns 0 when the layouts the kernels assume hold) */
 int anyv2v_selftest(void* scratch, int64_t scratch_bytes, void* stream);

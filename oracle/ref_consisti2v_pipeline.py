@@ -1,0 +1,297 @@
+"""Run the REFERENCE's own ConsistI2V pipeline class on the CPU (TEST INFRASTRUCTURE; needs /root/reference, this container only).
+
+``/root/reference/consisti2v/consisti2v/pipelines/pipeline_video_editing.py`` is imported verbatim: its
+``ConditionalVideoEditingPipeline.encode_vae_video`` (``:1226-1258``), ``invert`` (``:715-968``), ``__call__`` (``:469-711``) and
+``sample_with_pnp`` (``:1261-1576``) then run unmodified around the reference's own ``VideoLDMUNet3DConditionModel``
+(``oracle.ref_stubs.load_reference_consisti2v_unet``), its own ``consisti2v/pnp_utils.py`` hooks, its own ``consisti2v/utils.py``
+(``load_ddim_latents_at_t``) and its vendored ``consisti2v/ddim_inverse_scheduler.py``.  Stand-ins for what is absent here:
+
+* diffusers' ``DiffusionPipeline`` base (``register_modules`` / ``device`` / ``progress_bar``) and the scheduler class names the file
+  imports for type annotations;
+* torchvision's ``transforms`` (not installed): ``ToTensor`` / ``Resize`` / ``CenterCrop`` / ``Normalize`` / ``Compose`` restated from
+  torchvision's documented tensor semantics (``Resize`` of a TENSOR with ``antialias=None`` = plain bilinear,
+  ``align_corners=False``; an int size matches the SHORTER edge, the other edge is ``int(size * long / short)``; ``CenterCrop``
+  offsets are ``int(round((H - h) / 2))``) -- parity of the two pre-processing paths is pinned to this restatement, not to
+  torchvision itself;
+* the forward ``DDIMScheduler`` (diffusers, not vendored): ``ForwardDDIM`` below = the mirror image of the vendored inverse step on
+  the vendored scheduler's own ``alphas_cumprod`` (same convention as ``oracle.ref_pipeline.ForwardDDIM``);
+* VAE / CLIP text encoder / tokenizer: the deterministic toys of ``oracle.ref_pipeline``.
+
+The released model's ``scheduler_config.json`` is not in the reference tree; ``SCHED_CFG`` is the configuration
+``anyv2v_amd.schedulers.CONSISTI2V_SCHEDULER_CONFIG`` documents (timestep spacing pinned by ``configs/pipeline_256/pnp_edit.yaml:27``).
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import ref_pipeline as rp
+from . import ref_stubs
+
+SCHED_CFG = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False,
+                 set_alpha_to_one=True, steps_offset=1, prediction_type="epsilon", timestep_spacing="leading",
+                 rescale_betas_zero_snr=False)
+
+
+# ----------------------------------------------------------------------------------------------- torchvision.transforms stand-ins
+class _Compose:
+    def __init__(self, ts):
+        self.ts = ts
+
+    def __call__(self, x):
+        for t in self.ts:
+            x = t(x)
+        return x
+
+
+class _ToTensor:
+    def __call__(self, img):
+        return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+
+
+class _Resize:
+    def __init__(self, size, antialias=None):
+        assert antialias is None
+        self.size = size
+
+    def __call__(self, x):
+        H, W = x.shape[-2:]
+        if isinstance(self.size, int):
+            short, long = (H, W) if H <= W else (W, H)
+            new_short, new_long = self.size, int(self.size * long / short)
+            size = (new_short, new_long) if H <= W else (new_long, new_short)
+        else:
+            size = tuple(self.size)
+        if size == (H, W):
+            return x
+        return torch.nn.functional.interpolate(x[None], size=size, mode="bilinear", align_corners=False, antialias=False)[0]
+
+
+class _CenterCrop:
+    def __init__(self, size):
+        self.size = size
+
+    def __call__(self, x):
+        h, w = self.size
+        H, W = x.shape[-2:]
+        assert H >= h and W >= w
+        top, left = int(round((H - h) / 2.0)), int(round((W - w) / 2.0))
+        return x[..., top:top + h, left:left + w]
+
+
+class _Normalize:
+    def __init__(self, mean, std, inplace=False):
+        self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+    def __call__(self, x):
+        return (x - self.mean) / self.std
+
+
+# ----------------------------------------------------------------------------------------------- module loading
+def load_reference_consisti2v_pipeline():
+    """(pipeline module, unet module, pnp_utils module, utils module) -- everything from the reference's ``consisti2v/`` tree."""
+    import PIL.Image
+    import transformers  # noqa: F401  (the pipeline file imports CLIP class names from the real package)
+
+    unet_mod, ublocks, pnp = ref_stubs.load_reference_consisti2v_unet()
+    before = set(sys.modules)
+    ref_stubs.install_stubs()
+    root = os.path.join(ref_stubs.REFERENCE_ROOT, "consisti2v")
+
+    class _Logger:
+        def __getattr__(self, k):
+            return lambda *a, **kw: None
+
+    class BaseOutput:
+        pass
+
+    class DiffusionPipeline:
+        _progress_bar_config = {"disable": True}
+
+        def __init__(self):
+            self._device = torch.device("cpu")
+
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        @property
+        def device(self):
+            return self._device
+
+        @contextlib.contextmanager
+        def progress_bar(self, iterable=None, total=None):
+            yield types.SimpleNamespace(update=lambda *a, **k: None)
+
+    m = ref_stubs._mod
+    m("torchvision")
+    m("torchvision.io", read_video=None)
+    tf = m("torchvision.transforms", Compose=_Compose, ToTensor=_ToTensor, Resize=_Resize, CenterCrop=_CenterCrop, Normalize=_Normalize)
+    tf.functional = m("torchvision.transforms.functional")
+    m("diffusers")
+    m("diffusers.utils", is_accelerate_available=lambda: False, deprecate=lambda *a, **k: None, BaseOutput=BaseOutput,
+      logging=types.SimpleNamespace(get_logger=lambda *a, **k: _Logger()), load_image=lambda p: PIL.Image.open(p).convert("RGB"))
+    m("diffusers.configuration_utils", FrozenDict=dict)
+    m("diffusers.models", AutoencoderKL=object)
+    m("diffusers.pipelines")
+    m("diffusers.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
+    m("diffusers.schedulers", **{n: object for n in ("DDIMScheduler", "DPMSolverMultistepScheduler", "EulerAncestralDiscreteScheduler",
+                                                     "EulerDiscreteScheduler", "LMSDiscreteScheduler", "PNDMScheduler")})
+    pkg = "_ref_consisti2v_pkg"
+    try:
+        spec = importlib.util.spec_from_file_location("utils", os.path.join(root, "utils.py"))
+        utils = importlib.util.module_from_spec(spec)
+        sys.modules["utils"] = utils            # the pipeline file imports its siblings by these bare names
+        spec.loader.exec_module(utils)
+        sys.modules["pnp_utils"] = pnp
+        for sub in ("", ".models", ".utils", ".pipelines"):
+            p = types.ModuleType(pkg + sub)
+            p.__path__ = []
+            sys.modules[pkg + sub] = p
+        sys.modules[pkg + ".models.videoldm_unet"] = unet_mod
+        spec = importlib.util.spec_from_file_location(pkg + ".utils.frameinit_utils",
+                                                      os.path.join(root, "consisti2v", "utils", "frameinit_utils.py"))
+        fi = importlib.util.module_from_spec(spec)
+        sys.modules[pkg + ".utils.frameinit_utils"] = fi
+        spec.loader.exec_module(fi)
+        spec = importlib.util.spec_from_file_location(pkg + ".pipelines.pipeline_video_editing",
+                                                      os.path.join(root, "consisti2v", "pipelines", "pipeline_video_editing.py"))
+        pm = importlib.util.module_from_spec(spec)
+        sys.modules[pkg + ".pipelines.pipeline_video_editing"] = pm
+        spec.loader.exec_module(pm)
+    finally:
+        for k in set(sys.modules) - before:
+            if k.split(".")[0] in ("torchvision", "diffusers", "pnp_utils", "utils", pkg):
+                del sys.modules[k]
+    return pm, unet_mod, pnp, utils
+
+
+# ----------------------------------------------------------------------------------------------- components
+class ToyVAE(rp.ToyVAE):
+    @property
+    def dtype(self):
+        return self.mix.dtype
+
+
+class ForwardDDIM:
+    """diffusers ``DDIMScheduler`` call surface (eta 0, leading spacing, steps_offset 1) on the vendored inverse scheduler's
+    ``alphas_cumprod``: x0 / eps from the prediction (``consisti2v/ddim_inverse_scheduler.py:344-352``), then
+    ``sqrt(a_prev) x0 + sqrt(1 - a_prev) eps`` with ``a_prev`` the level one ratio BELOW t (1.0 below 0)."""
+    order, init_noise_sigma = 1, 1.0
+
+    def __init__(self, inverse_scheduler):
+        self.ac = inverse_scheduler.alphas_cumprod.double()
+        self.config = inverse_scheduler.config
+        self.timesteps, self.n = None, None
+
+    def set_timesteps(self, n, device=None):
+        self.n = n
+        r = self.config.num_train_timesteps // n
+        self.timesteps = torch.from_numpy((np.arange(0, n) * r).round()[::-1].copy().astype(np.int64) + self.config.steps_offset)
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None):
+        assert eta == 0.0
+        t = int(timestep)
+        prev = t - self.config.num_train_timesteps // self.n
+        a_t = self.ac[t]
+        a_p = self.ac[prev] if prev >= 0 else torch.tensor(1.0, dtype=torch.float64)
+        e, x = model_output.double(), sample.double()
+        pt = self.config.prediction_type
+        if pt == "epsilon":
+            x0, eps = (x - (1 - a_t).sqrt() * e) / a_t.sqrt(), e
+        elif pt == "v_prediction":
+            x0, eps = a_t.sqrt() * x - (1 - a_t).sqrt() * e, a_t.sqrt() * e + (1 - a_t).sqrt() * x
+        else:
+            raise NotImplementedError(pt)
+        return types.SimpleNamespace(prev_sample=(a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps).to(sample.dtype))
+
+
+def build_reference_pipeline(unet, dim):
+    """The reference's ``ConditionalVideoEditingPipeline`` (its real ``__init__``) around a reference UNet and the toy components.
+    Returns (pipeline, pipeline module, pnp_utils module, inverse-scheduler module)."""
+    pm, unet_mod, pnp, utils = load_reference_consisti2v_pipeline()
+    inv_mod = ref_stubs.load_reference_inverse_scheduler()
+    inv = inv_mod.DDIMInverseScheduler(**SCHED_CFG)
+    pipe = pm.ConditionalVideoEditingPipeline(vae=ToyVAE(), text_encoder=rp.ToyTextEncoder(dim), tokenizer=rp.ToyTokenizer(), unet=unet,
+                                              scheduler=inv)
+    return pipe, pm, pnp, inv_mod
+
+
+@torch.no_grad()
+def run_reference_job(unet_cfg, fill_weights, frames, edited, height, width, n_inv_steps, n_steps, t_idx, ratios, work_dir,
+                      frame_stride=3, edit_prompt="a robot", neg="blurry", cfg_txt=35.0):
+    """Stage 1 and stage 2 of the reference on ONE clip, driven as its two runners drive the pipeline
+    (``consisti2v/run_ddim_inversion.py:29-77,117-140``, ``run_pnp_edit.py:31-47,76-126``): frames and first frames are PNG FILES
+    (the pipeline opens paths); ``encode_vae_video`` -> ``invert`` (cfg 1 / 1, empty prompts, ``n_inv_steps``, files written) ->
+    ``__call__`` reconstruction from ``timesteps[t_idx]`` (cfg 1 / 1) -> ``init_pnp`` schedules -> ``sample_with_pnp`` (cfg_txt 35,
+    cfg_img 1, blend_ratio 0).  The latents handed to ``decode_latents`` are captured next to the decoded videos."""
+    unet_mod, _, _ = ref_stubs.load_reference_consisti2v_unet()
+    dim = unet_cfg["cross_attention_dim"]
+    n_frames = unet_cfg["n_frames"]
+    fdir = os.path.join(str(work_dir), "clip")
+    os.makedirs(fdir, exist_ok=True)
+    for i, f in enumerate(frames):
+        f.save(os.path.join(fdir, "%05d.png" % i))
+    first_path = os.path.join(fdir, "00000.png")
+    edited_path = os.path.join(str(work_dir), "edited.png")
+    edited.save(edited_path)
+    out_dir = os.path.join(str(work_dir), "ddim_latents")
+    dev = torch.device("cpu")
+
+    def make():
+        unet = fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**unet_cfg)).eval()
+        pipe, pm, pnp, inv_mod = build_reference_pipeline(unet, dim)
+        cap = []
+        orig = pipe.decode_latents
+        pipe.decode_latents = lambda lat, *a, **k: (cap.append(lat.detach().clone()), orig(lat, *a, **k))[1]
+        return pipe, pnp, cap
+
+    pipe, _, cap = make()                               # stage 1: a hook-free pipeline
+    inv = pipe.scheduler
+    from PIL import Image
+    frame_list = [Image.open(os.path.join(fdir, "%05d.png" % i)).convert("RGB") for i in range(n_frames)]
+    lat0 = pipe.encode_vae_video(frame_list, device=dev, height=height, width=width)
+    inverted = pipe.invert(prompt="", first_frame_paths=first_path, height=height, width=width, video_length=n_frames,
+                           num_inference_steps=n_inv_steps, guidance_scale_txt=1.0, guidance_scale_img=1.0, negative_prompt="",
+                           frame_stride=frame_stride, latents=lat0, generator=torch.Generator().manual_seed(8888), return_dict=False,
+                           output_type="latent", output_dir=out_dir).videos
+    inv_ts = [int(t) for t in inv.timesteps]
+    files = {t: torch.load(os.path.join(out_dir, f"ddim_latents_{t}.pt")) for t in inv_ts}
+    fwd = ForwardDDIM(inv)
+    fwd.set_timesteps(n_steps)
+    ts = fwd.timesteps.clone()
+    t0 = int(ts[t_idx])
+    pipe.scheduler = fwd
+    rec_video = pipe(prompt="", first_frame_paths=first_path, height=height, width=width, video_length=n_frames,
+                     num_inference_steps=n_steps, guidance_scale_txt=1.0, guidance_scale_img=1.0, negative_prompt="",
+                     frame_stride=frame_stride, latents=files[t0].clone(), generator=torch.Generator().manual_seed(8888),
+                     return_dict=True, ddim_init_latents_t_idx=t_idx).videos
+    rec_lat = cap[-1]
+
+    pipe2, pnp, cap2 = make()                           # stage 2: a fresh process in the reference
+    fwd2 = ForwardDDIM(inv)
+    fwd2.set_timesteps(n_steps)
+    pnp.register_conv_injection(pipe2, ts[: int(n_steps * ratios[0])])
+    pnp.register_spatial_attention_pnp(pipe2, ts[: int(n_steps * ratios[1])])
+    pnp.register_temp_attention_pnp(pipe2, ts[: int(n_steps * ratios[2])])
+    pipe2.register_modules(scheduler=fwd2)
+    edit_video = pipe2.sample_with_pnp(prompt=edit_prompt, first_frame_paths=edited_path, height=height, width=width, video_length=n_frames,
+                                       num_inference_steps=n_steps, guidance_scale_txt=cfg_txt, guidance_scale_img=1.0,
+                                       negative_prompt=neg, frame_stride=frame_stride, latents=files[t0].clone(),
+                                       generator=torch.manual_seed(8888), return_dict=True, ddim_init_latents_t_idx=t_idx,
+                                       ddim_inv_latents_path=out_dir, ddim_inv_prompt="", ddim_inv_1st_frame_path=first_path).videos
+    edit_lat = cap2[-1]
+    return dict(lat0=lat0, inverted=inverted, inv_ts=inv_ts, files=files, ts=[int(t) for t in ts], t0=t0, rec_video=rec_video,
+                rec_lat=rec_lat, edit_video=edit_video, edit_lat=edit_lat, out_dir=out_dir, first_path=first_path, edited_path=edited_path,
+                frames_dir=fdir, neg=neg, edit_prompt=edit_prompt, ratios=tuple(ratios), n_steps=n_steps, n_inv_steps=n_inv_steps,
+                t_idx=t_idx, cfg_txt=cfg_txt, frame_stride=frame_stride)

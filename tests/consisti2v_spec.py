@@ -127,3 +127,98 @@ def run_unet_cases(unet, pnp_module, call):
         pnp_module.register_time(model, t)
         out[f"unet_hook_t{t}"] = call(unet, sample, t, ehs, first, UNET_STRIDE)
     return out
+
+
+# ------------------------------------------------------------------------------------------------- the pipeline job (consisti2v_pipeline.pt)
+# one synthetic clip through both stages as the reference's runners drive them (run_ddim_inversion.py / run_pnp_edit.py) at toy size
+PIPE_JOB = dict(frames=UNET_CFG["n_frames"], height=64, width=128, seed=99, n_inv_steps=8, n_steps=4, t_idx=1, ratios=(0.5, 0.5, 0.75),
+                frame_stride=3, cfg_txt=35.0, edit_prompt="a robot", neg="blurry")
+
+
+def pipeline_frames():
+    """Source frames (wider than the target: the centre crop matters) and an edited first frame at the target size, as PIL images."""
+    import numpy as np
+    from PIL import Image
+    j = PIPE_JOB
+    n, H, W = j["frames"], j["height"], j["width"]
+    rng = np.random.RandomState(j["seed"])
+
+    def pic(h, w, ph):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        yy, xx = yy / h, xx / w
+        tex = rng.rand(h, w, 3).astype(np.float32)
+        img = np.stack([0.5 + 0.5 * np.sin(6.3 * (xx + ph)), yy, 0.5 + 0.5 * np.cos(6.3 * (xx * yy + ph))], -1)
+        return Image.fromarray((255 * (0.8 * img + 0.2 * tex)).clip(0, 255).astype("uint8"))
+    frames = [pic(H + 16, W + 40, i / max(n - 1, 1)) for i in range(n)]
+    edited = pic(H, W, 0.37).transpose(Image.FLIP_LEFT_RIGHT)
+    return frames, edited
+
+
+class ToyVaeAdapter:
+    """``oracle.ref_consisti2v_pipeline.ToyVAE`` behind ``anyv2v_amd.encoders``' VAE interface (what NativeVAE does around the real
+    AutoencoderKL)."""
+
+    def __init__(self, toy):
+        self.toy, self.config = toy, toy.config
+
+    def to(self, device):
+        return self
+
+    def encode_pixels(self, x, device):
+        z = self.toy.encode(x.float().cpu()).latent_dist.sample() * self.config.scaling_factor
+        return z.detach().to(device=device, dtype=torch.float16)
+
+    def decode_video(self, latents, decode_chunk_size=None):
+        z = latents[0].permute(1, 0, 2, 3).float().cpu() / self.config.scaling_factor
+        return self.toy.decode(z).sample.permute(1, 0, 2, 3)[None].float()
+
+
+def native_pipeline_job(device, trajectory_from=None, work_dir=None):
+    """Both stages on the native pipeline, driven like ``run_reference_job`` drives the reference's: returns the same keys.
+    ``trajectory_from``: {t: latents} to edit from (the reference's files) instead of the native inversion's own."""
+    from anyv2v_amd import consisti2v as c2
+    from anyv2v_amd.consisti2v_pipeline import ConditionalVideoEditingPipeline
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMInverseScheduler, DDIMScheduler
+    from anyv2v_amd.utils import LatentTrajectory
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    j = PIPE_JOB
+    H, W, n = j["height"], j["width"], j["frames"]
+    frames, edited = pipeline_frames()
+    dim = UNET_CFG["cross_attention_dim"]
+    unet = fill_weights(c2.VideoLDMUNet3DConditionModel(**UNET_CFG)).to(device)
+    tok = rp.ToyTokenizer()
+    pipe = ConditionalVideoEditingPipeline(vae=ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(dim), tok),
+                                           tokenizer=tok, unet=unet, scheduler=DDIMInverseScheduler(**CONSISTI2V_SCHEDULER_CONFIG))
+    pipe._device = torch.device(device)
+    out = {}
+    out["lat0"] = pipe.encode_vae_video(frames, pipe.device, height=H, width=W)
+    traj = pipe.invert(prompt="", first_frame_paths=frames[0], height=H, width=W, video_length=n, num_inference_steps=j["n_inv_steps"],
+                       guidance_scale_txt=1.0, guidance_scale_img=1.0, negative_prompt="", frame_stride=j["frame_stride"],
+                       latents=out["lat0"], output_type="latent", return_trajectory=True)
+    out["inv_ts"] = [int(t) for t in pipe.scheduler.timesteps]
+    out["files"] = {t: traj[t] for t in out["inv_ts"]}
+    if trajectory_from is not None:
+        traj = LatentTrajectory()
+        for t, v in trajectory_from.items():
+            traj[t] = v.to(device=device, dtype=torch.float16)
+    sched = DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG)
+    sched.set_timesteps(j["n_steps"])
+    ts = sched.timesteps.clone()
+    t0 = int(ts[j["t_idx"]])
+    pipe.register_modules(scheduler=sched)
+    out["rec_lat"] = pipe(prompt="", first_frame_paths=frames[0], height=H, width=W, video_length=n, num_inference_steps=j["n_steps"],
+                          guidance_scale_txt=1.0, guidance_scale_img=1.0, negative_prompt="", frame_stride=j["frame_stride"],
+                          latents=traj[t0].clone(), ddim_init_latents_t_idx=j["t_idx"], output_type="latent").videos
+    k = lambda r: ts[: int(j["n_steps"] * r)]
+    c2.register_conv_injection(pipe, k(j["ratios"][0]))
+    c2.register_spatial_attention_pnp(pipe, k(j["ratios"][1]))
+    c2.register_temp_attention_pnp(pipe, k(j["ratios"][2]))
+    common = dict(prompt=j["edit_prompt"], first_frame_paths=edited, height=H, width=W, video_length=n, num_inference_steps=j["n_steps"],
+                  guidance_scale_txt=j["cfg_txt"], guidance_scale_img=1.0, negative_prompt=j["neg"], frame_stride=j["frame_stride"],
+                  ddim_init_latents_t_idx=j["t_idx"], ddim_inv_latents_path=traj, ddim_inv_prompt="", ddim_inv_1st_frame_path=frames[0])
+    out["edit_lat"] = pipe.sample_with_pnp(latents=traj[t0].clone(), output_type="latent", **common).videos
+    out["edit_video"] = pipe.sample_with_pnp(latents=traj[t0].clone(), output_type="tensor", **common).videos
+    out["pipe"] = pipe
+    return out

@@ -238,6 +238,32 @@ def cfg_ddim_step(vtok, b_unc, b_cond, guidance, coef, lat, out):
     return out
 
 
+def guided_step(e, x, coef, *, b_txt, b_unc=-1, b_img=-1, g_txt=1.0, g_img=1.0, prediction=0, out=None):
+    h = lambda t: t.half().float()
+    eb = e.reshape(e.numel() // x.numel(), -1).float()
+    v = eb[b_txt]
+    if b_unc >= 0:
+        if b_img >= 0:
+            a = h(g_img * h(eb[b_img] - eb[b_unc]))
+            b = h(g_txt * h(v - eb[b_img]))
+            v = h(h(eb[b_unc] + a) + b)
+        else:
+            v = h(eb[b_unc] + h(g_txt * h(v - eb[b_unc])))
+    sa_t, sb_t, sa_p, sb_p = (float(c) for c in coef)
+    xf = x.reshape(-1).float()
+    if prediction == 0:
+        x0, eps = sa_t * xf - sb_t * v, sa_t * v + sb_t * xf
+    elif prediction == 1:
+        x0, eps = (xf - sb_t * v) / sa_t, v
+    else:
+        x0, eps = v, (xf - sa_t * v) / sb_t
+    y = (sa_p * x0 + sb_p * eps).half().reshape(x.shape)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def ddim_step(v, x, sa_t, sb_t, sa_p, sb_p, out=None):
     v, x = v.float(), x.float()
     x0 = sa_t * x - sb_t * v
@@ -273,7 +299,7 @@ def install(monkeypatch=None):
     """Replace every function of ``anyv2v_amd.ops`` with the emulation (tests only)."""
     from anyv2v_amd import ops
     names = ["gemm", "groupnorm", "layernorm", "softmax_rows", "attention", "silu", "add", "timestep_embedding", "ncfhw_to_tokens",
-             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "gather_rows", "rotary", "cfg_ddim_step", "ddim_step", "ff_geglu"]
+             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "gather_rows", "rotary", "cfg_ddim_step", "ddim_step", "guided_step", "ff_geglu"]
     g = globals()
     for n in names:
         if monkeypatch is not None:

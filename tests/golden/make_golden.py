@@ -234,6 +234,30 @@ def gen_consisti2v_unet():
     torch.save(fx, os.path.join(HERE, "consisti2v_unet.pt"))
 
 
+def gen_consisti2v_pipeline():
+    """``consisti2v_pipeline.pt`` (``--consisti2v-pipeline``): the reference's own ``ConditionalVideoEditingPipeline`` class
+    (``oracle.ref_consisti2v_pipeline``: verbatim pipeline file around the reference's UNet, hooks, inverse scheduler and
+    ``load_ddim_latents_at_t``; toy VAE / text encoder) through both stages on one synthetic clip -- ``tests/consisti2v_spec.PIPE_JOB``."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import consisti2v_spec as spec
+    from oracle import ref_consisti2v_pipeline as rcp
+    j = spec.PIPE_JOB
+    frames, edited = spec.pipeline_frames()
+    with tempfile.TemporaryDirectory() as tmp:
+        job = rcp.run_reference_job(spec.UNET_CFG, spec.fill_weights, frames, edited, j["height"], j["width"], j["n_inv_steps"],
+                                    j["n_steps"], j["t_idx"], j["ratios"], tmp, frame_stride=j["frame_stride"],
+                                    edit_prompt=j["edit_prompt"], neg=j["neg"], cfg_txt=j["cfg_txt"])
+    h = lambda x: x.detach().to(torch.float16).contiguous()
+    fx = dict(spec=dict(j), inv_ts=job["inv_ts"], ts=job["ts"], t0=job["t0"], lat0=h(job["lat0"]),
+              trajectory=h(torch.stack([job["files"][t] for t in job["inv_ts"]])), rec_lat=h(job["rec_lat"]), edit_lat=h(job["edit_lat"]),
+              edit_video=h(job["edit_video"]), rec_video=h(job["rec_video"]))
+    torch.save(fx, os.path.join(HERE, "consisti2v_pipeline.pt"))
+    print("consisti2v_pipeline.pt", {k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in fx.items() if k != "spec"})
+    print("  |edit_lat| max", float(fx["edit_lat"].float().abs().max()), " edit vs reconstruction",
+          float((fx["edit_lat"].float() - fx["rec_lat"].float()).abs().max()))
+
+
 def gen_seine():
     """``seine_decoder_hooks.pt`` (``--seine``): the reference's own ``CrossAttnUpBlock3D`` (``seine/models/unet_blocks.py:444-575``
     with ``seine/models/attention.py`` / ``resnet.py`` below it, ``oracle.ref_stubs.load_reference_seine_decoder``) as stand-ins
@@ -275,6 +299,9 @@ if __name__ == "__main__":
         gen_consisti2v()
     if "--consisti2v-unet" in sys.argv:
         gen_consisti2v_unet()
+        sys.exit(0)
+    if "--consisti2v-pipeline" in sys.argv:
+        gen_consisti2v_pipeline()
         sys.exit(0)
     if "--pipeline" in sys.argv:
         gen_ref_pipeline("mini")

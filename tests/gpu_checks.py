@@ -2240,6 +2240,26 @@ def check_consisti2v_unet():
     return out
 
 
+def check_consisti2v_pipeline():
+    """ConsistI2V end to end, pipeline level: ``anyv2v_amd.consisti2v_pipeline.ConditionalVideoEditingPipeline`` on the kernels --
+    ``encode_vae_video``, ``invert``, ``__call__`` (reconstruction), ``sample_with_pnp`` -- vs the fixture the REFERENCE's own pipeline
+    class produced on the CPU in fp32 (``make_golden.py --consisti2v-pipeline``, ``oracle/ref_consisti2v_pipeline.py``); every stage
+    starts from the reference's own trajectory.  The edit's bound carries the factor 35 of the text guidance (tests/test_consisti2v.py)."""
+    import consisti2v_spec as spec
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "consisti2v_pipeline.pt"))
+    files = {t: fx["trajectory"][i] for i, t in enumerate(fx["inv_ts"])}
+    nat = spec.native_pipeline_job(DEV, trajectory_from=files)
+    out = [dict(name="consisti2v pipeline: inversion timesteps", err=0.0, tol=0.0, ok=nat["inv_ts"] == fx["inv_ts"])]
+    out.append(_res("consisti2v pipeline: encode_vae_video", nat["lat0"].float().cpu(), fx["lat0"].float(), 3e-3))
+    for i, t in enumerate(fx["inv_ts"]):
+        out.append(_res(f"consisti2v pipeline: invert, latents written at t={t}", nat["files"][t].float().cpu(), fx["trajectory"][i].float(), 2e-2))
+    out.append(_res("consisti2v pipeline: __call__ reconstruction from t_idx 1", nat["rec_lat"].float().cpu(), fx["rec_lat"].float(), 2e-2))
+    out.append(_res("consisti2v pipeline: sample_with_pnp (text guidance 35)", nat["edit_lat"].float().cpu(), fx["edit_lat"].float(), 0.25))
+    dec = torch.from_numpy(nat["pipe"].decode_latents(fx["edit_lat"].to(DEV)))
+    out.append(_res("consisti2v pipeline: decode_latents of the reference's edited latents", dec, fx["edit_video"].float(), 4e-3))
+    return out
+
+
 def check_seine_hooks():
     """the SEINE hook family (``anyv2v_amd/seine.py``) on the kernels vs the fixture the REFERENCE's own
     ``CrossAttnUpBlock3D`` + ``seine/pnp_utils.py`` produced on the CPU in fp32 (``make_golden.py --seine``): un-hooked, and with

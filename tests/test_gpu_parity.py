@@ -235,6 +235,12 @@ def test_consisti2v_whole_unet_vs_the_references_own_unet_and_hooks():
     _assert_all(gc.check_consisti2v_unet())
 
 
+def test_consisti2v_pipeline_vs_the_references_own_pipeline_class():
+    """ConsistI2V end to end, pipeline level: inversion, reconstruction and PnP edit on the kernels vs the reference's own
+    ``ConditionalVideoEditingPipeline`` (fixture)."""
+    _assert_all(gc.check_consisti2v_pipeline())
+
+
 def test_seine_hook_family_vs_the_references_own_blocks_and_hooks():
     """SEINE's decoder blocks + PnP hooks (incl. the cross-attention hook) on the kernels vs a fixture produced by the
     reference's own code."""
