@@ -126,6 +126,19 @@ class OmegaConf:
         return out
 
     @staticmethod
+    def from_dotlist(items) -> Config:
+        """``["a.b=1", "c=text"]`` -> nested config; values parsed as YAML scalars (``consisti2v/run_pnp_edit.py:138-140``)."""
+        acc: dict = {}
+        for it in items:
+            key, _, val = str(it).partition("=")
+            node = acc
+            parts = key.strip().split(".")
+            for part in parts[:-1]:
+                node = node.setdefault(part, {})
+            node[parts[-1]] = yaml.safe_load(val) if val != "" else None
+        return Config(acc)
+
+    @staticmethod
     def to_yaml(cfg: Config, resolve: bool = False) -> str:
         return yaml.safe_dump(cfg.to_container(resolve=resolve), sort_keys=False)
 

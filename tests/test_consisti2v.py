@@ -215,3 +215,87 @@ def test_native_consisti2v_pipeline_vs_reference_fixture(monkeypatch):
         ok, err = _close(nat[k], fx[k], tol)
         assert ok, (k, err)
     _check_decode(nat, fx["edit_lat"], fx["edit_video"])
+
+
+# ------------------------------------------------------------------------------------------------- the CLI runners
+def _consisti2v_workspace(base):
+    """<base>/model (toy checkpoint: unet/config.json + safetensors in the reference's key naming), <base>/clip (PNG frames)."""
+    import json
+
+    import numpy as np
+    from PIL import Image
+    from safetensors.torch import save_file
+    from anyv2v_amd import consisti2v as c2
+    base = str(base)
+    os.makedirs(os.path.join(base, "model", "unet"), exist_ok=True)
+    unet = spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG))
+    save_file({k: v.contiguous() for k, v in unet.state_dict().items()}, os.path.join(base, "model", "unet", "diffusion_pytorch_model.safetensors"))
+    json.dump(dict(spec.UNET_CFG, _class_name="VideoLDMUNet3DConditionModel"), open(os.path.join(base, "model", "unet", "config.json"), "w"))
+    frames, edited = spec.pipeline_frames()
+    os.makedirs(os.path.join(base, "clip"), exist_ok=True)
+    W, H = spec.PIPE_JOB["width"], spec.PIPE_JOB["height"]
+    for i, f in enumerate(frames):
+        f.resize((W, H), resample=Image.Resampling.LANCZOS).save(os.path.join(base, "clip", f"{i:05d}.png"))
+    edited.save(os.path.join(base, "edited.png"))
+    return base
+
+
+def run_consisti2v_cli_stages(base, device):
+    """Stage 1 and stage 2 through the two CLIs, as two processes would run them (``python -m anyv2v_amd.consisti2v_run_*``)."""
+    from anyv2v_amd import consisti2v_run_ddim_inversion as s1, consisti2v_run_pnp_edit as s2
+    j = spec.PIPE_JOB
+    common = [f"device={device}", f"model_path={base}/model", "video_name=clip", f"video_path={base}/missing.mp4",
+              f"video_frames_path={base}/clip", f"image_size=[{j['width']},{j['height']}]", f"n_frames={j['frames']}"]
+    s1.cli(["--config", os.path.join(ROOT_DIR, "configs", "consisti2v", "pipeline_256", "ddim_inversion_256.yaml")] + common +
+           [f"output_dir={base}/ddim_inversion/clip", f"inverse_config.output_dir={base}/outputs/clip", f"inverse_config.n_steps={j['n_inv_steps']}",
+            f"recon_config.n_steps={j['n_steps']}", f"recon_config.ddim_init_latents_t_idx={j['t_idx']}"])
+    s2.cli(["--config", os.path.join(ROOT_DIR, "configs", "consisti2v", "pipeline_256", "pnp_edit.yaml")] + common +
+           [f"output_dir={base}/results/clip", f"edited_first_frame_path={base}/edited.png", f"ddim_latents_path={base}/outputs",
+            f"n_steps={j['n_steps']}", f"ddim_init_latents_t_idx={j['t_idx']}", "editing_prompt=a robot", "pnp_f_t=0.5", "pnp_spatial_attn_t=0.5",
+            "pnp_temp_attn_t=0.75"])
+
+
+ROOT_DIR = os.path.dirname(HERE)
+
+
+def check_consisti2v_cli_outputs(base):
+    from anyv2v_amd.mp4 import read_mp4
+    from PIL import Image
+    j = spec.PIPE_JOB
+    lat = sorted(os.listdir(os.path.join(base, "outputs", "clip")))
+    assert len(lat) == j["n_inv_steps"] and all(f.startswith("ddim_latents_") and f.endswith(".pt") for f in lat)
+    x = torch.load(os.path.join(base, "outputs", "clip", "ddim_latents_501.pt"))
+    assert tuple(x.shape) == (1, 4, j["frames"], j["height"] // 8, j["width"] // 8) and torch.isfinite(x.float()).all()
+    for d, fps in ((os.path.join(base, "ddim_inversion", "clip", "ddim_reconstruction"), 10.0), (os.path.join(base, "results", "clip", "a robot", "video"), 8.0)):
+        vid, f = read_mp4(d + ".mp4")
+        assert len(vid) == j["frames"] and vid[0].size == (j["width"], j["height"]) and f == fps
+        gif = Image.open(d + ".gif")
+        assert gif.n_frames == j["frames"] and gif.size == (j["width"], j["height"])
+    rec, _ = read_mp4(os.path.join(base, "ddim_inversion", "clip", "ddim_reconstruction.mp4"))
+    ed, _ = read_mp4(os.path.join(base, "results", "clip", "a robot", "video.mp4"))
+    import numpy as np
+    assert not np.array_equal(np.asarray(rec[1]), np.asarray(ed[1]))
+    return np.stack([np.asarray(f) for f in ed])
+
+
+def test_consisti2v_cli_runners_end_to_end(monkeypatch, tmp_path):
+    """``consisti2v/run_ddim_inversion.py`` -> ``run_pnp_edit.py`` as CLIs: config files with the reference's keys and dotlist
+    overrides, a checkpoint directory, PNG frames in; ``ddim_latents_{t}.pt``, reconstruction and edited gif / mp4 out; same seed ->
+    the same video."""
+    emu.install(monkeypatch)
+    base = _consisti2v_workspace(tmp_path)
+    run_consisti2v_cli_stages(base, "cpu")
+    a = check_consisti2v_cli_outputs(base)
+    run_consisti2v_cli_stages(base, "cpu")
+    b = check_consisti2v_cli_outputs(base)
+    assert (a == b).all()
+
+
+@pytest.mark.gpu
+def test_consisti2v_cli_runners_on_gpu(tmp_path):
+    """The same two CLIs on the HIP library."""
+    base = _consisti2v_workspace(tmp_path)
+    run_consisti2v_cli_stages(base, "cuda:0")
+    a = check_consisti2v_cli_outputs(base)
+    run_consisti2v_cli_stages(base, "cuda:0")
+    assert (a == check_consisti2v_cli_outputs(base)).all()
