@@ -533,7 +533,7 @@ __global__ void attn_naive_kernel(const AttnK p, const float* __restrict__ bias)
 // takes the exact softmax over it (no online rescaling), and multiplies O^T = V^T P^T.  The P registers feed the second MFMA
 // directly: a lane's scores are keys {4 lq + r + 16 kb}, and the contraction index of an MFMA may be any permutation as long as
 // both operands use it -- the V^T fragment is read in that key order (two 8-byte LDS reads).
-template <int DS, int NKB>   // DS = dpad / 32 (2..4), NKB = padded keys / 16 (even: PV contracts 32 keys per MFMA)
+template <int DS, int NKB>   // DS = dpad / 32 (2..5), NKB = padded keys / 16 (even: PV contracts 32 keys per MFMA)
 __global__ __launch_bounds__(256) void small_attn_mfma_kernel(const AttnK p) {
     constexpr int DPAD = DS * 32, SKP = NKB * 16;
     constexpr int KLD = DPAD + 8;    // halves per K row (+16 B: breaks the power-of-2 row stride for the ds_read_b128 fragments)
@@ -717,10 +717,12 @@ extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_
     int rc = fill(d, k, head_dim);
     if (rc != ANYV2V_OK) return rc;
     k.causal = (d->flags & 16) ? 1 : 0;
-    // short sequences, head_dim a multiple of 16: whole-sequence MFMA kernel (K and V^T of a head in LDS); flag bit0 = naive kernel
+    // short sequences, head_dim a multiple of 8 (16-byte chunks of a head are loaded whole): whole-sequence MFMA kernel (K and V^T of
+    // a head in LDS, zero-padded to 32 DS columns); flag bit0 = naive kernel.  DS = 5 (head_dim 136..160, ConsistI2V's temporal
+    // attention at C = 1280 / 8 heads) fits the LDS with up to 96 keys only.
     const int ds = (head_dim + 31) / 32;
-    const int nkb = d->Sk <= 96 ? 6 : (d->Sk <= 288 ? 18 : 0);
-    const bool fast = !(d->flags & 1) && head_dim % 16 == 0 && ds >= 2 && ds <= 4 && nkb > 0 && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
+    const int nkb = d->Sk <= 96 ? 6 : (d->Sk <= 288 && ds <= 4 ? 18 : 0);
+    const bool fast = !(d->flags & 1) && head_dim % 8 == 0 && ds >= 2 && ds <= 5 && nkb > 0 && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
                       d->ldv % 8 == 0 && d->ldo % 4 == 0 && av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) &&
                       (((uintptr_t)d->O) & 7) == 0 && d->heads <= 65535 && d->batch <= 65535;
     if (!fast) return launch_naive(k, (hipStream_t)stream);
@@ -737,7 +739,7 @@ extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_
         hipLaunchKernelGGL((small_attn_mfma_kernel<DS_, NKB_>), grid, dim3(256), lds, (hipStream_t)stream, k);            \
     } while (0)
     if (nkb == 6) {
-        if (ds == 2) AV_SA(2, 6); else if (ds == 3) AV_SA(3, 6); else AV_SA(4, 6);
+        if (ds == 2) AV_SA(2, 6); else if (ds == 3) AV_SA(3, 6); else if (ds == 4) AV_SA(4, 6); else AV_SA(5, 6);
     } else {
         if (ds == 2) AV_SA(2, 18); else if (ds == 3) AV_SA(3, 18); else AV_SA(4, 18);
     }

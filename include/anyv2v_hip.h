@@ -177,8 +177,8 @@ int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);
 
 /* Attention for any head_dim <= 160, used once per clip (and by the ConsistI2V hook family's temporal attention, head_dim = C / 8): image_latents_temporal_encoder (2 heads x dim 4) and the CLIP towers of
  * encode_prompt / _encode_image (pipeline_i2vgen_xl.py:224-441: text 16 heads x 64 with the causal mask, vision 16 heads x 80).
- * head_dim a multiple of 16 and Sk <= 288: a whole-sequence MFMA kernel (K and V^T of a head in LDS, exact softmax over the
- * score row block in registers); anything else, or flags bit0: one thread per (batch, head, query).  Same addressing as above
+ * head_dim a multiple of 8 in 40..128 and Sk <= 288, or in 136..160 and Sk <= 96: a whole-sequence MFMA kernel (K and V^T of a
+ * head in LDS, exact softmax over the score row block in registers); anything else, or flags bit0: one thread per (batch, head, query).  Same addressing as above
  * with explicit head_dim; flags bit4 (16): causal mask (key j visible to query s iff j <= s). */
 int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream);
 /* The same with an additive score bias: softmax(scale * Q K^T + bias[head]) V, bias fp32 [heads, Sq, Sk] shared by all batch

@@ -841,12 +841,14 @@ def check_attention(naive_too=True):
 
 # ------------------------------------------------------------------------------------------------ CLIP towers (F1)
 def check_attention_small_mfma():
-    """Whole-sequence MFMA attention of the CLIP towers (``anyv2v_attention_small_f16``: head_dim a multiple of 16, Sk <= 288) vs
+    """Whole-sequence MFMA attention of the CLIP towers (``anyv2v_attention_small_f16``: head_dim a multiple of 8 up to 160, Sk <= 288) vs
     fp32 SDPA and vs the one-thread-per-query kernel it replaces: ViT-H/14 (257 tokens, 16 x 80), the text tower (77 tokens, 16 x 64,
     causal), head_dim 128, query counts that are not multiples of the 64-query block, column windows of a fused QKV matrix."""
     out = []
+    # (head_dim 40 / 160: ConsistI2V's temporal attention at C = 320 / 1280 with 8 heads -- not multiples of 16 / five 32-column groups)
     for (B, h, S, d, causal) in [(2, 16, 257, 80, False), (3, 16, 77, 64, True), (1, 4, 200, 128, False), (2, 3, 50, 96, True),
-                                 (1, 2, 288, 64, False)]:
+                                 (1, 2, 288, 64, False), (3, 8, 24, 40, False), (2, 8, 77, 160, False), (5, 8, 16, 160, True),
+                                 (2, 4, 90, 56, False)]:
         H = h * d
         qkv = rnd(B * S, 3 * H, seed=S + d)
         o = torch.zeros(B * S, H, dtype=torch.float16, device=DEV)
@@ -860,6 +862,20 @@ def check_attention_small_mfma():
         o2 = torch.zeros_like(o)
         ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o2, naive=True, **kw)
         out.append(_res(f"attention[small mfma] == one-thread-per-query kernel S{S} d{d}", o, o2.float(), 1.5e-3))
+    # the temporal layout of the ConsistI2V blocks: one sequence per (clip, pixel), its F rows HW apart; keys = F frames + 8 gathered rows
+    Bc, Fr, HW, h, d = 2, 16, 48, 8, 40
+    C = h * d
+    q = rnd(Bc * Fr * HW, C, seed=5)
+    kv = rnd(Bc * HW * (Fr + 8), 2 * C, seed=6)
+    o = torch.zeros(Bc * Fr * HW, C, dtype=torch.float16, device=DEV)
+    kw = dict(batch=Bc * HW, heads=h, Sq=Fr, Sk=Fr + 8, inner=HW, q_strides=(Fr * HW, 1, HW), kv_strides=(HW * (Fr + 8), Fr + 8, 1),
+              scale=d ** -0.5, head_dim=d)
+    ops.attention(q, kv[:, :C], kv[:, C:], o, **kw)
+    qs = q.float().view(Bc, Fr, HW, h, d).permute(0, 2, 3, 1, 4)                      # [B, HW, h, F, d]
+    ks = kv[:, :C].float().view(Bc, HW, Fr + 8, h, d).permute(0, 1, 3, 2, 4)
+    vs = kv[:, C:].float().view(Bc, HW, Fr + 8, h, d).permute(0, 1, 3, 2, 4)
+    ref = F.scaled_dot_product_attention(qs, ks, vs).permute(0, 3, 1, 2, 4).reshape(Bc * Fr * HW, C)
+    out.append(_res("attention[small mfma] temporal layout (inner = HW), 8 x 40, 16 queries x 24 keys vs fp32 SDPA", o, ref, KTOL))
     return out
 
 

@@ -2,12 +2,13 @@
 forward + guided step at 16 frames x 256^2 / 512^2 (the reference's configs/pipeline_256, pipeline_512), random weights, eager
 launches.  `python tools/consisti2v_bench.py [256|512] [steps]` -> one JSON line.  Not the headline bench (bench.py is I2VGen-XL)."""
 import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anyv2v_amd import consisti2v as c2  # noqa: E402
 from anyv2v_amd.consisti2v_pipeline import ConditionalVideoEditingPipeline  # noqa: E402
 from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMInverseScheduler, DDIMScheduler  # noqa: E402
