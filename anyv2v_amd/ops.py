@@ -35,12 +35,30 @@ def _rowmajor(t: torch.Tensor, name: str):
 
 
 _WS = {}
+WS_SLOT = 0   # callers that enqueue on several streams at once (two step engines side by side) give each stream its own scratch
+
+
+class workspace_slot:
+    """``with ops.workspace_slot(k):`` -- the launches enqueued inside use scratch buffer ``k`` (re-entrant, host-side)."""
+
+    def __init__(self, slot: int):
+        self.slot, self.prev = int(slot), 0
+
+    def __enter__(self):
+        global WS_SLOT
+        self.prev, WS_SLOT = WS_SLOT, self.slot
+        return self
+
+    def __exit__(self, *exc):
+        global WS_SLOT
+        WS_SLOT = self.prev
+        return False
 
 
 def _workspace(device) -> torch.Tensor:
-    """Persistent fp32 scratch for split-K partial tiles (64 MiB per device; allocated once, outside any graph capture
+    """Persistent fp32 scratch for split-K partial tiles (64 MiB per device and slot; allocated once, outside any graph capture
     because the first GEMM of a process always runs eagerly during warm-up)."""
-    key = str(device)
+    key = f"{device}:{WS_SLOT}"
     if key not in _WS:
         _WS[key] = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)
     return _WS[key]

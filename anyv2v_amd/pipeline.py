@@ -175,6 +175,10 @@ class _StepEngine:
             self.sample[s].copy_(self.sample[L])
 
     def step(self, t_row: torch.Tensor, coef_row: torch.Tensor, key: tuple):
+        with ops.workspace_slot(getattr(self.pipe, "ws_slot", 0)):
+            self._step(t_row, coef_row, key)
+
+    def _step(self, t_row: torch.Tensor, coef_row: torch.Tensor, key: tuple):
         self.ctx.t_buf.copy_(t_row, non_blocking=True)
         self.coef.copy_(coef_row, non_blocking=True)
         if not self.use_graphs:
@@ -208,6 +212,7 @@ class I2VGenXLPipeline:
         self._guidance_scale = 1.0
         self._device = torch.device("cpu")
         self._engines: Dict[tuple, _StepEngine] = {}  # step engines (static buffers + HIP graphs) kept across clips, LRU
+        self.ws_slot = 0   # split-K scratch buffer of this pipeline's launches (``sibling``: a second stream needs its own)
         self.source_cache: Optional[SourceFeatureCache] = None   # set (``enable_source_cache``) by multi-edit jobs
 
     # ------------------------------------------------------------------ construction / plumbing
@@ -256,6 +261,15 @@ class I2VGenXLPipeline:
             from .encoders import attach_native_clip_encoders
             attach_native_clip_encoders(pipe, root)
         return pipe
+
+    def sibling(self, ws_slot: int = 1):
+        """A second pipeline object around the SAME components (no weights copied) with its own scheduler slot, step engines,
+        conditioning cache and scratch buffer: ``run_group_anyv2v`` edits clip k on one stream with it while this pipeline
+        inverts clip k + 1 on another."""
+        p = type(self)(vae=self.vae, text_encoder=self.text_encoder, tokenizer=self.tokenizer, image_encoder=self.image_encoder,
+                       feature_extractor=self.feature_extractor, unet=self.unet, scheduler=self.scheduler)
+        p._device, p.ws_slot = self._device, int(ws_slot)
+        return p
 
     def to(self, device):
         device = torch.device(device)

@@ -53,34 +53,72 @@ def ddim_sampling(config, first_frame, ddim_latents_at_T, pipe: I2VGenXLPipeline
                 generator=g, return_dict=True, ddim_init_latents_t_idx=ddim_init_latents_t_idx).frames[0]
 
 
-def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False,
-         pipe=None, trajectories=None):
-    """``pipe``: reuse a pipeline that is already built (``run_group_anyv2v``: both stages in one process); ``trajectories``: dict
-    filled with {absolute latents directory: LatentTrajectory} of every inversion run here (the in-HBM hand-off to stage 2)."""
-    rank, local_rank, world = init_distributed()
-    # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
-    # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
-    fp_mode = bool(frame_parallel) and world > 1
-    writer = rank == 0 or not fp_mode
-    e_rank, e_world = (0, 1) if fp_mode else (rank, world)
-    if pipe is None:
-        pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
-                                                variant="fp16", random_init_seed=random_init_seed)
-        pipe.to(device)
-        if synthetic_encoders:
-            attach_synthetic_encoders(pipe)
-        if fp_mode:
-            pipe.unet.set_frame_parallel(FrameParallel())
-    inverse_scheduler = DDIMInverseScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
-    ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
-    video_dir = template_config.video_dir
-    assert os.path.exists(video_dir), f"video_dir: {video_dir} does not exist"
-    all_active = [e for e in configs_list if e["active"] is not False]
-    for config_entry in configs_list:
-        if config_entry["active"] is False:
-            logger.info(f"Skipping config_entry: {config_entry}")
-    for config_entry in shard_entries(configs_list, e_rank, e_world):
-        entry_idx = all_active.index(config_entry)
+class _RngState:
+    """Host + device RNG state of this process (the pipelined runner parks an inversion entry between its enqueue and its finish
+    while an edit entry re-seeds everything)."""
+
+    def __init__(self, device):
+        import random
+
+        import numpy as np
+        self.device = device
+        self.py, self.np, self.cpu = random.getstate(), np.random.get_state(), torch.get_rng_state()
+        self.cuda = torch.cuda.get_rng_state(device) if device.type == "cuda" else None
+
+    def restore(self):
+        import random
+
+        import numpy as np
+        random.setstate(self.py)
+        np.random.set_state(self.np)
+        torch.set_rng_state(self.cpu)
+        if self.cuda is not None:
+            torch.cuda.set_rng_state(self.cuda, self.device)
+
+
+class Stage1:
+    """Stage 1 over a list of entries.  ``entries()`` yields one generator per entry this rank works on; a generator runs the
+    entry up to the point where the inversion is ENQUEUED (frames loaded, VAE encode, 50 steps launched, nothing read back) and
+    yields the absolute latents directory -- ``run_group_anyv2v`` edits the previous clip at that point --, then finishes it
+    (files, reconstruction).  ``main`` simply exhausts them one after the other."""
+
+    def __init__(self, template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None,
+                 frame_parallel=False, pipe=None, trajectories=None):
+        self.template_config, self.configs_list, self.device, self.logger = template_config, configs_list, device, logger
+        self.trajectories = trajectories
+        self.rank, self.local_rank, self.world = init_distributed()
+        # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
+        # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
+        self.fp_mode = bool(frame_parallel) and self.world > 1
+        self.writer = self.rank == 0 or not self.fp_mode
+        self.e_rank, self.e_world = (0, 1) if self.fp_mode else (self.rank, self.world)
+        if pipe is None:
+            pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
+                                                    variant="fp16", random_init_seed=random_init_seed)
+            pipe.to(device)
+            if synthetic_encoders:
+                attach_synthetic_encoders(pipe)
+            if self.fp_mode:
+                pipe.unet.set_frame_parallel(FrameParallel())
+        self.pipe = pipe
+        self.inverse_scheduler = DDIMInverseScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
+        self.ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
+        video_dir = template_config.video_dir
+        assert os.path.exists(video_dir), f"video_dir: {video_dir} does not exist"
+        self.all_active = [e for e in configs_list if e["active"] is not False]
+        for config_entry in configs_list:
+            if config_entry["active"] is False:
+                logger.info(f"Skipping config_entry: {config_entry}")
+
+    def entries(self):
+        for config_entry in shard_entries(self.configs_list, self.e_rank, self.e_world):
+            yield self._entry(config_entry)
+
+    def _entry(self, config_entry):
+        template_config, logger, pipe = self.template_config, self.logger, self.pipe
+        rank, world, fp_mode, writer = self.rank, self.world, self.fp_mode, self.writer
+        ddim_scheduler = self.ddim_scheduler
+        entry_idx = self.all_active.index(config_entry)
         logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
         config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
         config.video_path = os.path.join(config.video_dir, config.video_name + ".mp4")
@@ -94,7 +132,7 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             skip = flag[0]
         if skip:
             logger.info(f"### Skipping !!! {config.output_dir} already exists. ")
-            continue
+            return
         logger.info(f"config: {OmegaConf.to_yaml(config)}")
         try:
             logger.info(f"Loading frames from: {config.video_frames_path}")
@@ -112,11 +150,21 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         if config.inverse_config.null_image_inversion:
             logger.info("### Inverse a null image!")
             first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
-        seed_everything(seed_for_entry(template_config.seed, entry_idx) if e_world > 1 else template_config.seed)
+        seed_everything(seed_for_entry(template_config.seed, entry_idx) if self.e_world > 1 else template_config.seed)
         g = torch.Generator().manual_seed(template_config.seed)
-        ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, inverse_scheduler, g, write=writer)
-        if trajectories is not None:
-            trajectories[os.path.abspath(str(config.inverse_config.output_dir))] = pipe._last_trajectory
+        # launched, not read back: the files are written below (``write=False`` keeps the trajectory in HBM only for now)
+        ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, self.inverse_scheduler, g, write=False)
+        traj = pipe._last_trajectory
+        latents_dir = os.path.abspath(str(config.inverse_config.output_dir))
+        if self.trajectories is not None:
+            self.trajectories[latents_dir] = traj
+        rng = _RngState(self.device)
+        yield latents_dir
+        rng.restore()
+        if writer:
+            # ddim_latents_{t}.pt, reference format, from a background thread (every reader in anyv2v_amd.utils joins it first)
+            traj.save(config.inverse_config.output_dir, background=True)
+            logger.info(f"saving noisy latents for {len(traj)} timesteps to {config.inverse_config.output_dir}")
         recon_config = config.recon_config
         if recon_config.enable_recon:
             t_idx = recon_config.ddim_init_latents_t_idx
@@ -126,17 +174,26 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             # very inversion writes (the template's default), hand the trajectory over in memory -- the files are still
             # being written in the background; any other directory is read from disk as configured
             src = recon_config.get("ddim_latents_path", None)
-            same = src is None or os.path.abspath(str(src)) == os.path.abspath(str(config.inverse_config.output_dir))
-            traj = pipe._last_trajectory if same else str(src)
-            ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
+            same = src is None or os.path.abspath(str(src)) == latents_dir
+            ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj if same else str(src))
             reconstructed_video = ddim_sampling(recon_config, first_frame, ddim_latents_at_t, pipe, ddim_scheduler, t_idx, g)
             if writer:
-                pipe._last_trajectory.wait()  # the latents directory is renamed into place when complete
+                traj.wait()  # the latents directory is renamed into place when complete
                 os.makedirs(config.output_dir, exist_ok=True)
                 reconstructed_video = [f.resize((512, 512), resample=Image.LANCZOS) for f in reconstructed_video]
                 export_to_gif(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.gif"), fps=10)
                 logger.info(f"Saved reconstructed video to {config.output_dir}")
-        pipe._last_trajectory.wait()
+        traj.wait()
+
+
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False,
+         pipe=None, trajectories=None):
+    """``pipe``: reuse a pipeline that is already built (``run_group_anyv2v``: both stages in one process); ``trajectories``: dict
+    filled with {absolute latents directory: LatentTrajectory} of every inversion run here (the in-HBM hand-off to stage 2)."""
+    stage = Stage1(template_config, configs_list, device, logger, synthetic_encoders, random_init_seed, frame_parallel, pipe, trajectories)
+    for entry in stage.entries():
+        for _ in entry:
+            pass
 
 
 def cli(argv=None):

@@ -53,45 +53,61 @@ def output_suffix(config, ddim_init_latents_t_idx) -> str:
             + str(config.pnp_temp_attn_t))
 
 
-def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False,
-         pipe=None, trajectories=None):
-    """``pipe`` / ``trajectories``: see ``run_group_ddim_inversion.main`` -- an entry whose ``ddim_latents_path`` is a key of
-    ``trajectories`` takes the source trajectory from HBM instead of reading the ``ddim_latents_{t}.pt`` files."""
-    rank, local_rank, world = init_distributed()
-    # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
-    # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
-    fp_mode = bool(frame_parallel) and world > 1
-    writer = rank == 0 or not fp_mode
-    e_rank, e_world = (0, 1) if fp_mode else (rank, world)
-    if pipe is None:
-        pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
-                                                variant="fp16", random_init_seed=random_init_seed)
-        pipe.to(device)
-        if synthetic_encoders:
-            attach_synthetic_encoders(pipe)
-        if fp_mode:
-            pipe.unet.set_frame_parallel(FrameParallel())
-    ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
-    all_active = [e for e in configs_list if e["active"] is not False]
-    for config_entry in configs_list:
-        if config_entry["active"] is False:
-            logger.info(f"Skipping config_entry: {config_entry}")
-    my_latents, lat_shape = [], None
-    my_entries = shard_entries(configs_list, e_rank, e_world)
-    # Several edits of one clip on this rank (the demo group config: 8 edits of one clip): keep the source branch's injected features
-    # in HBM after the first edit, so that the further ones run [negative, editing] only (pipeline.SourceFeatureCache; exact).
-    # ANYV2V_SOURCE_CACHE=0 switches it off.
-    clips = [e.get("video_name") for e in my_entries]
-    if os.environ.get("ANYV2V_SOURCE_CACHE", "1") == "1" and len(clips) != len(set(clips)) and pipe.source_cache is None:
-        pipe.enable_source_cache(True)
-    loaded_trajectories = {}   # one LatentTrajectory object per clip (read once, shared by the clip's edits)
-    for config_entry in my_entries:
-        entry_idx = all_active.index(config_entry)
-        logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
-        config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
+class Stage2:
+    """Stage 2 over a list of entries: ``my_entries`` (this rank's share, list order), ``run_entry`` (one edit, files written),
+    ``latents_dir_of`` (which inversion an entry edits: ``run_group_anyv2v`` schedules the edits of a clip right behind its
+    inversion), ``finish`` (the cross-rank gather).  ``main`` runs them in list order."""
+
+    def __init__(self, template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None,
+                 frame_parallel=False, pipe=None, trajectories=None):
+        self.template_config, self.configs_list, self.device, self.logger = template_config, configs_list, device, logger
+        self.trajectories = trajectories
+        self.rank, self.local_rank, self.world = init_distributed()
+        # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
+        # the ranks inside the UNet (parallel.FrameParallel); inputs, latents and RNG draws are replicated; rank 0 writes.
+        self.fp_mode = bool(frame_parallel) and self.world > 1
+        self.writer = self.rank == 0 or not self.fp_mode
+        self.e_rank, self.e_world = (0, 1) if self.fp_mode else (self.rank, self.world)
+        if pipe is None:
+            pipe = I2VGenXLPipeline.from_pretrained(template_config.get("model_path", MODEL_ID), torch_dtype=torch.float16,
+                                                    variant="fp16", random_init_seed=random_init_seed)
+            pipe.to(device)
+            if synthetic_encoders:
+                attach_synthetic_encoders(pipe)
+            if self.fp_mode:
+                pipe.unet.set_frame_parallel(FrameParallel())
+        self.pipe = pipe
+        self.ddim_scheduler = DDIMScheduler.from_pretrained(MODEL_ID, subfolder="scheduler")
+        self.all_active = [e for e in configs_list if e["active"] is not False]
+        for config_entry in configs_list:
+            if config_entry["active"] is False:
+                logger.info(f"Skipping config_entry: {config_entry}")
+        self.my_latents, self.lat_shape = {}, None
+        self.my_entries = shard_entries(configs_list, self.e_rank, self.e_world)
+        # Several edits of one clip on this rank (the demo group config: 8 edits of one clip): keep the source branch's injected features
+        # in HBM after the first edit, so that the further ones run [negative, editing] only (pipeline.SourceFeatureCache; exact).
+        # ANYV2V_SOURCE_CACHE=0 switches it off.
+        clips = [e.get("video_name") for e in self.my_entries]
+        if os.environ.get("ANYV2V_SOURCE_CACHE", "1") == "1" and len(clips) != len(set(clips)) and pipe.source_cache is None:
+            pipe.enable_source_cache(True)
+        self.loaded_trajectories = {}   # one LatentTrajectory object per clip (read once, shared by the clip's edits)
+
+    def _config(self, config_entry):
+        config = OmegaConf.merge(self.template_config, OmegaConf.create(config_entry))
         config.video_path = os.path.join(config.video_dir, config.video_name + ".mp4")
         config.video_frames_path = os.path.join(config.video_dir, config.video_name)
         config.edited_first_frame_path = os.path.join(config.data_dir, config.edited_first_frame_path)
+        return config
+
+    def latents_dir_of(self, config_entry) -> str:
+        return os.path.abspath(str(self._config(config_entry).ddim_latents_path))
+
+    def run_entry(self, config_entry):
+        template_config, logger, pipe, device = self.template_config, self.logger, self.pipe, self.device
+        ddim_scheduler, loaded_trajectories = self.ddim_scheduler, self.loaded_trajectories
+        entry_idx = self.all_active.index(config_entry)
+        logger.info(f"[rank {self.rank}/{self.world}] Processing config_entry: {config_entry}")
+        config = self._config(config_entry)
         logger.info(f"config: {OmegaConf.to_yaml(config)}")
         for k, v in config.items():  # logs only -- the reference's `continue` continues this inner loop (:89-93)
             if "ReplaceMe" in str(v):
@@ -112,7 +128,7 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
         logger.info(f"ddim_scheduler.timesteps: {ddim_scheduler.timesteps}")
         # read the whole source trajectory once into HBM (the reference re-reads one file per step, :1134)
         tkey = (os.path.abspath(str(config.ddim_latents_path)), int(config.n_steps), int(t_idx))
-        handed = (trajectories or {}).get(tkey[0])
+        handed = (self.trajectories or {}).get(tkey[0])
         if handed is not None:
             traj = handed
         else:
@@ -122,7 +138,7 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
                     config.ddim_latents_path, device=device, timesteps=[int(t) for t in ddim_scheduler.timesteps[t_idx:]])
             traj = loaded_trajectories[tkey]
         ddim_latents_at_t = load_ddim_latents_at_t(ddim_scheduler.timesteps[t_idx], traj)
-        seed_everything(seed_for_entry(template_config.seed, entry_idx) if e_world > 1 else template_config.seed)
+        seed_everything(seed_for_entry(template_config.seed, entry_idx) if self.e_world > 1 else template_config.seed)
         random_latents = torch.randn(ddim_latents_at_t.shape, dtype=torch.float32).to(ddim_latents_at_t)  # drawn even if unused (:124)
         logger.info(f"Blending random_ratio (1 means random latent): {config.random_ratio}")
         mixed_latents = random_latents * config.random_ratio + ddim_latents_at_t * (1 - config.random_ratio)
@@ -136,11 +152,11 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             generator=torch.manual_seed(config.seed), return_dict=True, ddim_init_latents_t_idx=t_idx,
             ddim_inv_latents_path=traj, ddim_inv_prompt=config.ddim_inv_prompt, ddim_inv_1st_frame=src_1st_frame,
             output_type="latent").frames
-        my_latents.append(edited_latents)
-        lat_shape = tuple(edited_latents.shape)
+        self.my_latents[entry_idx] = edited_latents
+        self.lat_shape = tuple(edited_latents.shape)
         video = pipe.decode_latents(edited_latents, decode_chunk_size=1)  # (frame-parallel: every rank decodes its frames)
-        if not writer:
-            continue
+        if not self.writer:
+            return
         edited_video = pipe.vae.to_pil(video)
 
         output_dir = os.path.join(config.output_dir, output_suffix(config, t_idx))
@@ -155,19 +171,32 @@ def main(template_config, configs_list, device, logger, synthetic_encoders=False
             frame.save(os.path.join(output_dir, f"{name}_{i:05d}.png"))
         torch.save(edited_latents.cpu(), os.path.join(output_dir, "edited_latents.pt"))
 
-    if fp_mode:
-        import torch.distributed as dist
-        dist.barrier()
-    elif world > 1:
-        import torch.distributed as dist
-        shape = lat_shape or (1, 4, template_config.n_frames, template_config.image_size[1] // 8, template_config.image_size[0] // 8)
-        # every entry's latents reach rank 0, in entry order (a rank may have run several entries, or none)
-        gathered = gather_latents(my_latents, len(all_active), shape, torch.float16, device)
-        if rank == 0:
-            out = os.path.join(template_config.get("data_dir", "."), "gathered_latents.pt")
-            torch.save(gathered.cpu(), out)
-            logger.info(f"all_gather of the edited latents of {len(all_active)} entries from {world} ranks -> {out}")
-        dist.barrier()
+    def finish(self):
+        template_config, device = self.template_config, self.device
+        my_latents = [self.my_latents[k] for k in sorted(self.my_latents)]   # entry order, whatever order they were run in
+        if self.fp_mode:
+            import torch.distributed as dist
+            dist.barrier()
+        elif self.world > 1:
+            import torch.distributed as dist
+            shape = self.lat_shape or (1, 4, template_config.n_frames, template_config.image_size[1] // 8, template_config.image_size[0] // 8)
+            # every entry's latents reach rank 0, in entry order (a rank may have run several entries, or none)
+            gathered = gather_latents(my_latents, len(self.all_active), shape, torch.float16, device)
+            if self.rank == 0:
+                out = os.path.join(template_config.get("data_dir", "."), "gathered_latents.pt")
+                torch.save(gathered.cpu(), out)
+                self.logger.info(f"all_gather of the edited latents of {len(self.all_active)} entries from {self.world} ranks -> {out}")
+            dist.barrier()
+
+
+def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False,
+         pipe=None, trajectories=None):
+    """``pipe`` / ``trajectories``: see ``run_group_ddim_inversion.main`` -- an entry whose ``ddim_latents_path`` is a key of
+    ``trajectories`` takes the source trajectory from HBM instead of reading the ``ddim_latents_{t}.pt`` files."""
+    stage = Stage2(template_config, configs_list, device, logger, synthetic_encoders, random_init_seed, frame_parallel, pipe, trajectories)
+    for config_entry in stage.my_entries:
+        stage.run_entry(config_entry)
+    stage.finish()
 
 
 def cli(argv=None):

@@ -481,7 +481,13 @@ def main():
     ap.add_argument("--no-clip", action="store_true", help="skip the end-to-end timing of one whole clip")
     ap.add_argument("--no-multi-edit", action="store_true", help="skip the several-edits-of-one-clip timing (source feature cache)")
     ap.add_argument("--seed", type=int, default=8888)
+    ap.add_argument("--serial", action="store_true",
+                    help="the inversion step and the edit step of a pair one after the other on one stream (rounds 1-3); default: the "
+                         "job's software pipeline -- the inversion step of the NEXT clip beside the edit step of the current clip, on "
+                         "two streams, as run_group_anyv2v runs a multi-clip job")
+    ap.add_argument("--overlap", action="store_true", help="(default since round 4; kept for old command lines)")
     args = ap.parse_args()
+    args.overlap = not args.serial
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -521,7 +527,9 @@ def main():
     cond3 = dict(encoder_hidden_states=ehs, fps=fps3, image_latents=il_all, image_embeddings=ie)
     pnp_utils.clear_time(pipe)   # inversion steps run hook-free (stage 1 of the reference has no hooks registered)
     e_inv = _StepEngine(pipe, s_inv, cond1, b_unc=-1, b_cond=0, guidance=1.0, dup_slots=[])
-    e_pnp = _StepEngine(pipe, s_pnp, cond3, b_unc=1, b_cond=2, guidance=9.0, dup_slots=[1], shared_stem=True)
+    # the edit loop runs on a sibling pipeline object (same weights; its own split-K scratch), as run_group_anyv2v's stage 2 does:
+    # the two loops are enqueued on two streams
+    e_pnp = _StepEngine(pipe.sibling(ws_slot=1), s_pnp, cond3, b_unc=1, b_cond=2, guidance=9.0, dup_slots=[1], shared_stem=True)
     # as pipe.sample_with_pnp configures its three-branch engine: the source branch's prediction is never read, so its forward stops
     # behind the last hook site (exact, bit-equal; anyv2v_amd/pipeline.py)
     e_pnp.drop_src_tail = os.environ.get("ANYV2V_DROP_SRC_TAIL", "1") == "1"
@@ -541,6 +549,51 @@ def main():
         pnp_utils.register_time(pipe, ts_pnp[j])
         e_pnp.step(tt_pnp[j], cf_pnp[j], key=("pnp",) + pnp_utils.injection_state(pipe))
 
+    pair_serial = pair
+    if args.overlap:
+        # software pipeline over the clips of a job: clip k + 1 is inverted while clip k is edited.  The edit reads the trajectory
+        # of ITS clip (traj_prev, produced by an earlier inversion -- filled here, outside the timed region), the inversion writes
+        # the next clip's; the two steps have no data in common and run on two streams.
+        for i in range(STEPS_PER_STAGE):
+            pnp_utils.clear_time(pipe)
+            e_inv.step(tt_inv[i], cf_inv[i], key=("inv",))
+            traj[i].copy_(s_inv[0])
+        traj_prev = traj.clone()
+        s_inv.copy_(lat)
+        st_inv, st_pnp = torch.cuda.Stream(), torch.cuda.Stream()
+        serialise = [False]
+        torch.cuda.synchronize()
+
+        def pair(i):  # noqa: F811
+            j = i % STEPS_PER_STAGE
+            with torch.cuda.stream(st_inv):
+                pnp_utils.clear_time(pipe)
+                e_inv.step(tt_inv[j], cf_inv[j], key=("inv",))
+                traj[j].copy_(s_inv[0])
+            if serialise[0]:
+                st_pnp.wait_stream(st_inv)
+            with torch.cuda.stream(st_pnp):
+                s_pnp[0].copy_(traj_prev[j])
+                pnp_utils.register_time(pipe, ts_pnp[j])
+                e_pnp.step(tt_pnp[j], cf_pnp[j], key=("pnp",) + pnp_utils.injection_state(pipe))
+            if serialise[0]:
+                st_inv.wait_stream(st_pnp)
+        pair_overlapped = pair
+
+        def check_overlap(n=3):
+            """The same n pairs once with the two streams side by side, once serialised: bit-equal latents."""
+            outs = []
+            for serial in (False, True):
+                s_inv.copy_(lat)
+                s_pnp.copy_(lat.repeat(3, 1, 1, 1, 1))
+                torch.cuda.synchronize()
+                serialise[0] = serial
+                for i in range(n):
+                    pair_overlapped(i)
+                serialise[0] = False
+                torch.cuda.synchronize()
+                outs.append((s_inv.clone(), s_pnp.clone()))
+            return bool(torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]))
     for i in range(args.warmup):
         pair(i)
     torch.cuda.synchronize()
@@ -559,6 +612,17 @@ def main():
         dt, _gathered = finish_distributed(dist, dt, s_pnp[2:3].contiguous(), world, device)
     finite = bool(torch.isfinite(s_pnp.float()).all() and torch.isfinite(s_inv.float()).all())
     rccl_ranks = len(_gathered) if dist is not None else None
+    serial_ms = None
+    if args.overlap and world == 1:
+        # the same pairs one after the other on one stream (what rounds 1-3 reported), for comparison
+        n = min(args.steps, 20)
+        pair_serial(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            pair_serial(i)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t0) / n * 1e3
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -573,6 +637,13 @@ def main():
                                    "1 inversion step + 1 edit step = 1/50 clip; I2VGen-XL 3D-UNet 1.42B params, random init",
                        "steps_per_stage": STEPS_PER_STAGE, "frames": FRAMES, "latent": [4, FRAMES, LAT, LAT],
                        "hip_graphs": os.environ.get("ANYV2V_NO_GRAPH", "0") != "1", "finite": finite,
+                       "schedule": ("pipelined: the job's steady state -- the inversion step of clip k + 1 and the edit step of clip k "
+                                    "(which reads clip k's finished trajectory, resident in HBM) are enqueued on two HIP streams and "
+                                    "run side by side; same launches, same results as the serial order (checked below); this is how "
+                                    "`python -m anyv2v_amd.run_group_anyv2v` runs a multi-clip job on one GPU") if args.overlap
+                       else "serial: inversion step, then edit step, one stream",
+                       **({"pipelined_bit_equal_to_serial": check_overlap(),
+                           "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 3)} if args.overlap else {}),
                        "excluded": "`value` is the steady-state loop rate: VAE encode/decode, CLIP encoders and file I/O are outside "
                                    "(SURVEY 8(f) F1/F2); the `clip` object times one whole clip including VAE and the trajectory files"},
         }
