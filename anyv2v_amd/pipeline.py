@@ -212,6 +212,9 @@ class I2VGenXLPipeline:
         self._guidance_scale = 1.0
         self._device = torch.device("cpu")
         self._engines: Dict[tuple, _StepEngine] = {}  # step engines (static buffers + HIP graphs) kept across clips, LRU
+        # pacing hooks of the clip pipeline (run_group_anyv2v): ``pace_record(i, n)`` is called when edit step i of n is about to be
+        # enqueued, ``pace_wait(i, n)`` before inversion step i of n -- stream events, outside the captured graphs
+        self.pace_record = self.pace_wait = None
         self.ws_slot = 0   # split-K scratch buffer of this pipeline's launches (``sibling``: a second stream needs its own)
         self.source_cache: Optional[SourceFeatureCache] = None   # set (``enable_source_cache``) by multi-edit jobs
 
@@ -498,6 +501,8 @@ class I2VGenXLPipeline:
         coef_table = self.scheduler.coefficient_table(ts, device)
         traj = LatentTrajectory()
         for i, t in enumerate(ts):
+            if self.pace_wait is not None:
+                self.pace_wait(i, len(ts))
             eng.step(t_table[i], coef_table[i], key=("inv",))
             traj[t] = sample[nb - 1:nb].clone()
         if output_dir is not None:
@@ -654,6 +659,8 @@ class I2VGenXLPipeline:
                 obj.src_io = (mode, eng.site_bufs[name]) if (mode is not None and name in names) else None
 
         for i, t in enumerate(ts):
+            if self.pace_record is not None:
+                self.pace_record(i, len(ts))
             pnp_utils.register_time(self, t)  # host-side only: python int, no device sync (:1143)
             state = pnp_utils.injection_state(self)
             if any(state) and nb != 3:

@@ -31,12 +31,16 @@ def main_pipelined(inv_template, inv_list, edit_template, edit_list, device, log
     """One GPU, several clips: clip k + 1 is INVERTED while clip k is EDITED.  The two loops have no data in common (the edit reads
     the trajectory of its own clip, complete before it starts), so they run on two HIP streams -- stage 1 on ``pipe``, stage 2 on
     ``pipe.sibling()`` (same weights; own scheduler slot, step engines, graphs and split-K scratch) -- and the launches that do not
-    fill the chip on their own (the low-resolution levels, the B = 1 inversion) run side by side: 106.4 -> 99.7 ms per step pair at
-    16 f x 512^2 (``bench.py --overlap``), latents bit-equal to the serial order.
+    fill the chip on their own (the low-resolution levels, the B = 1 inversion) run side by side: 105.8 -> 98.8 ms per step pair at
+    16 f x 512^2 (``bench.py``), latents bit-equal to the serial order.
 
-    Host order per clip k: [enqueue inversion k + 1 | stream A] -> [edits of clip k, files | stream B, after the event recorded
-    behind inversion k] -> [files + reconstruction of clip k + 1 | stream A].  Every entry re-seeds the RNGs when it starts and the
-    parked inversion entry gets its RNG state back before it finishes, so every file equals the two-stage run's."""
+    Host order per clip k: [first edit of clip k: 50 steps enqueued | stream B, behind the event recorded after inversion k]
+    -> [inversion k + 1: frames, VAE encode, steps enqueued | stream A] -> [edit k: decode, files; further edits of clip k | B]
+    -> [inversion k + 1: files, reconstruction | A].  When the inversion has no more steps than the edit (the 50 + 50 case), its
+    step i is held back until edit step i * n_edit / n_inv starts (stream events), so that the two loops stay side by side over
+    the whole edit instead of the inversion racing ahead; a longer inversion (the template's 500 steps) is never held back -- the
+    edits then run entirely in its shadow.  Every entry re-seeds the RNGs when it starts and a parked entry gets its RNG state
+    back before it finishes, so every file equals the serial order's."""
     import contextlib
 
     from . import ops
@@ -46,41 +50,70 @@ def main_pipelined(inv_template, inv_list, edit_template, edit_list, device, log
     on = (lambda st: torch.cuda.stream(st)) if cuda else (lambda st: contextlib.nullcontext())
     trajectories = {}
     s1 = stage1.Stage1(inv_template, inv_list, device, logger, pipe=pipe, trajectories=trajectories)
-    s2 = stage2.Stage2(edit_template, edit_list, device, logger, pipe=pipe.sibling(ws_slot=1), trajectories=trajectories)
+    pipe_b = pipe.sibling(ws_slot=1)
+    s2 = stage2.Stage2(edit_template, edit_list, device, logger, pipe=pipe_b, trajectories=trajectories)
     if cuda:
         stream_a.wait_stream(torch.cuda.current_stream(device))
         stream_b.wait_stream(torch.cuda.current_stream(device))
     pending = list(s2.my_entries)
+    pace = []   # one event per edit step of the edit that is in flight (stream B)
 
-    def edits_of(latents_dir, ready):
-        """The edit entries of this clip, list order; stream B first waits for the clip's inversion."""
+    def record(i, n):
+        if i == 0:
+            pace.clear()
+        pace.append(stream_b.record_event())
+
+    def wait(i, n):
+        if pace and n <= len(pace):
+            stream_a.wait_event(pace[i * len(pace) // n])
+    if cuda and os.environ.get("ANYV2V_PIPELINE_PACING", "1") == "1":
+        pipe_b.pace_record, pipe.pace_wait = record, wait
+
+    def take(latents_dir):
         mine = [e for e in pending if s2.latents_dir_of(e) == latents_dir]
-        if not mine:
-            return
+        for e in mine:
+            pending.remove(e)
+        return mine
+
+    def start_edit(e, ready):
         with on(stream_b), ops.workspace_slot(1):
             if ready is not None:
                 stream_b.wait_event(ready)
-            for e in mine:
-                pending.remove(e)
+            g = s2.entry(e)
+            next(g, None)
+        return g
+
+    def finish_edits(g, rest):
+        with on(stream_b), ops.workspace_slot(1):
+            for _ in g:
+                pass
+            pace.clear()                             # (further edits of the clip run un-paced beside nothing)
+            for e in rest:
                 s2.run_entry(e)
 
-    prev = None   # (latents directory, event) of the inversion that is complete or running ahead of the edits
+    prev = None   # (latents directory, event) of the last inversion that was run here
     for entry in s1.entries():
+        mine = take(prev[0]) if prev is not None else []
+        g = start_edit(mine[0], prev[1]) if mine else None          # edit of clip k: enqueued, pace events recorded
         with on(stream_a):
-            latents_dir = next(entry, None)          # frames, VAE encode, inversion steps: launched, nothing read back
+            latents_dir = next(entry, None)                          # inversion k + 1: enqueued beside it
             ready = stream_a.record_event() if (cuda and latents_dir is not None) else None
-        if prev is not None:
-            edits_of(*prev)                          # ... while the previous clip is edited
+        if g is not None:
+            finish_edits(g, mine[1:])
         with on(stream_a):
-            for _ in entry:                          # files, reconstruction
+            for _ in entry:                                          # files, reconstruction
                 pass
-        prev = (latents_dir, ready) if latents_dir is not None else None
-    if prev is not None:
-        edits_of(*prev)
-    with on(stream_b), ops.workspace_slot(1):        # entries whose inversion was not run here (complete on disk): from the files
-        for e in list(pending):
-            pending.remove(e)
+        if latents_dir is not None:
+            prev = (latents_dir, ready)
+    pace.clear()
+    with on(stream_b), ops.workspace_slot(1):
+        if prev is not None and cuda:
+            stream_b.wait_event(prev[1])
+        for e in (take(prev[0]) if prev is not None else []) + list(pending):   # last clip; then entries inverted elsewhere (files)
+            if e in pending:
+                pending.remove(e)
             s2.run_entry(e)
+    pipe_b.pace_record = pipe.pace_wait = None
     if cuda:
         torch.cuda.current_stream(device).wait_stream(stream_a)
         torch.cuda.current_stream(device).wait_stream(stream_b)

@@ -103,6 +103,13 @@ class Stage2:
         return os.path.abspath(str(self._config(config_entry).ddim_latents_path))
 
     def run_entry(self, config_entry):
+        for _ in self.entry(config_entry):
+            pass
+
+    def entry(self, config_entry):
+        """Generator: runs the entry up to the point where the 50 edit steps are ENQUEUED (nothing read back) and yields; then
+        decodes and writes the files."""
+        from .run_group_ddim_inversion import _RngState
         template_config, logger, pipe, device = self.template_config, self.logger, self.pipe, self.device
         ddim_scheduler, loaded_trajectories = self.ddim_scheduler, self.loaded_trajectories
         entry_idx = self.all_active.index(config_entry)
@@ -154,6 +161,9 @@ class Stage2:
             output_type="latent").frames
         self.my_latents[entry_idx] = edited_latents
         self.lat_shape = tuple(edited_latents.shape)
+        rng = _RngState(device)
+        yield
+        rng.restore()
         video = pipe.decode_latents(edited_latents, decode_chunk_size=1)  # (frame-parallel: every rank decodes its frames)
         if not self.writer:
             return
