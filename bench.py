@@ -564,20 +564,27 @@ def main():
         serialise = [False]
         torch.cuda.synchronize()
 
+        pacing = os.environ.get("ANYV2V_PIPELINE_PACING", "1") == "1"
+
         def pair(i):  # noqa: F811
             j = i % STEPS_PER_STAGE
-            with torch.cuda.stream(st_inv):
-                pnp_utils.clear_time(pipe)
-                e_inv.step(tt_inv[j], cf_inv[j], key=("inv",))
-                traj[j].copy_(s_inv[0])
-            if serialise[0]:
-                st_pnp.wait_stream(st_inv)
+            # the edit step is enqueued first and paces the inversion step (run_group_anyv2v.main_pipelined): inversion step j does not
+            # start before edit step j does, so the cheaper loop cannot race ahead and leave the edit alone on the chip
             with torch.cuda.stream(st_pnp):
+                if serialise[0]:
+                    st_pnp.wait_stream(st_inv)
+                started = st_pnp.record_event() if pacing else None
                 s_pnp[0].copy_(traj_prev[j])
                 pnp_utils.register_time(pipe, ts_pnp[j])
                 e_pnp.step(tt_pnp[j], cf_pnp[j], key=("pnp",) + pnp_utils.injection_state(pipe))
-            if serialise[0]:
-                st_inv.wait_stream(st_pnp)
+            with torch.cuda.stream(st_inv):
+                if serialise[0]:
+                    st_inv.wait_stream(st_pnp)
+                elif started is not None:
+                    st_inv.wait_event(started)
+                pnp_utils.clear_time(pipe)
+                e_inv.step(tt_inv[j], cf_inv[j], key=("inv",))
+                traj[j].copy_(s_inv[0])
         pair_overlapped = pair
 
         def check_overlap(n=3):
