@@ -129,6 +129,41 @@ def run_unet_cases(unet, pnp_module, call):
     return out
 
 
+# ------------------------------------------------------------------------------------------------- the released width (consisti2v_unet_full.pt)
+# 1250 M parameters (anyv2v_amd.consisti2v_pipeline.CONSISTI2V_UNET_CONFIG), [source, negative, editing] x 15 + 1 frames x 32 x 32
+# latent pixels (configs/pipeline_256): spatial head_dim 64 with Sk = 2 HW, temporal head_dim 40 / 80 / 160 with 16 + 8 keys.
+FULL_H = FULL_W = 32
+
+
+def unet_full_cfg():
+    from anyv2v_amd.consisti2v_pipeline import CONSISTI2V_UNET_CONFIG
+    return dict(CONSISTI2V_UNET_CONFIG)
+
+
+def unet_full_inputs(seed=INPUT_SEED):
+    cfg = unet_full_cfg()
+    g = torch.Generator().manual_seed(seed + 177)
+    r = lambda *s: torch.randn(*s, generator=g).half().float()
+    sample = r(B, 4, cfg["n_frames"] - 1, FULL_H, FULL_W)
+    first = r(1, 4, 1, FULL_H, FULL_W).repeat(B, 1, 1, 1, 1)
+    ehs = r(B, 77, cfg["cross_attention_dim"])
+    return sample, first, ehs
+
+
+def run_unet_full_cases(unet, pnp_module, call):
+    """Un-hooked and with all three hook families on (t = 981), frame stride 3."""
+    sample, first, ehs = unet_full_inputs()
+    out = {"full_nohook": call(unet, sample, 981, ehs, first, UNET_STRIDE)}
+    model = types.SimpleNamespace(unet=unet)
+    conv_s, spa_s, tmp_s = schedules()
+    pnp_module.register_conv_injection(model, conv_s)
+    pnp_module.register_spatial_attention_pnp(model, spa_s)
+    pnp_module.register_temp_attention_pnp(model, tmp_s)
+    pnp_module.register_time(model, 981)
+    out["full_hook_t981"] = call(unet, sample, 981, ehs, first, UNET_STRIDE)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- the pipeline job (consisti2v_pipeline.pt)
 # one synthetic clip through both stages as the reference's runners drive them (run_ddim_inversion.py / run_pnp_edit.py) at toy size
 PIPE_JOB = dict(frames=UNET_CFG["n_frames"], height=64, width=128, seed=99, n_inv_steps=8, n_steps=4, t_idx=1, ratios=(0.5, 0.5, 0.75),

@@ -234,6 +234,31 @@ def gen_consisti2v_unet():
     torch.save(fx, os.path.join(HERE, "consisti2v_unet.pt"))
 
 
+def gen_consisti2v_unet_full():
+    """``consisti2v_unet_full.pt`` (``--consisti2v-unet-full``): the reference's own ``VideoLDMUNet3DConditionModel`` at the released
+    model's width (1250 M parameters, fp32 on the CPU: a few minutes), un-hooked and with the reference's three hook families on."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import consisti2v_spec as spec
+    unet_mod, ublocks, pnp = ref_stubs.load_reference_consisti2v_unet()
+    t0 = time.time()
+    unet = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.unet_full_cfg())).eval()
+    print(f"reference UNet built: {sum(p.numel() for p in unet.parameters()) / 1e6:.1f} M parameters, {time.time() - t0:.0f} s")
+
+    def call(u, sample, t, ehs, first, stride):
+        t1 = time.time()
+        with torch.no_grad():
+            y = u(sample, t, encoder_hidden_states=ehs, first_frame_latents=first, frame_stride=stride).sample.clone()
+        print(f"  forward {time.time() - t1:.0f} s, |y| max {float(y.abs().max()):.3f}")
+        return y
+    out = spec.run_unet_full_cases(unet, pnp, call)
+    a, h = out["full_nohook"], out["full_hook_t981"]
+    print(f"hooked vs un-hooked, branches 1-2: {float((h[1:] - a[1:]).abs().max() / a.abs().max()):.3f}; source branch equal {bool(torch.equal(h[:1], a[:1]))}")
+    fx = {"spec": dict(cfg=spec.unet_full_cfg(), H=spec.FULL_H, W=spec.FULL_W, weight_seed=spec.WEIGHT_SEED, input_seed=spec.INPUT_SEED),
+          "full_nohook": a.half(), "full_hook_t981": h.half()}
+    torch.save(fx, os.path.join(HERE, "consisti2v_unet_full.pt"))
+
+
 def gen_consisti2v_pipeline():
     """``consisti2v_pipeline.pt`` (``--consisti2v-pipeline``): the reference's own ``ConditionalVideoEditingPipeline`` class
     (``oracle.ref_consisti2v_pipeline``: verbatim pipeline file around the reference's UNet, hooks, inverse scheduler and
@@ -299,6 +324,9 @@ if __name__ == "__main__":
         gen_consisti2v()
     if "--consisti2v-unet" in sys.argv:
         gen_consisti2v_unet()
+        sys.exit(0)
+    if "--consisti2v-unet-full" in sys.argv:
+        gen_consisti2v_unet_full()
         sys.exit(0)
     if "--consisti2v-pipeline" in sys.argv:
         gen_consisti2v_pipeline()

@@ -299,3 +299,19 @@ def test_consisti2v_cli_runners_on_gpu(tmp_path):
     a = check_consisti2v_cli_outputs(base)
     run_consisti2v_cli_stages(base, "cuda:0")
     assert (a == check_consisti2v_cli_outputs(base)).all()
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available() or os.environ.get("ANYV2V_LONG_TESTS", "0") != "1",
+                    reason="needs /root/reference; ~2 minutes of fp32 CPU work at 1250 M parameters (ANYV2V_LONG_TESTS=1)")
+def test_full_width_unet_fixture_is_what_the_reference_code_produces():
+    warnings.filterwarnings("ignore")
+    unet_mod, ublocks, pnp = ref_stubs.load_reference_consisti2v_unet()
+    ref = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.unet_full_cfg())).eval()
+
+    def call(u, sample, t, ehs, first, stride):
+        with torch.no_grad():
+            return u(sample, t, encoder_hidden_states=ehs, first_frame_latents=first, frame_stride=stride).sample
+    out = spec.run_unet_full_cases(ref, pnp, call)
+    fx = torch.load(os.path.join(HERE, "golden", "consisti2v_unet_full.pt"))
+    for k in ("full_nohook", "full_hook_t981"):
+        assert float((out[k] - fx[k].float()).abs().max()) <= 2e-3 * float(fx[k].float().abs().max()), k

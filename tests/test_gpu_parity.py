@@ -235,6 +235,14 @@ def test_consisti2v_whole_unet_vs_the_references_own_unet_and_hooks():
     _assert_all(gc.check_consisti2v_unet())
 
 
+def test_consisti2v_unet_at_the_released_width_vs_the_references_own_unet():
+    """The 1250 M-parameter configuration at 16 f x 256^2 against a fixture of the reference's own class (fp32, CPU)."""
+    res = gc.check_consisti2v_unet_full()
+    for r in res:
+        print(f"{'ok  ' if r['ok'] else 'FAIL'} {r['name']}: {r['err']:.3e} (tol {r['tol']:.2e})")
+    _assert_all(res)
+
+
 def test_consisti2v_pipeline_vs_the_references_own_pipeline_class():
     """ConsistI2V end to end, pipeline level: inversion, reconstruction and PnP edit on the kernels vs the reference's own
     ``ConditionalVideoEditingPipeline`` (fixture)."""
