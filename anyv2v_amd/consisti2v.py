@@ -673,6 +673,7 @@ class VideoLDMUNet3DConditionModel(nn.Module):
         self.conv_in.pack()
         self.conv_out.pack()
         self._packed = True
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1   # captured graphs point at the packed tensors of one generation
 
     def load_state_dict(self, sd, strict=True, **kw):
         out = super().load_state_dict(sd, strict=strict, **kw)
@@ -691,6 +692,7 @@ class VideoLDMUNet3DConditionModel(nn.Module):
         B, C, F, H, W = sample.shape
         ctx = _Ctx(B, F, H, W, dev, self.groups)
         c0 = cfgd.block_out_channels[0]
+        # (device tensors pass through untouched: a captured step keeps the timestep in a static buffer)
         t = torch.as_tensor(timestep, device=dev).reshape(-1).float().expand(B).contiguous()
         emb = self.time_embedding.run(ops.timestep_embedding(t, c0))
         if self.use_frame_stride_condition:
@@ -747,6 +749,16 @@ def register_time(model, t):
         for block in blocks:
             setattr(model.unet.up_blocks[res].attentions[block].transformer_blocks[0].attn1.processor, "t", t)
             setattr(model.unet.up_blocks[res].tempo_attns[block].transformer_blocks[0].attn1.processor, "t", t)
+
+
+def injection_state(model):
+    """(conv, spatial, temporal) injection on / off at the registered timestep: which launches a forward issues -- the key of a
+    captured graph."""
+    r = model.unet.up_blocks[1].resnets[1]
+    a = model.unet.up_blocks[2].attentions[0].transformer_blocks[0].attn1.processor
+    m = model.unet.up_blocks[2].tempo_attns[0].transformer_blocks[0].attn1.processor
+    return (pnp_on(r.t, r.injection_schedule), pnp_on(a.t, getattr(a, "injection_schedule", None)),
+            pnp_on(m.t, getattr(m, "injection_schedule", None)))
 
 
 def clear_time(model):

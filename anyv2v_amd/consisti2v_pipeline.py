@@ -87,6 +87,41 @@ def frame_to_pixels(img: Image.Image, height: int, width: int, crop: bool) -> to
     return ((x - 0.5) / 0.5)[None]
 
 
+class _StepGraphs:
+    """Static inputs of the UNet forward of one loop geometry + one captured HIP graph per injection state."""
+
+    def __init__(self, unet, nb, latents, ehs, frame_stride):
+        dev = latents.device
+        self.unet = unet
+        # OFF by default: measured at the released width (tools/consisti2v_bench.py, 10 steps, graphs kept across calls) replaying the
+        # ~1400-node graph is no faster than the eager launches at 16 f x 256^2 (15.7 / 30.5 ms per inversion / PnP step against
+        # 16.0 / 25.9) and slower at 512^2 (44.7 / 81.0 against 34.6 / 82.0) -- the forward of this family is many 5-20 us launches
+        # and the per-node cost of a replay is of that order.  ANYV2V_CONSISTI2V_GRAPHS=1 switches it on.
+        self.use_graphs = dev.type == "cuda" and os.environ.get("ANYV2V_CONSISTI2V_GRAPHS", "0") == "1"
+        self.x = torch.empty((nb,) + tuple(latents.shape[1:]), dtype=torch.float16, device=dev)
+        self.ehs = torch.empty((nb,) + tuple(ehs.shape[1:]), dtype=torch.float16, device=dev)
+        self.ff = torch.empty((nb, latents.shape[1], 1) + tuple(latents.shape[3:]), dtype=torch.float16, device=dev)
+        self.t_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.fs = None if frame_stride is None else torch.full((1,), float(frame_stride), dtype=torch.float32, device=dev)
+        self.graphs, self.outs = {}, {}
+
+    def _forward(self):
+        return self.unet(self.x, self.t_buf, encoder_hidden_states=self.ehs, first_frame_latents=self.ff, frame_stride=self.fs).sample.contiguous()
+
+    def run(self, key):
+        if not self.use_graphs:
+            return self._forward()
+        if key not in self.graphs:
+            self._forward()                               # warm-up outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.outs[key] = self._forward()
+            self.graphs[key] = g
+        self.graphs[key].replay()
+        return self.outs[key]
+
+
 # ------------------------------------------------------------------------------------------------- the pipeline
 class ConditionalVideoEditingPipeline:
     def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet: Optional[c2.VideoLDMUNet3DConditionModel] = None, scheduler=None):
@@ -94,6 +129,7 @@ class ConditionalVideoEditingPipeline:
         self.vae_scale_factor = 8
         self._device = torch.device("cpu")
         self.freq_filter = None
+        self._engines = {}
 
     # ------------------------------------------------------------------ construction / plumbing
     @classmethod
@@ -271,25 +307,44 @@ class ConditionalVideoEditingPipeline:
 
     def _denoise(self, latents, ff_input, text_embeddings, timesteps, frame_stride, branches, g_img, g_txt, source=None, on_step=None):
         """``latents`` [1, C, F - 1, h, w]; ``ff_input`` [nb, C, 1, h, w]; ``branches`` = (b_unc, b_img, b_txt) of the guided rows;
-        ``source(t)`` -> the source branch's latents at t (PnP: row 0 of the batch)."""
-        n_guided = ff_input.shape[0] - (1 if source is not None else 0)
+        ``source(t)`` -> the source branch's latents at t (PnP: row 0 of the batch).
+
+        One step = the UNet forward over all rows (static input buffers, ``_StepGraphs``) + one guided-step kernel.  The forward can
+        be replayed as a HIP graph per injection state (ANYV2V_CONSISTI2V_GRAPHS=1); measured, that does not pay for this family."""
+        nb = ff_input.shape[0]
+        n_guided = nb - (1 if source is not None else 0)
         latents = latents.to(torch.float16).contiguous()
-        ehs = text_embeddings.contiguous()
-        ff = ff_input.to(torch.float16).contiguous()
         pred = self.scheduler.prediction
+        eng = self._step_graphs(nb, latents, text_embeddings, frame_stride)
+        eng.ehs.copy_(text_embeddings)
+        eng.ff.copy_(ff_input)
         for t in timesteps:
             t = int(t)
-            rows = [latents] * n_guided
             if source is not None:
-                rows = [source(t)] + rows
+                eng.x[0].copy_(source(t)[0], non_blocking=True)
                 c2.register_time(self, t)
-            x = self.scheduler.scale_model_input(torch.cat(rows) if len(rows) > 1 else latents, t)
-            e = self.unet(x, t, encoder_hidden_states=ehs, first_frame_latents=ff, frame_stride=frame_stride).sample.contiguous()
+            for b in range(nb - n_guided, nb):
+                eng.x[b].copy_(latents[0])
+            eng.t_buf.fill_(float(t))
+            e = eng.run(c2.injection_state(self) if source is not None else None)
             latents = ops.guided_step(e, latents, self.scheduler.coefficients(t), b_unc=branches[0], b_img=branches[1], b_txt=branches[2],
                                       g_img=g_img, g_txt=g_txt, prediction=pred)
             if on_step is not None:
                 on_step(t, latents)
         return latents
+
+    def _step_graphs(self, nb, latents, ehs, frame_stride):
+        if not self.unet._packed:
+            self.unet.pack()
+        key = (nb, tuple(latents.shape[1:]), tuple(ehs.shape[1:]), None if frame_stride is None else float(frame_stride), str(latents.device),
+               id(self.unet), self.unet._pack_gen)
+        eng = self._engines.pop(key, None)
+        if eng is None:
+            eng = _StepGraphs(self.unet, nb, latents, ehs, frame_stride)
+        self._engines[key] = eng       # most recently used last
+        while len(self._engines) > 3:  # (inversion / reconstruction, CFG sampling, PnP edit: every engine pins a graph pool)
+            self._engines.pop(next(iter(self._engines)))
+        return eng
 
     @staticmethod
     def _branches(mode, offset=0):

@@ -52,9 +52,9 @@ def main():
                                                   frame_stride=3, latents=traj[T].clone(), ddim_init_latents_t_idx=0,
                                                   ddim_inv_latents_path=traj, ddim_inv_prompt="", ddim_inv_1st_frame_path=frames[0],
                                                   output_type="latent").videos)
-    print(json.dumps(dict(what="ConsistI2V full width, eager", size=size, frames=16, steps=n, unet_params_M=round(n_params / 1e6, 1),
+    print(json.dumps(dict(what="ConsistI2V full width", size=size, frames=16, steps=n, unet_params_M=round(n_params / 1e6, 1),
                           inversion_ms_per_step=round(1e3 * t_inv / n, 2), pnp_edit_ms_per_step=round(1e3 * t_ed / n, 2),
-                          finite=bool(torch.isfinite(ed.float()).all()), edit_absmax=float(ed.float().abs().max()))))
+                          hip_graphs=os.environ.get("ANYV2V_CONSISTI2V_GRAPHS", "0") == "1", finite=bool(torch.isfinite(ed.float()).all()), edit_absmax=float(ed.float().abs().max()))))
 
 
 if __name__ == "__main__":
