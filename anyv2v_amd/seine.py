@@ -21,6 +21,7 @@ The reference installs its hooks by replacing ``module.forward`` and setting ``t
 (not on processors); the native modules read the same two attributes."""
 from __future__ import annotations
 
+import types
 from typing import List
 
 import torch
@@ -28,7 +29,7 @@ from torch import nn
 
 from . import ops
 from .consisti2v import ROTARY_THETA, _Ctx, _RotaryFreqs, _sched
-from .unet import Conv2d, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, Upsample2D, pnp_on
+from .unet import Conv2d, Downsample2D, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU, Upsample2D, pnp_on
 
 
 class CrossAttention(nn.Module):
@@ -187,7 +188,32 @@ class Transformer3DModel(nn.Module):
         return ops.gemm(h, self.proj_out.weight.reshape(self.proj_out.weight.shape[0], -1), bias=self.proj_out.bias, residual=x)
 
 
-class CrossAttnUpBlock3D(nn.Module):
+def _res3d(cin, cout, temb_channels, groups, eps):
+    r = ResnetBlock2D(cin, cout, temb_channels, groups, eps)
+    r.norm_over_frames = True     # ResnetBlock3D: GroupNorm statistics over all frames of a batch element
+    return r
+
+
+class _SeineBlock(nn.Module):
+    """Packing (one GEMM for the time-embedding projections of the block's ResNets) shared by the block types below."""
+
+    def pack(self):
+        for m in self.modules():
+            if m is not self and hasattr(m, "pack"):
+                m.pack()
+        col = 0
+        for r in self.resnets:
+            r._temb_col = col
+            col += r.out_channels
+        self._w_temb = torch.cat([r.time_emb_proj.weight.data for r in self.resnets], 0).contiguous()
+        self._b_temb = torch.cat([r.time_emb_proj.bias.data for r in self.resnets], 0).contiguous()
+        self._packed = True
+
+    def enter(self, ctx):
+        ctx.temb_all = ops.gemm(ops.silu(ctx.emb), self._w_temb, bias=self._b_temb)
+
+
+class CrossAttnUpBlock3D(_SeineBlock):
     """``seine/models/unet_blocks.py:444-575``; constructor argument names are the reference's."""
 
     def __init__(self, in_channels, out_channels, prev_output_channel, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
@@ -211,18 +237,6 @@ class CrossAttnUpBlock3D(nn.Module):
         self._packed = False
         self._w_temb = self._b_temb = None
 
-    def pack(self):
-        for m in self.modules():
-            if m is not self and hasattr(m, "pack"):
-                m.pack()
-        col = 0
-        for r in self.resnets:
-            r._temb_col = col
-            col += r.out_channels
-        self._w_temb = torch.cat([r.time_emb_proj.weight.data for r in self.resnets], 0).contiguous()
-        self._b_temb = torch.cat([r.time_emb_proj.bias.data for r in self.resnets], 0).contiguous()
-        self._packed = True
-
     def load_state_dict(self, sd, strict=True, **kw):
         out = super().load_state_dict(sd, strict=strict, **kw)
         self._packed = False
@@ -234,6 +248,7 @@ class CrossAttnUpBlock3D(nn.Module):
             x = attn.run(ctx, x)
         if self.upsamplers is not None:
             x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
+            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
         return x
 
     def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, **unused):
@@ -255,6 +270,236 @@ class CrossAttnUpBlock3D(nn.Module):
         y = self.run(ctx, tok(hidden_states), [tok(s) for s in res_hidden_states_tuple])
         Ho, Wo = (2 * H, 2 * W) if self.upsamplers is not None else (H, W)
         return y.view(B, F, Ho, Wo, -1).permute(0, 4, 1, 2, 3)
+
+
+# ------------------------------------------------------------------------------------------------- the other blocks, the UNet
+def _seine_opts(use_first_frame, use_relative_position):
+    if use_first_frame or use_relative_position:
+        raise NotImplementedError("use_first_frame / use_relative_position are off in the released SEINE model")
+
+
+class CrossAttnDownBlock3D(_SeineBlock):
+    """``seine/models/unet_blocks.py:235-362``: per layer ResnetBlock3D -> Transformer3DModel; stride-2 ``Downsample3D`` behind."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32, attn_num_head_channels=1,
+                 cross_attention_dim=1280, add_downsample=True, use_linear_projection=False, use_first_frame=False,
+                 use_relative_position=False, **unused):
+        super().__init__()
+        _seine_opts(use_first_frame, use_relative_position)
+        self.has_cross_attention = True
+        self.resnets = nn.ModuleList([_res3d(in_channels if i == 0 else out_channels, out_channels, temb_channels, resnet_groups, resnet_eps)
+                                      for i in range(num_layers)])
+        self.attentions = nn.ModuleList([Transformer3DModel(attn_num_head_channels, out_channels // attn_num_head_channels, out_channels,
+                                                            cross_attention_dim, resnet_groups, use_linear_projection)
+                                         for _ in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def run(self, ctx, x):
+        outs = []
+        for resnet, attn in zip(self.resnets, self.attentions):
+            x = attn.run(ctx, resnet.run(ctx, x, None, ctx.H, ctx.W))
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
+            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            outs.append(x)
+        return x, outs
+
+
+class DownBlock3D(_SeineBlock):
+    """``seine/models/unet_blocks.py:365-441``."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32, add_downsample=True, **unused):
+        super().__init__()
+        self.has_cross_attention = False
+        self.resnets = nn.ModuleList([_res3d(in_channels if i == 0 else out_channels, out_channels, temb_channels, resnet_groups, resnet_eps)
+                                      for i in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def run(self, ctx, x):
+        outs = []
+        for resnet in self.resnets:
+            x = resnet.run(ctx, x, None, ctx.H, ctx.W)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
+            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            outs.append(x)
+        return x, outs
+
+
+class UNetMidBlock3DCrossAttn(_SeineBlock):
+    """``seine/models/unet_blocks.py:145-232``: resnet, then (transformer, resnet) per layer."""
+
+    def __init__(self, in_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32, attn_num_head_channels=1,
+                 cross_attention_dim=1280, use_linear_projection=False, use_first_frame=False, use_relative_position=False, **unused):
+        super().__init__()
+        _seine_opts(use_first_frame, use_relative_position)
+        self.has_cross_attention = True
+        self.resnets = nn.ModuleList([_res3d(in_channels, in_channels, temb_channels, resnet_groups, resnet_eps) for _ in range(num_layers + 1)])
+        self.attentions = nn.ModuleList([Transformer3DModel(attn_num_head_channels, in_channels // attn_num_head_channels, in_channels,
+                                                            cross_attention_dim, resnet_groups, use_linear_projection)
+                                         for _ in range(num_layers)])
+
+    def run(self, ctx, x):
+        x = self.resnets[0].run(ctx, x, None, ctx.H, ctx.W)
+        for attn, resnet in zip(self.attentions, self.resnets[1:]):
+            x = resnet.run(ctx, attn.run(ctx, x), None, ctx.H, ctx.W)
+        return x
+
+
+class UpBlock3D(_SeineBlock):
+    """``seine/models/unet_blocks.py:577-648``."""
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
+                 add_upsample=True, **unused):
+        super().__init__()
+        self.has_cross_attention = False
+        self.resnets = nn.ModuleList()
+        for i in range(num_layers):
+            skip = in_channels if i == num_layers - 1 else out_channels
+            rin = prev_output_channel if i == 0 else out_channels
+            self.resnets.append(_res3d(rin + skip, out_channels, temb_channels, resnet_groups, resnet_eps))
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def run(self, ctx, x, skips: List[torch.Tensor]):
+        for resnet in self.resnets:
+            x = resnet.run(ctx, x, skips.pop(), ctx.H, ctx.W)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
+            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
+        return x
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = Linear(in_channels, time_embed_dim)
+        self.linear_2 = Linear(time_embed_dim, time_embed_dim)
+
+    def run(self, x):
+        return ops.gemm(ops.gemm(x, self.linear_1.weight, bias=self.linear_1.bias, act=ops.ACT_SILU), self.linear_2.weight,
+                        bias=self.linear_2.bias)
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class UNet3DConditionModel(nn.Module):
+    """``seine/models/unet.py:98-560`` on the HIP kernels, for the released configuration family (Stable-Diffusion-1.x layout inflated to
+    video; ``use_concat``: ``in_channels`` 9 = noisy latents | mask | masked-video latents; no class embedding, ``use_first_frame`` /
+    ``use_relative_position`` off).  Module tree and state-dict keys are the reference's (the ``ema`` state dict of ``seine.pt`` loads
+    strictly).  ``forward(sample [B, 9, F, h, w], timestep, encoder_hidden_states [B, L, D]).sample`` -> [B, 4, F, h, w]."""
+
+    def __init__(self, sample_size=None, in_channels=4, out_channels=4, flip_sin_to_cos=True, freq_shift=0,
+                 down_block_types=("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
+                 mid_block_type="UNetMidBlock3DCrossAttn",
+                 up_block_types=("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"),
+                 block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=1280,
+                 attention_head_dim=8, use_linear_projection=False, class_embed_type=None, num_class_embeds=None, use_first_frame=False,
+                 use_relative_position=False, **unused):
+        super().__init__()
+        if not flip_sin_to_cos or freq_shift != 0 or class_embed_type is not None or num_class_embeds is not None \
+                or mid_block_type != "UNetMidBlock3DCrossAttn":
+            raise NotImplementedError("native UNet3DConditionModel: flip_sin_to_cos=True, freq_shift=0, no class embedding only")
+        _seine_opts(use_first_frame, use_relative_position)
+        nb = len(block_out_channels)
+        heads = tuple(attention_head_dim) if isinstance(attention_head_dim, (list, tuple)) else (attention_head_dim,) * nb
+        boc = tuple(block_out_channels)
+        self.config = _Cfg(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels, block_out_channels=boc,
+                           cross_attention_dim=cross_attention_dim, center_input_sample=False, class_embed_type=None)
+        self.sample_size, self.groups = sample_size, norm_num_groups
+        ted = boc[0] * 4
+        self.conv_in = Conv2d(in_channels, boc[0], 3, padding=1, pad_cin_to=64)
+        self.time_embedding = _TimestepEmbedding(boc[0], ted)
+        common = dict(temb_channels=ted, resnet_eps=norm_eps, resnet_groups=norm_num_groups, cross_attention_dim=cross_attention_dim,
+                      use_linear_projection=use_linear_projection)
+        self.down_blocks = nn.ModuleList()
+        out = boc[0]
+        for i, typ in enumerate(down_block_types):
+            cin, out = out, boc[i]
+            kw = dict(in_channels=cin, out_channels=out, num_layers=layers_per_block, add_downsample=i != nb - 1, **common)
+            if typ == "CrossAttnDownBlock3D":
+                self.down_blocks.append(CrossAttnDownBlock3D(attn_num_head_channels=heads[i], **kw))
+            elif typ == "DownBlock3D":
+                self.down_blocks.append(DownBlock3D(**kw))
+            else:
+                raise NotImplementedError(typ)
+        self.mid_block = UNetMidBlock3DCrossAttn(in_channels=boc[-1], attn_num_head_channels=heads[-1], **common)
+        self.up_blocks = nn.ModuleList()
+        rboc, rheads = boc[::-1], heads[::-1]
+        out = rboc[0]
+        for i, typ in enumerate(up_block_types):
+            prev, out = out, rboc[i]
+            kw = dict(in_channels=rboc[min(i + 1, nb - 1)], out_channels=out, prev_output_channel=prev, num_layers=layers_per_block + 1,
+                      add_upsample=i != nb - 1, **common)
+            if typ == "CrossAttnUpBlock3D":
+                self.up_blocks.append(CrossAttnUpBlock3D(attn_num_head_channels=rheads[i], **kw))
+            elif typ == "UpBlock3D":
+                self.up_blocks.append(UpBlock3D(**kw))
+            else:
+                raise NotImplementedError(typ)
+        self.conv_norm_out = GroupNorm(norm_num_groups, boc[0], norm_eps)
+        self.conv_act = SiLU()
+        self.conv_out = Conv2d(boc[0], out_channels, 3, padding=1)
+        self._packed = False
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def pack(self):
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            blk.pack()
+        self.conv_in.pack()
+        self.conv_out.pack()
+        self._packed = True
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._packed = False
+        return out
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states=None, return_dict=True, **unused):
+        if not self._packed:
+            self.pack()
+        dev = sample.device
+        B, C, F, H, W = sample.shape
+        ctx = _Ctx(B, F, H, W, dev, self.groups)
+        c0 = self.config.block_out_channels[0]
+        t = torch.as_tensor(timestep, device=dev).reshape(-1).float().expand(B).contiguous()
+        ctx.emb = self.time_embedding.run(ops.timestep_embedding(t, c0))
+        ehs = encoder_hidden_states.to(torch.float16)
+        ctx.L = ehs.shape[1]
+        ctx.context = ehs.reshape(B * ctx.L, -1).contiguous()
+        xin = torch.zeros((B * F * H * W, 64), dtype=torch.float16, device=dev)
+        ops.ncfhw_to_tokens(sample.to(torch.float16).contiguous(), xin, col0=0)
+        x = self.conv_in.tokens(xin, H, W)
+        skips = [x]
+        for blk in self.down_blocks:
+            blk.enter(ctx)
+            x, outs = blk.run(ctx, x)
+            skips.extend(outs)
+        self.mid_block.enter(ctx)
+        x = self.mid_block.run(ctx, x)
+        for blk in self.up_blocks:
+            blk.enter(ctx)
+            x = blk.run(ctx, x, skips)
+        # (conv_norm_out is a plain GroupNorm on [b, c, f, h, w]: statistics over all frames of a batch element)
+        x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, F * H * W, groups=self.groups,
+                          eps=self.conv_norm_out.eps, silu=True)
+        vtok = torch.empty((x.shape[0], 8), dtype=torch.float16, device=dev)
+        self.conv_out.tokens(x, H, W, out=vtok)
+        out = ops.tokens_to_ncfhw(vtok, B, self.config.out_channels, F, H, W)
+        if not return_dict:
+            return (out,)
+        return types.SimpleNamespace(sample=out)
 
 
 # ------------------------------------------------------------------------------------------------- hook registration

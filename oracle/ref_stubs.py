@@ -387,7 +387,7 @@ def load_reference_seine_blocks():
     return res, utl
 
 
-def load_reference_seine_decoder():
+def load_reference_seine_decoder(with_unet=False):
     """Everything SEINE's hook family touches, from the reference's own files: ``CrossAttnUpBlock3D``
     (``seine/models/unet_blocks.py:444-575``: ``ResnetBlock3D`` + ``Transformer3DModel`` per layer, ``Upsample3D``), the attention
     classes of ``seine/models/attention.py`` (``CrossAttention``, ``TemporalAttention`` with ``RelativePositionBias`` and the rotary
@@ -395,7 +395,8 @@ def load_reference_seine_decoder():
     ``rotary_embedding_torch`` (not installed) is the library the reference vendors as
     ``consisti2v/consisti2v/models/rotary_embedding.py`` -- that file is imported in its place; diffusers' ``FeedForward`` is the
     oracle's (unpinned, as everywhere).  Returns (attention module, unet_blocks module, resnet module, pnp_utils module,
-    RotaryEmbedding class)."""
+    RotaryEmbedding class).  ``with_unet``: also the WHOLE ``UNet3DConditionModel`` (``seine/models/unet.py:98-560``, imported verbatim),
+    as ``unet_blocks module.unet``."""
     import importlib
     import torch
     from torch import nn
@@ -425,6 +426,39 @@ def load_reference_seine_decoder():
         att = importlib.import_module("_ref_seine_models.attention")
         res = importlib.import_module("_ref_seine_models.resnet")
         ublocks = importlib.import_module("_ref_seine_models.unet_blocks")
+        if with_unet:
+            # ``seine/models/unet.py:16-23``: the config decorator, the embedding classes (restated as for ConsistI2V) and names only
+            import inspect
+
+            class _Logger:
+                def __getattr__(self, k):
+                    return lambda *a, **kw: None
+
+            def register_to_config(init):
+                sig = inspect.signature(init)
+
+                def wrapped(self, *a, **kw):
+                    bound = sig.bind(self, *a, **kw)
+                    bound.apply_defaults()
+                    object.__setattr__(self, "_cfg", types.SimpleNamespace(**{k: v for k, v in bound.arguments.items() if k != "self"}))
+                    init(self, *a, **kw)
+                return wrapped
+
+            class ConfigMixin:
+                @property
+                def config(self):
+                    return self._cfg
+
+            class ModelMixin(nn.Module):
+                @property
+                def dtype(self):
+                    return next(self.parameters()).dtype
+            _install_unet_stubs(nn, _Dummy, _Logger)
+            _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+            _mod("diffusers.utils", BaseOutput=object, deprecate=lambda *a, **k: None,
+                 logging=types.SimpleNamespace(get_logger=lambda *a, **k: _Logger()))
+            _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+            ublocks.unet = importlib.import_module("_ref_seine_models.unet")
         spec = importlib.util.spec_from_file_location("_ref_seine_pnp_utils", os.path.join(REFERENCE_ROOT, "seine", "pnp_utils.py"))
         pnp = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(pnp)

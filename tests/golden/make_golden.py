@@ -315,10 +315,39 @@ def gen_seine():
     torch.save(fx, os.path.join(HERE, "seine_decoder_hooks.pt"))
 
 
+def gen_seine_unet():
+    """``seine_unet.pt`` (``--seine-unet``): the reference's own ``UNet3DConditionModel`` (``seine/models/unet.py``, every block from
+    the reference's files, ``oracle.ref_stubs.load_reference_seine_decoder(with_unet=True)``) at toy width, un-hooked and with the
+    reference's own four hook families registered on ``unet.up_blocks[1..3]`` (``register_time`` also walks the encoder and mid block)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import seine_spec as spec
+    att, ublocks, res, pnp, Rotary = ref_stubs.load_reference_seine_decoder(with_unet=True)
+    unet = spec.fill_weights(ublocks.unet.UNet3DConditionModel(**spec.UNET_CFG), spec.WEIGHT_SEED).eval()
+
+    def call(u, sample, t, ehs):
+        with torch.no_grad():
+            return u(sample, t, encoder_hidden_states=ehs).sample.clone()
+    out = spec.run_unet_cases(unet, pnp, call)
+    assert torch.equal(out["unet_nohook_t101"], out["unet_hook_t101"]), "a timestep outside every schedule must leave the UNet un-hooked"
+    a = out["unet_nohook"]
+    fx = {"spec": dict(cfg=spec.UNET_CFG, H=spec.UNET_H, W=spec.UNET_W, F=spec.UNET_F, weight_seed=spec.WEIGHT_SEED, input_seed=spec.INPUT_SEED,
+                       pnp=spec.PNP, n_keys=len(unet.state_dict())), "unet_nohook": a}
+    for t in spec.TS_CASES:
+        h = out[f"unet_hook_t{t}"]
+        fx[f"unet_hook_t{t}"] = h
+        print(f"seine unet t={t}: shape {tuple(h.shape)} max {float(h.abs().max()):.3f}  editing vs source {float((h[2] - h[0]).abs().max()):.3f}")
+    print(f"hooked t=981 vs un-hooked, branches 1-2: {float((out['unet_hook_t981'][1:] - a[1:]).abs().max() / a.abs().max()):.3f}; "
+          f"source branch equal {bool(torch.equal(out['unet_hook_t981'][:1], a[:1]))}")
+    torch.save(fx, os.path.join(HERE, "seine_unet.pt"))
+
+
 if __name__ == "__main__":
     assert ref_stubs.reference_available(), "needs /root/reference"
     if "--seine" in sys.argv:
         gen_seine()
+        sys.exit(0)
+    if "--seine-unet" in sys.argv:
+        gen_seine_unet()
         sys.exit(0)
     if "--consisti2v" in sys.argv:
         gen_consisti2v()

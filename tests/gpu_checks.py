@@ -2325,6 +2325,25 @@ def check_seine_hooks():
     return out
 
 
+def check_seine_unet():
+    """The whole SEINE UNet (``anyv2v_amd/seine.py:UNet3DConditionModel``) on the kernels vs the fixture the REFERENCE's own
+    ``UNet3DConditionModel`` + ``seine/pnp_utils.py`` produced on the CPU in fp32 (``make_golden.py --seine-unet``)."""
+    import seine_spec as spec
+    from anyv2v_amd import seine as sn
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "seine_unet.pt"))
+    unet = spec.fill_weights(sn.UNet3DConditionModel(**spec.UNET_CFG), spec.WEIGHT_SEED).to(DEV)
+
+    def call(u, sample, t, ehs):
+        return u(sample.to(DEV).half(), t, encoder_hidden_states=ehs.to(DEV).half()).sample.float().cpu()
+    got = spec.run_unet_cases(unet, sn, call)
+    out = []
+    for case in ["nohook"] + [f"hook_t{t}" for t in spec.TS_CASES]:
+        out.append(_res(f"seine whole UNet (toy width), {case} vs the reference's own UNet + hooks", got[f"unet_{case}"], fx[f"unet_{case}"], 8e-3))
+    out.append(dict(name="seine whole UNet: a timestep outside every schedule == un-hooked (bit-equal)", err=0.0, tol=0.0,
+                    ok=bool(torch.equal(got["unet_nohook_t101"], got["unet_hook_t101"]))))
+    return out
+
+
 def check_attention_bias_and_rotary_windows():
     """``anyv2v_attention_bias_f16`` (additive score bias [heads, Sq, Sk], frame-strided sequences, qk_mod aliasing) and
     ``anyv2v_rotary_f16`` with one window per head vs PyTorch fp32."""

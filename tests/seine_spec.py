@@ -67,3 +67,35 @@ def run_cases(blocks, pnp_module, call):
         for i, blk in blocks.items():
             out[f"block{i}_hook_t{t}"] = call(blk, *block_inputs(i))
     return out
+
+
+# ------------------------------------------------------------------------------------------------- the whole UNet (seine_unet.pt)
+# UNet3DConditionModel with the released model's options at toy width: 4 levels, 2 layers per block, 9 input channels
+# (latents | mask | masked-video latents), 1 x 1-conv projections, head_dim >= 32 everywhere (RotaryEmbedding(32) per head).
+UNET_CFG = dict(sample_size=8, in_channels=9, out_channels=4, block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=8,
+                cross_attention_dim=CROSS, attention_head_dim=(2, 1, 2, 4), use_linear_projection=False)
+UNET_H, UNET_W, UNET_F = 8, 16, 4
+
+
+def unet_inputs(seed=INPUT_SEED):
+    g = torch.Generator().manual_seed(seed + 277)
+    r = lambda *s: torch.randn(*s, generator=g).half().float()
+    return r(B, 9, UNET_F, UNET_H, UNET_W), r(B, TOKENS, CROSS)
+
+
+def run_unet_cases(unet, pnp_module, call):
+    """``call(unet, sample, t, ehs)`` -> prediction; un-hooked (t = 981, 101), then with the FOUR hook families at each TS_CASES (+ 101)."""
+    out = {}
+    sample, ehs = unet_inputs()
+    out["unet_nohook"] = call(unet, sample, 981, ehs)
+    out["unet_nohook_t101"] = call(unet, sample, 101, ehs)
+    model = types.SimpleNamespace(unet=unet)
+    s = schedules()
+    pnp_module.register_conv_injection(model, s["pnp_f_t"])
+    pnp_module.register_spatial_attention_pnp(model, s["pnp_spatial_attn_t"])
+    pnp_module.register_cross_attention_pnp(model, s["pnp_cross_attn_t"])
+    pnp_module.register_temp_attention_pnp(model, s["pnp_temp_attn_t"])
+    for t in TS_CASES + (101,):
+        pnp_module.register_time(model, t)
+        out[f"unet_hook_t{t}"] = call(unet, sample, t, ehs)
+    return out

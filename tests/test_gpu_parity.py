@@ -255,6 +255,10 @@ def test_seine_hook_family_vs_the_references_own_blocks_and_hooks():
     _assert_all(gc.check_seine_hooks())
 
 
+def test_seine_whole_unet_vs_the_references_own_unet_and_hooks():
+    _assert_all(gc.check_seine_unet())
+
+
 def test_attention_score_bias_and_per_head_rotary():
     _assert_all(gc.check_attention_bias_and_rotary_windows())
 

@@ -98,3 +98,55 @@ def test_seine_fixture_is_what_the_reference_code_produces_and_keys_match():
     nt = nat_blocks[1].attentions[0].transformer_blocks[0].attn_temp
     for n in (4, 16, 40):
         assert torch.allclose(ta.time_rel_pos_bias(n, device="cpu").float(), nt.time_rel_pos_bias.table(n, "cpu"), atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------- the whole UNet
+UNET_FIXTURE = os.path.join(HERE, "golden", "seine_unet.pt")
+
+
+def _native_unet():
+    from anyv2v_amd import seine as sn
+    return sn, spec.fill_weights(sn.UNet3DConditionModel(**spec.UNET_CFG), spec.WEIGHT_SEED)
+
+
+def _native_unet_call(u, sample, t, ehs):
+    return u(sample.half(), t, encoder_hidden_states=ehs.half()).sample.float()
+
+
+def test_native_seine_unet_vs_reference_fixture(monkeypatch):
+    """``UNet3DConditionModel.forward`` (``seine/models/unet.py:365-513``) un-hooked and under the four hook families."""
+    emu.install(monkeypatch)
+    sn, unet = _native_unet()
+    fx = torch.load(UNET_FIXTURE)
+    out = spec.run_unet_cases(unet, sn, _native_unet_call)
+    assert torch.equal(out["unet_nohook_t101"], out["unet_hook_t101"])
+    for case in ["nohook"] + [f"hook_t{t}" for t in spec.TS_CASES]:
+        got, ref = out[f"unet_{case}"], fx[f"unet_{case}"]
+        assert got.shape == ref.shape == (spec.B, 4, spec.UNET_F, spec.UNET_H, spec.UNET_W)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        l2 = float((got - ref).norm() / ref.norm())
+        assert err < 8e-3 and l2 < 4e-3, (case, err, l2)
+    a = out["unet_nohook"]
+    assert torch.equal(a[:1], out["unet_hook_t981"][:1])
+    assert float((a[1:] - out["unet_hook_t981"][1:]).abs().max() / a.abs().max()) > 0.05
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_seine_unet_fixture_is_what_the_reference_code_produces_and_keys_match():
+    warnings.filterwarnings("ignore")
+    att, ublocks, res, pnp, Rotary = ref_stubs.load_reference_seine_decoder(with_unet=True)
+    ref = spec.fill_weights(ublocks.unet.UNet3DConditionModel(**spec.UNET_CFG), spec.WEIGHT_SEED).eval()
+    sn, nat = _native_unet()
+    rs, ns = ref.state_dict(), nat.state_dict()
+    assert sorted(rs.keys()) == sorted(ns.keys())
+    assert all(tuple(rs[k].shape) == tuple(ns[k].shape) for k in rs)
+    nat.load_state_dict(rs, strict=True)
+
+    def call(u, sample, t, ehs):
+        with torch.no_grad():
+            return u(sample, t, encoder_hidden_states=ehs).sample
+    out = spec.run_unet_cases(ref, pnp, call)
+    fx = torch.load(UNET_FIXTURE)
+    for k, v in fx.items():
+        if k != "spec":
+            assert torch.allclose(out[k], v, rtol=1e-5, atol=1e-5 * float(v.abs().max())), k
