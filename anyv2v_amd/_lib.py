@@ -83,6 +83,7 @@ SYMBOLS = {
     "anyv2v_cfg_ddim_step_f16": (C.c_int, [_VP, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "anyv2v_ddim_step_f16": (C.c_int, [_VP, _VP, _VP, _F32, _F32, _F32, _F32, _I64, _VP]),
     "anyv2v_guided_step_f16": (C.c_int, [_VP, _I64, _I32, _I32, _I32, _F32, _F32, _I32, _F32, _F32, _F32, _F32, _VP, _VP, _VP]),
+    "anyv2v_guided_step_noise_f16": (C.c_int, [_VP, _I64, _I32, _I32, _I32, _F32, _F32, _I32, _F32, _F32, _F32, _F32, _VP, _VP, _VP, _F32, _VP]),
     "anyv2v_set_batch_hint": (C.c_int, [_I32, _I32]),
     "anyv2v_last_error": (C.c_char_p, []),
     "anyv2v_version": (C.c_int, []),

@@ -163,7 +163,7 @@ __global__ void ddim_step_kernel(const half_t* __restrict__ V, const half_t* __r
 // each guidance operation rounded to fp16 like the reference's fp16 tensors; the step in fp32.
 __global__ void guided_step_kernel(const half_t* __restrict__ E, long long n, int b_unc, int b_img, int b_txt, float g_img, float g_txt,
                                    int pred, float sa_t, float sb_t, float sa_p, float sb_p, const half_t* __restrict__ X,
-                                   half_t* __restrict__ Y) {
+                                   half_t* __restrict__ Y, const half_t* __restrict__ N, float sigma) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float e = (float)E[(long long)b_txt * n + i];
         if (b_unc >= 0) {
@@ -189,7 +189,9 @@ __global__ void guided_step_kernel(const half_t* __restrict__ E, long long n, in
             x0 = e;
             eps = (x - sa_t * e) / sb_t;
         }
-        Y[i] = (half_t)(sa_p * x0 + sb_p * eps);
+        float y = sa_p * x0 + sb_p * eps;
+        if (N != nullptr) y += sigma * (float)N[i];   // ancestral (DDPM) step: + sqrt(variance) * noise
+        Y[i] = (half_t)y;
     }
 }
 
@@ -349,8 +351,21 @@ extern "C" int anyv2v_guided_step_f16(const void* E, int64_t n, int32_t b_unc, i
              "guided_step: bad arguments");
     AV_CHECK(!(prediction == 1 && sa_t == 0.f) && !(prediction == 2 && sb_t == 0.f), "guided_step: this prediction type is singular at this alpha");
     hipLaunchKernelGGL(guided_step_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const half_t*)E, (long long)n,
-                       b_unc, b_img, b_txt, g_img, g_txt, prediction, sa_t, sb_t, sa_p, sb_p, (const half_t*)X, (half_t*)Y);
+                       b_unc, b_img, b_txt, g_img, g_txt, prediction, sa_t, sb_t, sa_p, sb_p, (const half_t*)X, (half_t*)Y,
+                       (const half_t*)nullptr, 0.f);
     return av_launch_status("guided_step");
+}
+
+extern "C" int anyv2v_guided_step_noise_f16(const void* E, int64_t n, int32_t b_unc, int32_t b_img, int32_t b_txt, float g_img, float g_txt,
+                                            int32_t prediction, float sa_t, float sb_t, float c_x0, float c_eps, const void* X, void* Y,
+                                            const void* noise, float sigma, void* stream) {
+    AV_CHECK(E && X && Y && n > 0 && b_txt >= 0 && prediction >= 0 && prediction <= 2 && (b_img < 0 || b_unc >= 0) && (noise || sigma == 0.f),
+             "guided_step_noise: bad arguments");
+    AV_CHECK(!(prediction == 1 && sa_t == 0.f) && !(prediction == 2 && sb_t == 0.f), "guided_step_noise: this prediction type is singular at this alpha");
+    hipLaunchKernelGGL(guided_step_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const half_t*)E, (long long)n,
+                       b_unc, b_img, b_txt, g_img, g_txt, prediction, sa_t, sb_t, c_x0, c_eps, (const half_t*)X, (half_t*)Y,
+                       (const half_t*)noise, sigma);
+    return av_launch_status("guided_step_noise");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -414,8 +414,9 @@ PRED_V, PRED_EPSILON, PRED_SAMPLE = 0, 1, 2
 
 
 def guided_step(e: torch.Tensor, x: torch.Tensor, coef, *, b_txt: int, b_unc: int = -1, b_img: int = -1, g_txt: float = 1.0,
-                g_img: float = 1.0, prediction: int = PRED_V, out=None):
-    """e: [nb, ...] the UNet's prediction of every branch; x: one branch's latents; coef = (sa_t, sb_t, sa_p, sb_p)."""
+                g_img: float = 1.0, prediction: int = PRED_V, out=None, noise=None, sigma: float = 0.0):
+    """e: [nb, ...] the UNet's prediction of every branch; x: one branch's latents; coef = (sa_t, sb_t, c_x0, c_eps):
+    y = c_x0 x0 + c_eps eps (+ sigma noise) -- DDIM: (c_x0, c_eps) = (sa_p, sb_p)."""
     lib = _lib.load()
     assert e.is_contiguous() and x.is_contiguous() and e.dtype == x.dtype == torch.float16
     n = x.numel()
@@ -423,6 +424,12 @@ def guided_step(e: torch.Tensor, x: torch.Tensor, coef, *, b_txt: int, b_unc: in
     if out is None:
         out = torch.empty_like(x)
     sa_t, sb_t, sa_p, sb_p = (float(c) for c in coef)
+    if noise is not None or sigma != 0.0:
+        assert noise is None or (noise.is_contiguous() and noise.dtype == torch.float16 and noise.numel() == n)
+        _lib.check(lib.anyv2v_guided_step_noise_f16(_p(e), n, b_unc, b_img, b_txt, float(g_img), float(g_txt), int(prediction), sa_t, sb_t,
+                                                    sa_p, sb_p, _p(x), _p(out), _p(noise), float(sigma), _stream()),
+                   "anyv2v_guided_step_noise_f16")
+        return out
     _lib.check(lib.anyv2v_guided_step_f16(_p(e), n, b_unc, b_img, b_txt, float(g_img), float(g_txt), int(prediction), sa_t, sb_t, sa_p,
                                           sb_p, _p(x), _p(out), _stream()), "anyv2v_guided_step_f16")
     return out

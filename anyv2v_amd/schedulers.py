@@ -36,6 +36,16 @@ CONSISTI2V_SCHEDULER_CONFIG = dict(
     clip_sample_range=1.0, set_alpha_to_one=True, steps_offset=1, prediction_type="epsilon", thresholding=False,
     dynamic_thresholding_ratio=0.995, sample_max_value=1.0, timestep_spacing="leading", rescale_betas_zero_snr=False)
 
+# SEINE builds its schedulers from Stable Diffusion 1.4's ``scheduler/scheduler_config.json`` with the betas overridden by its own
+# config (``seine/run_pnp_edit.py:86-103``, ``configs/pnp_edit.yaml:28-31``: linear 1e-4 .. 0.02).  The SD-1.4 file is not in the
+# reference tree; these are its fields (epsilon prediction, ``set_alpha_to_one`` false, ``steps_offset`` 1, no sample clipping).  The
+# reference's ``load_ddim_latents_at_t(t + 1)`` under the DDPM sampler (``run_pnp_edit.py:170``) pins "DDPM timesteps = DDIM
+# timesteps - 1", i.e. diffusers-0.15's ``DDPMScheduler.set_timesteps`` without ``steps_offset`` (``seine/requirement.txt:5``).
+SEINE_SCHEDULER_CONFIG = dict(
+    num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None, clip_sample=False,
+    clip_sample_range=1.0, set_alpha_to_one=False, steps_offset=1, prediction_type="epsilon", thresholding=False,
+    dynamic_thresholding_ratio=0.995, sample_max_value=1.0, timestep_spacing="leading", rescale_betas_zero_snr=False)
+
 _PREDICTION = {"v_prediction": ops.PRED_V, "epsilon": ops.PRED_EPSILON, "sample": ops.PRED_SAMPLE}
 
 
@@ -175,3 +185,57 @@ class DDIMInverseScheduler(_DDIMBase):
         cur = min(timestep - self._ratio(), self.config.num_train_timesteps - 1)
         a_c, a_n = self._abar(cur), self._abar(timestep)
         return (math.sqrt(a_c), math.sqrt(1.0 - a_c), math.sqrt(a_n), math.sqrt(1.0 - a_n))
+
+
+class DDPMScheduler(_DDIMBase):
+    """diffusers-0.15 ``DDPMScheduler`` as SEINE's edit loop calls it (``seine/run_pnp_edit.py:93-103,205``: ``set_timesteps``,
+    ``timesteps``, ``step(noise_pred, t, x)["prev_sample"]``; variance type "fixed_small", no sample clipping): the ancestral step
+    ``x' = c0 x0 + ct x + sqrt(var) n`` with ``c0 = sqrt(a_prev) beta_t / (1 - a_t)``, ``ct = sqrt(alpha_t) (1 - a_prev) / (1 - a_t)``,
+    ``var = (1 - a_prev) / (1 - a_t) beta_t`` (0 at t = 0), ``alpha_t = a_t / a_prev``, ``a_prev`` = 1 below timestep 0.  The noise is
+    drawn from the global RNG (or ``generator``) in the sample's dtype on the sample's device, as ``randn_tensor`` does.  UNPINNED:
+    diffusers is not in the reference tree; restated from the 0.15.0 release the reference pins (``seine/requirement.txt:5``)."""
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self._check_n(num_inference_steps)
+        self.num_inference_steps = num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * self._ratio()).round()[::-1].copy().astype(np.int64)   # (no steps_offset in 0.15)
+        self.timesteps = torch.from_numpy(ts).to(device)
+
+    def ancestral_coefficients(self, timestep: int):
+        """(sa_t, sb_t, c_x0, c_eps, sigma) of ``ops.guided_step``: x = sa_t x0 + sb_t eps, so c0 x0 + ct x = (c0 + ct sa_t) x0 + ct sb_t eps."""
+        n = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
+        prev = timestep - self.config.num_train_timesteps // n
+        a_t = float(self.alphas_cumprod[timestep])
+        a_p = float(self.alphas_cumprod[prev]) if prev >= 0 else 1.0
+        alpha_t = a_t / a_p
+        beta_t = 1.0 - alpha_t
+        c0 = math.sqrt(a_p) * beta_t / (1.0 - a_t)
+        ct = math.sqrt(alpha_t) * (1.0 - a_p) / (1.0 - a_t)
+        var = max((1.0 - a_p) / (1.0 - a_t) * beta_t, 1e-20)
+        sa_t, sb_t = math.sqrt(a_t), math.sqrt(1.0 - a_t)
+        return sa_t, sb_t, c0 + ct * sa_t, ct * sb_t, (math.sqrt(var) if timestep > 0 else 0.0)
+
+    def coefficients(self, timestep: int):
+        return self.ancestral_coefficients(timestep)[:4]
+
+    noise_on_host = False   # tests: draw from the CPU generator (the fixture's stream) whatever device the sample lives on
+
+    def draw_noise(self, like: torch.Tensor, timestep: int, generator=None):
+        if int(timestep) <= 0:
+            return None
+        if self.noise_on_host:
+            return torch.randn(like.shape, generator=generator, dtype=like.dtype).to(like.device)
+        return torch.randn(like.shape, generator=generator, device=like.device, dtype=like.dtype)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True, **unused):
+        if self.prediction != ops.PRED_EPSILON or self.config.clip_sample:
+            raise NotImplementedError("DDPM step: epsilon prediction without sample clipping only")
+        sa_t, sb_t, cx, ce, sigma = self.ancestral_coefficients(int(timestep))
+        e = model_output.to(torch.float16).contiguous()
+        x = sample.to(torch.float16).contiguous()
+        noise = self.draw_noise(e, int(timestep), generator)
+        prev = ops.guided_step(e.view(1, -1), x, (sa_t, sb_t, cx, ce), b_txt=0, prediction=self.prediction, noise=noise, sigma=sigma)
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev)
+

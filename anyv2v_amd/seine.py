@@ -530,6 +530,14 @@ def register_time(model, t):
             setattr(getattr(blk, name), "t", t)
 
 
+def clear_time(model):
+    """No hook fires until the next ``register_time`` (the reference's inversion runs in a process of its own, without hooks)."""
+    model.unet.up_blocks[1].resnets[1].t = None
+    for blk in _blocks_of(model.unet):
+        for name in ("attn1", "attn2", "attn_temp"):
+            getattr(blk, name).t = None
+
+
 def register_conv_injection(model, injection_schedule, d_s=0.1, d_t=0.5):
     """``seine/pnp_utils.py:150-196``."""
     setattr(model.unet.up_blocks[1].resnets[1], "injection_schedule", _sched(injection_schedule))

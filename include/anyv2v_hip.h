@@ -253,6 +253,15 @@ int anyv2v_ddim_step_f16(const void* V, const void* X, void* Y, float sa_t, floa
 int anyv2v_guided_step_f16(const void* E, int64_t n, int32_t b_unc, int32_t b_img, int32_t b_txt, float g_img, float g_txt,
                            int32_t prediction, float sa_t, float sb_t, float sa_p, float sb_p, const void* X, void* Y, void* stream);
 
+/* The same with general coefficients and an additive noise term -- the ancestral (DDPM) step of SEINE's edit loop
+ * (seine/run_pnp_edit.py:205 `self.scheduler.step(noise_pred, t, x)` with sample_method "ddpm"):
+ *   y = c_x0 * x0 + c_eps * eps + sigma * noise[i]      x0 / eps from the guided prediction as above (sa_t, sb_t).
+ * DDPM without sample clipping: c_x0 = coeff_x0 + coeff_xt * sa_t, c_eps = coeff_xt * sb_t (x = sa_t x0 + sb_t eps).  noise may be NULL
+ * when sigma is 0 (the last step). */
+int anyv2v_guided_step_noise_f16(const void* E, int64_t n, int32_t b_unc, int32_t b_img, int32_t b_txt, float g_img, float g_txt,
+                                 int32_t prediction, float sa_t, float sb_t, float c_x0, float c_eps, const void* X, void* Y,
+                                 const void* noise, float sigma, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 /* Launch heuristics (kernel family, split-K factor, GroupNorm chunking) see rows * num / den from now on; grids and bounds keep the true
  * row counts.  The PnP edit runs some steps on [negative, editing] only (steps outside every injection schedule; steps whose source
@@ -266,7 +275,7 @@ const char* anyv2v_last_error(void);
 /* ABI version = major * 100 + minor.  Descriptors carry no size field: a caller MUST be compiled against the header of the
  * library it loads (check anyv2v_version() >= the ANYV2V_ABI_VERSION it was built with) and MUST zero-initialise every
  * descriptor (new fields are appended with 0 = "off").  101: AnyV2VGemmDesc grew ln_c1 / ln_eps / reserved0 (round 3), flags
- * bits 13-16 select the persistent kernel's tile order (round 4).  102: anyv2v_ff_geglu_f16.  103: anyv2v_guided_step_f16. */
+ * bits 13-16 select the persistent kernel's tile order (round 4).  102: anyv2v_ff_geglu_f16.  103: anyv2v_guided_step_f16, anyv2v_guided_step_noise_f16. */
 #define ANYV2V_ABI_VERSION 103
 int anyv2v_version(void);
 /* MFMA / LDS layout self-test used by the gpu test-suite (returns 0 when the layouts the kernels assume hold) */

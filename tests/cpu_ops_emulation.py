@@ -238,7 +238,7 @@ def cfg_ddim_step(vtok, b_unc, b_cond, guidance, coef, lat, out):
     return out
 
 
-def guided_step(e, x, coef, *, b_txt, b_unc=-1, b_img=-1, g_txt=1.0, g_img=1.0, prediction=0, out=None):
+def guided_step(e, x, coef, *, b_txt, b_unc=-1, b_img=-1, g_txt=1.0, g_img=1.0, prediction=0, out=None, noise=None, sigma=0.0):
     h = lambda t: t.half().float()
     eb = e.reshape(e.numel() // x.numel(), -1).float()
     v = eb[b_txt]
@@ -257,7 +257,10 @@ def guided_step(e, x, coef, *, b_txt, b_unc=-1, b_img=-1, g_txt=1.0, g_img=1.0, 
         x0, eps = (xf - sb_t * v) / sa_t, v
     else:
         x0, eps = v, (xf - sa_t * v) / sb_t
-    y = (sa_p * x0 + sb_p * eps).half().reshape(x.shape)
+    y = sa_p * x0 + sb_p * eps
+    if noise is not None:
+        y = y + float(sigma) * noise.reshape(-1).float()
+    y = y.half().reshape(x.shape)
     if out is not None:
         out.copy_(y)
         return out

@@ -341,10 +341,37 @@ def gen_seine_unet():
     torch.save(fx, os.path.join(HERE, "seine_unet.pt"))
 
 
+def gen_seine_pipeline():
+    """``seine_pipeline.pt`` (``--seine-pipeline``): the reference's own runner classes (``oracle/ref_seine_pipeline.py``: both runner
+    files imported verbatim around the reference's UNet, hooks and helpers; toy VAE / text encoder) through both stages on one
+    synthetic clip -- ``tests/seine_spec.JOB`` -- once with the DDIM sampler, once with the shipped default, ancestral DDPM."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import seine_spec as spec
+    from oracle import ref_seine_pipeline as rsp
+    frames, edited = spec.job_frames()
+    h = lambda x: x.detach().to(torch.float16).contiguous()
+    fx = {"spec": dict(spec.JOB)}
+    for sm in ("ddim", "ddpm"):
+        inv, ed = spec.job_configs(sm)
+        with tempfile.TemporaryDirectory() as tmp:
+            job = rsp.run_reference_job(spec.UNET_CFG, spec.fill_weights, spec.WEIGHT_SEED, frames, edited, inv, ed, tmp)
+        if sm == "ddim":
+            fx.update(inv_ts=job["inv_ts"], lat0=h(job["lat0"]), trajectory=h(torch.stack([job["files"][t] for t in job["inv_ts"]])),
+                      recon_lat=h(job["recon_lat"]), recon_frames=job["recon_frames"])
+        fx[f"edit_ts_{sm}"], fx[f"edit_lat_{sm}"], fx[f"edited_frames_{sm}"] = job["edit_ts"], h(job["edit_lat"]), job["edited_frames"]
+        print(sm, "edit timesteps", job["edit_ts"], "|edit_lat| max", float(job["edit_lat"].abs().max()))
+    torch.save(fx, os.path.join(HERE, "seine_pipeline.pt"))
+    print("seine_pipeline.pt", {k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in fx.items() if k != "spec"})
+
+
 if __name__ == "__main__":
     assert ref_stubs.reference_available(), "needs /root/reference"
     if "--seine" in sys.argv:
         gen_seine()
+        sys.exit(0)
+    if "--seine-pipeline" in sys.argv:
+        gen_seine_pipeline()
         sys.exit(0)
     if "--seine-unet" in sys.argv:
         gen_seine_unet()

@@ -2344,6 +2344,32 @@ def check_seine_unet():
     return out
 
 
+def check_seine_pipeline():
+    """SEINE end to end, runner-class level: ``anyv2v_amd.seine_pipeline`` on the kernels vs the fixture the REFERENCE's own
+    ``SEINEDDIMInversionPipeline`` / ``SEINEPnPPipeline`` produced on the CPU (``make_golden.py --seine-pipeline``), DDIM and DDPM samplers
+    (the DDPM noise is drawn from the CPU generator, the fixture's stream); the edit starts from the reference's own trajectory."""
+    import tempfile
+
+    import seine_spec as spec
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "seine_pipeline.pt"))
+    files = {t: fx["trajectory"][i] for i, t in enumerate(fx["inv_ts"])}
+    out = []
+    for sm in ("ddim", "ddpm"):
+        with tempfile.TemporaryDirectory() as tmp:
+            nat = spec.native_job(DEV, tmp, sm, trajectory_from=files)
+        if sm == "ddim":
+            out.append(_res("seine runners: frames -> VAE latents", nat["lat0"].float().cpu(), fx["lat0"].float(), 2e-3))
+            for i, t in enumerate(fx["inv_ts"]):
+                out.append(_res(f"seine runners: ddim_inversion, file at t={t}", nat["files"][t].float().cpu(), fx["trajectory"][i].float(), 1e-2))
+            out.append(_res("seine runners: ddim_sample reconstruction", nat["recon_lat"].float().cpu(), fx["recon_lat"].float(), 2e-2))
+        out.append(dict(name=f"seine runners: edit timesteps ({sm})", err=0.0, tol=0.0, ok=nat["edit_ts"] == fx[f"edit_ts_{sm}"]))
+        out.append(_res(f"seine runners: edit_video, {sm} sampler, cfg 4", nat["edit_lat"].float().cpu(), fx[f"edit_lat_{sm}"].float(), 6e-2))
+        dec = nat["pipe"].decode_latents(fx[f"edit_lat_{sm}"].to(DEV))
+        d = int((dec.int() - fx[f"edited_frames_{sm}"].int()).abs().max())
+        out.append(dict(name=f"seine runners: decode_latents of the reference's latents ({sm}), max |uint8 diff|", err=float(d), tol=1.0, ok=d <= 1))
+    return out
+
+
 def check_attention_bias_and_rotary_windows():
     """``anyv2v_attention_bias_f16`` (additive score bias [heads, Sq, Sk], frame-strided sequences, qk_mod aliasing) and
     ``anyv2v_rotary_f16`` with one window per head vs PyTorch fp32."""

@@ -99,3 +99,102 @@ def run_unet_cases(unet, pnp_module, call):
         pnp_module.register_time(model, t)
         out[f"unet_hook_t{t}"] = call(unet, sample, t, ehs)
     return out
+
+
+# ------------------------------------------------------------------------------------------------- the two-stage job (seine_pipeline.pt)
+JOB = dict(frames=UNET_F, height=64, width=128, inv_steps=8, save_steps=4, edit_steps=4, cfg_scale=4.0, prompt="a robot", negative_prompt="blurry",
+           pnp=dict(pnp_f_t=0.5, pnp_spatial_attn_t=0.5, pnp_cross_attn_t=0.25, pnp_temp_attn_t=0.75))
+
+
+def job_configs(sample_method="ddpm"):
+    """The reference's two yaml files (``configs/seine/``: same keys and values as ``seine/configs/``) with the toy job's overrides."""
+    import os
+    from anyv2v_amd.config import OmegaConf
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "seine")
+    inv, ed = OmegaConf.load(os.path.join(root, "ddim_inversion.yaml")), OmegaConf.load(os.path.join(root, "pnp_edit.yaml"))
+    j = JOB
+    inv.device = ed.device = "cpu"
+    inv.image_size = ed.image_size = [j["height"], j["width"]]
+    inv.n_steps, inv.n_save_steps, inv.n_frame_to_invert = j["inv_steps"], j["save_steps"], j["frames"]
+    ed.n_ddim_inversion_steps, ed.n_frame_inverted, ed.n_frames, ed.n_steps = j["inv_steps"], j["frames"], j["frames"], j["edit_steps"]
+    ed.sample_method, ed.cfg_scale, ed.prompt, ed.negative_prompt = sample_method, j["cfg_scale"], j["prompt"], j["negative_prompt"]
+    for k, v in j["pnp"].items():
+        ed[k] = v
+    return inv, ed
+
+
+def job_frames():
+    import numpy as np
+    from PIL import Image
+    j = JOB
+    rng = np.random.RandomState(7)
+
+    def pic(ph):
+        yy, xx = np.mgrid[0:j["height"], 0:j["width"]].astype(np.float32)
+        yy, xx = yy / j["height"], xx / j["width"]
+        tex = rng.rand(j["height"], j["width"], 3).astype(np.float32)
+        img = np.stack([0.5 + 0.5 * np.sin(6.3 * (xx + ph)), yy, 0.5 + 0.5 * np.cos(6.3 * (xx * yy + ph))], -1)
+        return Image.fromarray((255 * (0.8 * img + 0.2 * tex)).clip(0, 255).astype("uint8"))
+    return [pic(i / 3.0) for i in range(j["frames"])], pic(0.41).transpose(Image.FLIP_LEFT_RIGHT)
+
+
+def native_job(device, work_dir, sample_method="ddpm", trajectory_from=None):
+    """Both stages on the native runner classes, driven like ``oracle.ref_seine_pipeline.run_reference_job`` drives the reference's.
+    ``trajectory_from``: {t: latents} written in place of the native inversion's own files before the edit stage."""
+    import os
+    from anyv2v_amd.seine_pipeline import SEINEDDIMInversionPipeline, SEINEPnPPipeline
+    from anyv2v_amd import seine as sn
+    from anyv2v_amd.schedulers import SEINE_SCHEDULER_CONFIG, DDIMScheduler
+    from anyv2v_amd.utils import seed_everything
+    from consisti2v_spec import ToyVaeAdapter
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    from pathlib import Path
+    import yaml
+    work_dir = str(work_dir)
+    frames, edited = job_frames()
+    clip_dir = os.path.join(work_dir, "clip")
+    os.makedirs(clip_dir, exist_ok=True)
+    for i, f in enumerate(frames):
+        f.save(os.path.join(clip_dir, "%05d.png" % i))
+    edited_path = os.path.join(work_dir, "edited.png")
+    edited.save(edited_path)
+    inv, ed = job_configs(sample_method)
+    inv.device = ed.device = str(device)
+    dim = UNET_CFG["cross_attention_dim"]
+
+    def parts():
+        unet = fill_weights(sn.UNet3DConditionModel(**UNET_CFG), WEIGHT_SEED).to(device)
+        tok = rp.ToyTokenizer()
+        return dict(unet=unet, vae=ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(dim), tok))
+    inv.src_video_path, inv.output_dir = clip_dir, os.path.join(work_dir, "ddim-inversion", "default")
+    seed_everything(inv.seed)
+    toy = DDIMScheduler(**SEINE_SCHEDULER_CONFIG)
+    toy.set_timesteps(inv.n_save_steps)
+    save_path = os.path.join(inv.output_dir, inv.model_name, Path(inv.src_video_path).stem, f"steps_{inv.n_steps}", f"nframes_{inv.n_frame_to_invert}")
+    os.makedirs(os.path.join(save_path, "ddim_latents"), exist_ok=True)
+    with open(os.path.join(save_path, "inversion_prompts.yaml"), "w") as f:
+        yaml.dump({Path(inv.src_video_path).stem: inv.inversion_prompt}, f)
+    p1 = SEINEDDIMInversionPipeline(device, inv, **parts())
+    out = {"lat0": p1.latent_at_0.clone()}
+    out["recon_frames"] = p1.extract_ddim_latents(inv, toy.timesteps, save_path)
+    out["recon_lat"] = p1.reconstructed_latents
+    lat_dir = os.path.join(save_path, "ddim_latents")
+    out["files"] = {int(f.split("_")[-1].split(".")[0]): torch.load(os.path.join(lat_dir, f)) for f in sorted(os.listdir(lat_dir))}
+    if trajectory_from is not None:
+        for t, v in trajectory_from.items():
+            torch.save(v.clone(), os.path.join(lat_dir, f"ddim_latents_{t}.pt"))
+    ed.src_video_path, ed.edited_first_frame_path, ed.ddim_inversion_dir = clip_dir + ".mp4", edited_path, inv.output_dir
+    comp = parts()              # (built before seeding: the DDPM noise stream is then a function of the seed alone)
+    seed_everything(ed.seed)
+    p2 = SEINEPnPPipeline(device, ed, **comp)
+    p2.scheduler.noise_on_host = True     # the fixture's noise stream is the CPU generator's
+    p2.scheduler.set_timesteps(ed.n_steps)
+    if ed.enable_pnp:
+        p2.init_pnp()
+    out["edited_frames"] = p2.edit_video(ed)
+    out["edit_lat"] = p2.edited_latents
+    out["edit_ts"] = [int(t) for t in p2.scheduler.timesteps]
+    out["pipe"] = p2
+    return out

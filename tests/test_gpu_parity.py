@@ -259,6 +259,10 @@ def test_seine_whole_unet_vs_the_references_own_unet_and_hooks():
     _assert_all(gc.check_seine_unet())
 
 
+def test_seine_runner_classes_vs_the_references_own_runner_classes():
+    _assert_all(gc.check_seine_pipeline())
+
+
 def test_attention_score_bias_and_per_head_rotary():
     _assert_all(gc.check_attention_bias_and_rotary_windows())
 

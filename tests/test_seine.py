@@ -150,3 +150,59 @@ def test_seine_unet_fixture_is_what_the_reference_code_produces_and_keys_match()
     for k, v in fx.items():
         if k != "spec":
             assert torch.allclose(out[k], v, rtol=1e-5, atol=1e-5 * float(v.abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------- the two runner classes
+PIPE_FIXTURE = os.path.join(HERE, "golden", "seine_pipeline.pt")
+# cfg_scale 4 multiplies the difference of two branch predictions (and its fp16 rounding) by 4, over 4 steps on latents that random
+# weights drive to |x| ~ 10-17: measured on the op emulation 2.2e-2 (DDIM) / 1.2e-2 (DDPM) of the range
+EDIT_TOL = 6e-2
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def _check_job(nat, ref, sm):
+    assert _rel(nat["lat0"], ref["lat0"]) <= 2e-3
+    for i, t in enumerate(ref["inv_ts"]):
+        e = _rel(nat["files"][t], ref["trajectory"][i])
+        assert e <= 1e-2, (f"inversion file t={t}", e)
+    assert sorted(nat["files"]) == ref["inv_ts"]
+    assert _rel(nat["recon_lat"], ref["recon_lat"]) <= 2e-2
+    assert nat["edit_ts"] == ref[f"edit_ts_{sm}"]
+    e = _rel(nat["edit_lat"], ref[f"edit_lat_{sm}"])
+    assert e <= EDIT_TOL, (f"edit ({sm})", e)
+    # decode_latents on the REFERENCE's latents: scaling, frame order, uint8 conversion ((x / 2 + 0.5) * 255 + 0.5, truncated)
+    dec = nat["pipe"].decode_latents(ref[f"edit_lat_{sm}"].to(nat["edit_lat"].device))
+    assert dec.shape == ref[f"edited_frames_{sm}"].shape and dec.dtype == torch.uint8
+    assert int((dec.int() - ref[f"edited_frames_{sm}"].int()).abs().max()) <= 1
+
+
+@pytest.mark.parametrize("sm", ["ddim", "ddpm"])
+def test_native_seine_runner_classes_vs_reference_fixture(monkeypatch, tmp_path, sm):
+    """``SEINEDDIMInversionPipeline`` / ``SEINEPnPPipeline`` on the op emulation vs the fixture the reference's own runner classes produced
+    (``make_golden.py --seine-pipeline``): frame pre-processing + VAE latents, every trajectory file, the DDIM reconstruction, the PnP edit
+    with the DDIM sampler and with the shipped default (ancestral DDPM, same noise stream), decoding."""
+    emu.install(monkeypatch)
+    fx = torch.load(PIPE_FIXTURE)
+    files = {t: fx["trajectory"][i] for i, t in enumerate(fx["inv_ts"])}
+    _check_job(spec.native_job("cpu", tmp_path, sm, trajectory_from=files), fx, sm)
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_seine_pipeline_fixture_is_what_the_reference_runner_classes_produce(tmp_path):
+    warnings.filterwarnings("ignore")
+    from oracle import ref_seine_pipeline as rsp
+    frames, edited = spec.job_frames()
+    fx = torch.load(PIPE_FIXTURE)
+    for sm in ("ddim", "ddpm"):
+        inv, ed = spec.job_configs(sm)
+        job = rsp.run_reference_job(spec.UNET_CFG, spec.fill_weights, spec.WEIGHT_SEED, frames, edited, inv, ed, tmp_path / sm)
+        assert _rel(fx[f"edit_lat_{sm}"], job["edit_lat"]) <= 2e-3 and torch.equal(fx[f"edited_frames_{sm}"], job["edited_frames"])
+        assert job["edit_ts"] == fx[f"edit_ts_{sm}"]
+        if sm == "ddim":
+            assert _rel(fx["lat0"], job["lat0"]) <= 1e-3 and _rel(fx["recon_lat"], job["recon_lat"]) <= 2e-3
+            for i, t in enumerate(job["inv_ts"]):
+                assert _rel(fx["trajectory"][i], job["files"][t]) <= 2e-3
