@@ -206,3 +206,70 @@ def test_seine_pipeline_fixture_is_what_the_reference_runner_classes_produce(tmp
             assert _rel(fx["lat0"], job["lat0"]) <= 1e-3 and _rel(fx["recon_lat"], job["recon_lat"]) <= 2e-3
             for i, t in enumerate(job["inv_ts"]):
                 assert _rel(fx["trajectory"][i], job["files"][t]) <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------- the CLI runners
+def run_seine_cli_stages(base, device):
+    """Both CLIs as two processes would run them, on a toy checkpoint directory (SD-style ``unet/config.json`` + ``seine.pt``)."""
+    import json
+    from anyv2v_amd import seine as sn
+    from anyv2v_amd import seine_run_ddim_inversion as s1, seine_run_pnp_edit as s2
+    base = str(base)
+    j = spec.JOB
+    os.makedirs(os.path.join(base, "sd", "unet"), exist_ok=True)
+    json.dump(dict(spec.UNET_CFG, _class_name="UNet2DConditionModel"), open(os.path.join(base, "sd", "unet", "config.json"), "w"))
+    unet = spec.fill_weights(sn.UNet3DConditionModel(**spec.UNET_CFG), spec.WEIGHT_SEED)
+    torch.save({"ema": unet.state_dict()}, os.path.join(base, "seine.pt"))
+    frames, edited = spec.job_frames()
+    os.makedirs(os.path.join(base, "clip"), exist_ok=True)
+    for i, f in enumerate(frames):
+        f.save(os.path.join(base, "clip", f"{i:05d}.png"))
+    edited.save(os.path.join(base, "edited.png"))
+    common = [f"device={device}", f"sd_path={base}/sd", f"ckpt_path={base}/seine.pt", f"image_size=[{j['height']},{j['width']}]"]
+    root = os.path.join(os.path.dirname(HERE), "configs", "seine")
+    save1 = s1.cli(["--config", os.path.join(root, "ddim_inversion.yaml"), "--video_path", os.path.join(base, "clip")] + common +
+                   [f"output_dir={base}/ddim-inversion/default", f"n_steps={j['inv_steps']}", f"n_save_steps={j['save_steps']}",
+                    f"n_frame_to_invert={j['frames']}"])
+    save2 = s2.cli(["--config", os.path.join(root, "pnp_edit.yaml")] + common +
+                   [f"output_dir={base}/results", f"src_video_path={base}/clip.mp4", f"edited_first_frame_path={base}/edited.png",
+                    f"ddim_inversion_dir={base}/ddim-inversion/default", f"n_ddim_inversion_steps={j['inv_steps']}", f"n_frame_inverted={j['frames']}",
+                    f"n_frames={j['frames']}", f"n_steps={j['edit_steps']}", "prompt=a robot", "pnp_f_t=0.5", "pnp_spatial_attn_t=0.5",
+                    "pnp_cross_attn_t=0.25", "pnp_temp_attn_t=0.75"])
+    return save1, save2
+
+
+def check_seine_cli_outputs(save1, save2):
+    import numpy as np
+    from PIL import Image
+    from anyv2v_amd.mp4 import read_mp4
+    j = spec.JOB
+    assert save1.endswith(os.path.join("seine", "clip", f"steps_{j['inv_steps']}", f"nframes_{j['frames']}"))
+    lat = sorted(os.listdir(os.path.join(save1, "ddim_latents")))
+    assert lat == sorted(f"ddim_latents_{t}.pt" for t in (1, 251, 501, 751))
+    x = torch.load(os.path.join(save1, "ddim_latents", "ddim_latents_751.pt"))
+    assert tuple(x.shape) == (1, 4, j["frames"], j["height"] // 8, j["width"] // 8) and torch.isfinite(x.float()).all()
+    import yaml
+    assert yaml.safe_load(open(os.path.join(save1, "inversion_prompts.yaml"))) == {"clip": ""}
+    assert yaml.safe_load(open(os.path.join(save1, "config.yaml")))["n_steps"] == j["inv_steps"]
+    assert len(os.listdir(os.path.join(save1, "recon_frames"))) == j["frames"] and len(read_mp4(os.path.join(save1, "inverted.mp4"))[0]) == j["frames"]
+    assert save2.endswith(os.path.join("seine", "clip", "a_robot", f"cfg4_f0.5_spa0.5_cro0.25_tmp0.75_stp{j['edit_steps']}"))
+    pngs = sorted(os.listdir(os.path.join(save2, "img_ode")))
+    assert pngs == [f"{i:05d}.png" for i in range(j["frames"])]
+    vid, fps = read_mp4(os.path.join(save2, "video_pnp_fps_8.mp4"))
+    assert len(vid) == j["frames"] and vid[0].size == (j["width"], j["height"]) and fps == 8.0
+    return np.stack([np.asarray(Image.open(os.path.join(save2, "img_ode", p))) for p in pngs])
+
+
+def test_seine_cli_runners_end_to_end(monkeypatch, tmp_path):
+    """``seine/run_ddim_inversion.py`` -> ``run_pnp_edit.py`` as CLIs: the reference's config files and directory layout (the edit finds
+    the inversion by globbing ``<ddim_inversion_dir>/seine/<clip>/steps_<n>/nframes_*``), a checkpoint in the reference's format
+    (``{"ema": state_dict}``), PNG frames in; latents, yaml files, frames and mp4 out; same seed -> same frames (DDPM sampler)."""
+    emu.install(monkeypatch)
+    a = check_seine_cli_outputs(*run_seine_cli_stages(tmp_path / "a", "cpu"))
+    b = check_seine_cli_outputs(*run_seine_cli_stages(tmp_path / "b", "cpu"))
+    assert (a == b).all()
+
+
+@pytest.mark.gpu
+def test_seine_cli_runners_on_gpu(tmp_path):
+    check_seine_cli_outputs(*run_seine_cli_stages(tmp_path / "a", "cuda:0"))
