@@ -533,8 +533,8 @@ __global__ void attn_naive_kernel(const AttnK p, const float* __restrict__ bias)
 // takes the exact softmax over it (no online rescaling), and multiplies O^T = V^T P^T.  The P registers feed the second MFMA
 // directly: a lane's scores are keys {4 lq + r + 16 kb}, and the contraction index of an MFMA may be any permutation as long as
 // both operands use it -- the V^T fragment is read in that key order (two 8-byte LDS reads).
-template <int DS, int NKB>   // DS = dpad / 32 (2..5), NKB = padded keys / 16 (even: PV contracts 32 keys per MFMA)
-__global__ __launch_bounds__(256) void small_attn_mfma_kernel(const AttnK p) {
+template <int DS, int NKB, bool BIAS = false>   // DS = dpad / 32 (2..5), NKB = padded keys / 16 (even: PV contracts 32 keys per MFMA)
+__global__ __launch_bounds__(256) void small_attn_mfma_kernel(const AttnK p, const float* __restrict__ bias = nullptr) {
     constexpr int DPAD = DS * 32, SKP = NKB * 16;
     constexpr int KLD = DPAD + 8;    // halves per K row (+16 B: breaks the power-of-2 row stride for the ds_read_b128 fragments)
     constexpr int VLD = SKP + 4;     // halves per V^T row
@@ -591,6 +591,8 @@ __global__ __launch_bounds__(256) void small_attn_mfma_kernel(const AttnK p) {
         for (int r = 0; r < 4; ++r) {
             const int key = kb * 16 + 4 * lq + r;
             const bool ok = key < p.Sk && (!p.causal || key <= qrow);
+            if (BIAS && ok && qrow < p.Sq)   // the bias in units of the raw score (logit = scale * s + bias; c = scale * log2 e)
+                sc[kb][r] += bias[((long long)h * p.Sq + qrow) * p.Sk + key] * (1.4426950408889634f / p.scale_log2);
             sc[kb][r] = ok ? sc[kb][r] : -1e30f;
             m = fmaxf(m, sc[kb][r]);
         }
@@ -711,6 +713,131 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     return av_launch_status("flash_attn_d64_v2");
 }
 
+// Any sequence length at head_dim <= 160 (a multiple of 8): the whole-sequence kernel above with a loop over 96-key blocks and the
+// online softmax (running maximum / sum per query, accumulators rescaled when the maximum moves).  SEINE's spatial attention runs
+// here: 8 heads of 40 / 80 / 160 channels over 2560 / 640 tokens (the head_dim-64 flash kernel does not apply, and the
+// one-thread-per-query kernel took 97 % of that model's forward).  Not tuned: K / V of a block are staged through registers, V is
+// transposed by scalar LDS stores.
+template <int DS>
+__global__ __launch_bounds__(256) void loop_attn_mfma_kernel(const AttnK p) {
+    constexpr int NKB = 6, DPAD = DS * 32, SKP = NKB * 16;
+    constexpr int KLD = DPAD + 8, VLD = SKP + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_la[];
+    half_t* const Ks = (half_t*)smem_la;                  // [SKP][KLD]
+    half_t* const Vt = Ks + SKP * KLD;                    // [DPAD][VLD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int qt = blockIdx.x, h = blockIdx.y, i = blockIdx.z;
+    const int D = p.head_dim;
+    const int iq = p.qk_mod > 0 ? i % p.qk_mod : i;
+    const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
+    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
+    const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
+    const int q0 = qt * 64 + w * 16;
+    const int qrow = q0 + l15;
+    h8 qf[DS];
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+        const int d0 = ds * 32 + lq * 8;
+        qf[ds] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (qrow < p.Sq && d0 < D) qf[ds] = *(const h8*)(p.Q + (qbase + (long long)qrow * p.q_seq) * p.ldq + h * D + d0);
+    }
+    f4 o[DPAD / 16];
+#pragma unroll
+    for (int db = 0; db < DPAD / 16; ++db) o[db] = (f4){0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+    const float c = p.scale_log2;
+    const int dch = DPAD / 8;
+    // causal: blocks entirely above the diagonal of this query block hold nothing visible
+    const int k_end = p.causal ? min(p.Sk, qt * 64 + 64) : p.Sk;
+    for (int k0 = 0; k0 < k_end; k0 += SKP) {
+        __syncthreads();   // the previous block's fragments are read
+        for (int cidx = tid; cidx < SKP * dch; cidx += 256) {
+            const int key = cidx / dch, d0 = (cidx - key * dch) * 8;
+            h8 kv = (h8){0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+            if (k0 + key < p.Sk && d0 < D) {
+                kv = *(const h8*)(p.K + (kbase + (long long)(k0 + key) * p.kv_seq) * p.ldk + h * D + d0);
+                vv = *(const h8*)(p.V + (vbase + (long long)(k0 + key) * p.kv_seq) * p.ldv + h * D + d0);
+            }
+            *(h8*)(Ks + key * KLD + d0) = kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(d0 + e) * VLD + key] = vv[e];
+        }
+        __syncthreads();
+        f4 sc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            sc[kb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                const h8 kf = *(const h8*)(Ks + (kb * 16 + l15) * KLD + ds * 32 + lq * 8);
+                sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], sc[kb], 0, 0, 0);
+            }
+        }
+        float mb = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + kb * 16 + 4 * lq + r;
+                const bool ok = key < p.Sk && (!p.causal || key <= qrow);
+                sc[kb][r] = ok ? sc[kb][r] : -1e30f;
+                mb = fmaxf(mb, sc[kb][r]);
+            }
+        mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m, mb);
+        const float alpha = exp2f((m - m_new) * c);     // 1 when the maximum stays; 0 for the first block (m = -1e30)
+        m = m_new;
+        float lb = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = sc[kb][r] > -1e29f ? exp2f((sc[kb][r] - m) * c) : 0.f;
+                sc[kb][r] = e;
+                lb += e;
+            }
+        lb += __shfl_xor(lb, 16, 64);
+        lb += __shfl_xor(lb, 32, 64);
+        l = l * alpha + lb;
+#pragma unroll
+        for (int db = 0; db < DPAD / 16; ++db)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+#pragma unroll
+        for (int kp = 0; kp < NKB / 2; ++kp) {
+            h8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (half_t)sc[2 * kp][r];
+                pf[4 + r] = (half_t)sc[2 * kp + 1][r];
+            }
+#pragma unroll
+            for (int db = 0; db < DPAD / 16; ++db) {
+                const half_t* vr = Vt + (db * 16 + l15) * VLD + kp * 32 + 4 * lq;
+                const h4 v0 = *(const h4*)vr, v1 = *(const h4*)(vr + 16);
+                const h8 vf = (h8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[db], 0, 0, 0);
+            }
+        }
+    }
+    if (qrow < p.Sq) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        half_t* op = p.O + (obase + (long long)qrow * p.q_seq) * p.ldo + h * D;
+#pragma unroll
+        for (int db = 0; db < DPAD / 16; ++db) {
+            const int d0 = db * 16 + 4 * lq;
+            if (d0 < D) {
+                h4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[db][r] * inv);
+                *(h4*)(op + d0) = ov;
+            }
+        }
+    }
+}
+
 extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_dim, void* stream) {
     AV_CHECK(head_dim > 0 && head_dim <= 160, "attention_small: head_dim must be in 1..160");
     AttnK k;
@@ -725,6 +852,27 @@ extern "C" int anyv2v_attention_small_f16(const AnyV2VAttnDesc* d, int32_t head_
     const bool fast = !(d->flags & 1) && head_dim % 8 == 0 && ds >= 2 && ds <= 5 && nkb > 0 && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
                       d->ldv % 8 == 0 && d->ldo % 4 == 0 && av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) &&
                       (((uintptr_t)d->O) & 7) == 0 && d->heads <= 65535 && d->batch <= 65535;
+    // the same conditions with a longer key sequence: the 96-key loop kernel (online softmax)
+    const bool loop_ok = !(d->flags & 1) && head_dim % 8 == 0 && ds >= 1 && ds <= 5 && nkb == 0 && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
+                         d->ldv % 8 == 0 && d->ldo % 4 == 0 && av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) &&
+                         (((uintptr_t)d->O) & 7) == 0 && d->heads <= 65535 && d->batch <= 65535;
+    if (loop_ok) {
+        const dim3 lgrid((unsigned)((d->Sq + 63) / 64), (unsigned)d->heads, (unsigned)d->batch);
+        const int dsl = ds < 2 ? 2 : ds;
+        const size_t llds = (size_t)96 * (dsl * 32 + 8) * 2 + (size_t)(dsl * 32) * (96 + 4) * 2;
+#define AV_LA(DS_)                                                                                                            \
+    do {                                                                                                                      \
+        static bool attr_set = false;                                                                                         \
+        if (!attr_set) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)loop_attn_mfma_kernel<DS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds); \
+            attr_set = true;                                                                                                  \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((loop_attn_mfma_kernel<DS_>), lgrid, dim3(256), llds, (hipStream_t)stream, k);                     \
+    } while (0)
+        if (dsl == 2) AV_LA(2); else if (dsl == 3) AV_LA(3); else if (dsl == 4) AV_LA(4); else AV_LA(5);
+#undef AV_LA
+        return av_launch_status("loop_attn_mfma");
+    }
     if (!fast) return launch_naive(k, (hipStream_t)stream);
     const dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->heads, (unsigned)d->batch);
     const size_t lds = (size_t)(nkb * 16) * (ds * 32 + 8) * 2 + (size_t)(ds * 32) * (nkb * 16 + 4) * 2;
@@ -752,6 +900,31 @@ extern "C" int anyv2v_attention_bias_f16(const AnyV2VAttnDesc* d, int32_t head_d
     AV_CHECK(head_dim > 0 && head_dim <= 160, "attention_bias: head_dim must be in 1..160");
     AV_CHECK(bias != nullptr, "attention_bias: null bias");
     AV_CHECK(d && d->scale > 0.f, "attention_bias: scale must be positive");
+    {   // short sequences at head_dim % 8 == 0: the whole-sequence MFMA kernel with the bias added to the score fragments
+        const int ds = (head_dim + 31) / 32;
+        if (!(d->flags & 1) && head_dim % 8 == 0 && ds >= 2 && ds <= 5 && d->Sk <= 96 && d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 &&
+            d->ldo % 4 == 0 && av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) && (((uintptr_t)d->O) & 7) == 0 &&
+            d->heads <= 65535 && d->batch <= 65535 && !(d->flags & 16)) {
+            AttnK kb;
+            int rcb = fill(d, kb, head_dim);
+            if (rcb != ANYV2V_OK) return rcb;
+            kb.causal = 0;
+            const dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->heads, (unsigned)d->batch);
+            const size_t lds = (size_t)96 * (ds * 32 + 8) * 2 + (size_t)(ds * 32) * (96 + 4) * 2;
+#define AV_SB(DS_)                                                                                                                       \
+    do {                                                                                                                                 \
+        static bool attr_set = false;                                                                                                    \
+        if (!attr_set) {                                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)small_attn_mfma_kernel<DS_, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                                             \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((small_attn_mfma_kernel<DS_, 6, true>), grid, dim3(256), lds, (hipStream_t)stream, kb, bias);                \
+    } while (0)
+            if (ds == 2) AV_SB(2); else if (ds == 3) AV_SB(3); else if (ds == 4) AV_SB(4); else AV_SB(5);
+#undef AV_SB
+            return av_launch_status("small_attn_mfma<bias>");
+        }
+    }
     AttnK k;
     int rc = fill(d, k, head_dim);
     if (rc != ANYV2V_OK) return rc;

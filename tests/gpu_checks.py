@@ -848,7 +848,11 @@ def check_attention_small_mfma():
     # (head_dim 40 / 160: ConsistI2V's temporal attention at C = 320 / 1280 with 8 heads -- not multiples of 16 / five 32-column groups)
     for (B, h, S, d, causal) in [(2, 16, 257, 80, False), (3, 16, 77, 64, True), (1, 4, 200, 128, False), (2, 3, 50, 96, True),
                                  (1, 2, 288, 64, False), (3, 8, 24, 40, False), (2, 8, 77, 160, False), (5, 8, 16, 160, True),
-                                 (2, 4, 90, 56, False)]:
+                                 (2, 4, 90, 56, False),
+                                 # longer than 288 keys (or 96 at head_dim 160): the 96-key loop kernel with the online softmax -- SEINE's
+                                 # spatial attention (8 heads x 40 / 80 / 160 over 2560 / 640 / 160 tokens)
+                                 (1, 8, 2560, 40, False), (2, 8, 640, 80, False), (3, 8, 160, 160, False), (1, 2, 401, 56, True),
+                                 (2, 3, 289, 24, False), (1, 4, 1000, 128, True)]:
         H = h * d
         qkv = rnd(B * S, 3 * H, seed=S + d)
         o = torch.zeros(B * S, H, dtype=torch.float16, device=DEV)
@@ -2374,21 +2378,30 @@ def check_attention_bias_and_rotary_windows():
     """``anyv2v_attention_bias_f16`` (additive score bias [heads, Sq, Sk], frame-strided sequences, qk_mod aliasing) and
     ``anyv2v_rotary_f16`` with one window per head vs PyTorch fp32."""
     out = []
+    # (head_dim 40 / 80 / 160, 16 frames: SEINE's temporal attention at the released width -- the whole-sequence MFMA kernel with the
+    # bias added to the score fragments; head_dim 20: the one-thread-per-query kernel)
+    for (heads, D, Fr) in ((3, 40, 6), (8, 80, 16), (8, 160, 16), (2, 20, 5)):
+        B, HW = 3, 10
+        C = heads * D
+        qkv = rnd(B * Fr * HW, 3 * C, seed=D)
+        bias = torch.randn(heads, Fr, Fr, device=DEV)
+        o = torch.zeros(B * Fr * HW, C, dtype=torch.float16, device=DEV)
+        for qk_mod in (0, B * HW // 3):
+            kw = dict(batch=B * HW, heads=heads, Sq=Fr, Sk=Fr, inner=HW, q_strides=(Fr * HW, 1, HW), kv_strides=(Fr * HW, 1, HW), qk_mod=qk_mod,
+                      scale=D ** -0.5, head_dim=D, bias=bias)
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, **kw)
+            x = qkv.float().view(B, Fr, HW, 3, heads, D).permute(3, 0, 2, 4, 1, 5)      # [3][B, HW, heads, F, D]
+            q, k, v = x[0], x[1], x[2]
+            if qk_mod:
+                q, k = q[:1].expand_as(q), k[:1].expand_as(k)
+            ref = F.scaled_dot_product_attention(q, k, v, attn_mask=bias[None, None], scale=D ** -0.5)   # [B, HW, heads, F, D]
+            ref = ref.permute(0, 3, 1, 2, 4).reshape(B * Fr * HW, C)
+            out.append(_res(f"attention + score bias, temporal view, {heads} x {D}, {Fr} frames, qk_mod {qk_mod}", o, ref, KTOL))
+            o2 = torch.zeros_like(o)
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o2, naive=True, **kw)
+            out.append(_res(f"attention + score bias == one-thread-per-query kernel, {heads} x {D}, qk_mod {qk_mod}", o, o2.float(), 1.5e-3))
     B, Fr, HW, heads, D = 3, 6, 10, 3, 40
     C = heads * D
-    qkv = rnd(B * Fr * HW, 3 * C)
-    bias = torch.randn(heads, Fr, Fr, device=DEV)
-    o = torch.zeros(B * Fr * HW, C, dtype=torch.float16, device=DEV)
-    for qk_mod in (0, B * HW // 3):
-        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, batch=B * HW, heads=heads, Sq=Fr, Sk=Fr, inner=HW,
-                      q_strides=(Fr * HW, 1, HW), kv_strides=(Fr * HW, 1, HW), qk_mod=qk_mod, scale=D ** -0.5, head_dim=D, bias=bias)
-        x = qkv.float().view(B, Fr, HW, 3, heads, D).permute(3, 0, 2, 4, 1, 5)      # [3][B, HW, heads, F, D]
-        q, k, v = x[0], x[1], x[2]
-        if qk_mod:
-            q, k = q[:1].expand_as(q), k[:1].expand_as(k)
-        ref = F.scaled_dot_product_attention(q, k, v, attn_mask=bias[None, None], scale=D ** -0.5)   # [B, HW, heads, F, D]
-        ref = ref.permute(0, 3, 1, 2, 4).reshape(B * Fr * HW, C)
-        out.append(_res(f"attention + score bias, temporal view, qk_mod {qk_mod}", o, ref, KTOL))
     xr = rnd(2 * Fr * HW, C + 16)
     got = ops.rotary(xr.clone(), 8, 32, HW, Fr, windows=heads, window_stride=D)
     pos = ((torch.arange(xr.shape[0], device=DEV) // HW) % Fr).float()
