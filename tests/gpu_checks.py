@@ -2207,11 +2207,12 @@ def check_vae(full: bool = True):
         z = torch.randn(*zs, generator=g).half().float()
         m0, l0 = oracle.encode_moments(x)
         m1, l1 = native.encode_moments(x.to(DEV))
-        out.append(_res(f"vae[{name}] encode: posterior mean vs oracle", m1.cpu(), m0, 2e-2))
-        out.append(_res(f"vae[{name}] encode: posterior logvar vs oracle", l1.cpu(), l0, 2e-2))
+        # bounds = 3 x the measured error of the full-width model on an MI355X (round 4: mean 1.6e-3, logvar 1.2e-3, decode 2.3e-3)
+        out.append(_res(f"vae[{name}] encode: posterior mean vs oracle", m1.cpu(), m0, 5e-3))
+        out.append(_res(f"vae[{name}] encode: posterior logvar vs oracle", l1.cpu(), l0, 4e-3))
         d0 = oracle.decode(z)
         d1 = native.decode(z.to(DEV))
-        out.append(_res(f"vae[{name}] decode vs oracle", d1.cpu(), d0, 2e-2))
+        out.append(_res(f"vae[{name}] decode vs oracle", d1.cpu(), d0, 7e-3))
     return out
 
 
@@ -2434,7 +2435,7 @@ def check_frame_parallel(Fr=4, hw=16, tol=4e-3):
     out = []
     fp = FrameParallel()
     native, oracle, ocfg = build_pair("mini", 1234)
-    otol = 3e-2   # mini model, HIP fp16 (or the CPU emulation) vs the fp32 CPU oracle: the bound of check_unet_vs_oracle's fixed form
+    otol = 8e-3   # mini model, HIP fp16 (or the CPU emulation) vs the fp32 CPU oracle: 3 x the measured 2.0-2.4e-3 (round 4)
     for B in (1, 3):
         inp = config1_inputs(ocfg, B, Fr, hw)
         if B == 3:  # the edit loop's batch: slots 1 and 2 share latent and image latents (shared stem allowed)
@@ -2503,7 +2504,7 @@ def check_frame_parallel(Fr=4, hw=16, tol=4e-3):
                                    ddim_inv_image_latents=il[:1]).frames
         finals.append((traj[T].float().cpu(), res.float().cpu()))
         pnp_utils.clear_time(pipe)
-    out.append(_res(f"frame-parallel rank {fp.rank}: pipeline.invert {n_steps} steps vs unsharded", finals[1][0], finals[0][0], 2e-2))
+    out.append(_res(f"frame-parallel rank {fp.rank}: pipeline.invert {n_steps} steps vs unsharded", finals[1][0], finals[0][0], 6e-3))   # measured 1.5e-3
     out.append(_res(f"frame-parallel rank {fp.rank}: pipeline.sample_with_pnp {n_steps} steps vs unsharded", finals[1][1],
                     finals[0][1], 4e-2))
     native.set_frame_parallel(None)

@@ -48,6 +48,8 @@ def _run(tmp_path, device):
     for r in range(2):
         res = torch.load(tmp_path / f"fp{r}.pt")
         assert len(res) >= 5
+        for x in res:
+            print(f"{'ok  ' if x['ok'] else 'FAIL'} rank {r}: {x['name']}: {x['err']:.3e} (tol {x['tol']:.1e})")
         bad += [f"{x['name']}: {x['err']:.3e} > {x['tol']:.1e}" for x in res if not x["ok"]]
     assert not bad, "\n".join(bad)
 

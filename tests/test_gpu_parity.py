@@ -1,5 +1,7 @@
 """`-m gpu` parity tests: HIP kernels / native UNet / pipeline loops vs PyTorch fp32, the CPU oracle and the golden
 fixtures generated from the reference's own code.  All calls go through the C ABI (anyv2v_amd.ops -> ctypes)."""
+import os
+
 import pytest
 import torch
 
@@ -9,6 +11,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _assert_all(results):
+    if os.environ.get("ANYV2V_PRINT_ROWS", "0") == "1":   # every row's measured error in the log (-s), not only the failures
+        for r in results:
+            print(f"{'ok  ' if r['ok'] else 'FAIL'} {r['name']}: {r['err']:.3e} (l2 {r.get('l2', float('nan')):.3e}, tol {r['tol']:.1e})")
     bad = [f"{r['name']}: err {r['err']:.3e} (l2 {r.get('l2', float('nan')):.3e}) > tol {r['tol']:.1e}" for r in results
            if not r["ok"] and not r.get("informational")]
     assert not bad, "\n".join(bad)
