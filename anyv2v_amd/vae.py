@@ -41,13 +41,16 @@ class _Scratch:
     """GroupNorm scratch sized for the largest call of one encode / decode."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, M, rows_per_group, device, groups=32):
+        """One buffer per scratch slot (``ops.workspace_slot``): the clip pipeline encodes the next clip on one stream while it
+        decodes the current one on another."""
         need = ops.gn_scratch_floats(M, rows_per_group, groups)
-        if self.buf is None or self.buf.numel() < need or self.buf.device != device:
-            self.buf = torch.empty(need, dtype=torch.float32, device=device)
-        return self.buf
+        buf = self.bufs.get(ops.WS_SLOT)
+        if buf is None or buf.numel() < need or buf.device != device:
+            buf = self.bufs[ops.WS_SLOT] = torch.empty(need, dtype=torch.float32, device=device)
+        return buf
 
 
 class VAEResnetBlock(nn.Module):

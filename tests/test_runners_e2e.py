@@ -428,7 +428,7 @@ def _tree(root):
     return out
 
 
-def _check_pipelined_equals_serial(tmp_path, device):
+def _check_pipelined_equals_serial(tmp_path, device, native_vae=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     if device == "cpu":
@@ -438,6 +438,15 @@ def _check_pipelined_equals_serial(tmp_path, device):
     torch.set_grad_enabled(False)
     base = _make_workspace(tmp_path)
     from anyv2v_amd import run_group_anyv2v as fused
+    if native_vae:   # the real AutoencoderKL architecture (full width: 8 x downscale; random weights) on the kernels instead of the stand-in:
+        # the pipelined order then runs VAE encodes (next clip) and decodes (current clip) on two streams at once
+        from anyv2v_amd import encoders
+        synth = encoders.attach_synthetic_encoders
+
+        def attach(pipe):
+            synth(pipe)
+            encoders.attach_native_vae(pipe, random_init_seed=0)
+        fused.attach_synthetic_encoders = attach
     log = logging.getLogger("e2e")
     for tag, pipelined in (("ser", False), ("pipe", True)):
         inv, inv_list, ed, ed_list = _two_clip_job(base, tag)
@@ -472,3 +481,14 @@ def test_pipelined_fused_runner_writes_what_the_serial_one_writes(tmp_path, monk
 def test_pipelined_fused_runner_on_gpu(tmp_path):
     """The same on cuda:0: HIP graphs replayed on two streams side by side, bit-equal files."""
     _check_pipelined_equals_serial(tmp_path, "cuda")
+
+
+@pytest.mark.gpu
+def test_pipelined_fused_runner_on_gpu_with_the_native_vae(tmp_path):
+    """... and with the AutoencoderKL on the kernels: encodes of clip k + 1 and decodes of clip k overlap (per-stream GroupNorm scratch)."""
+    from anyv2v_amd import run_group_anyv2v as fused
+    saved = fused.attach_synthetic_encoders
+    try:
+        _check_pipelined_equals_serial(tmp_path, "cuda", native_vae=True)
+    finally:
+        fused.attach_synthetic_encoders = saved
