@@ -171,9 +171,12 @@ class ConditionalVideoEditingPipeline:
             from .encoders import NativeVAE
             pipe.vae = NativeVAE(state_dict=load_file(vpath))
         if os.path.isdir(os.path.join(root, "text_encoder")):
-            from .encoders import attach_native_clip_encoders
-            attach_native_clip_encoders(pipe, root)
+            from .encoders import attach_native_text_encoder
+            if not attach_native_text_encoder(pipe, root):
+                raise FileNotFoundError(f"{root}/text_encoder exists but {root}/tokenizer does not: cannot build the text encoder")
         if pipe.vae is None or pipe.text_encoder is None:
+            if os.path.isfile(wpath):
+                logger.warning(f"{root}: UNet weights found but no {'vae' if pipe.vae is None else 'text_encoder'} -- using the synthetic stand-in")
             from .encoders import SyntheticTextEncoder, SyntheticVAE
             pipe.vae = pipe.vae or SyntheticVAE()
             pipe.text_encoder = pipe.text_encoder or SyntheticTextEncoder(dim=int(_first(cfg["cross_attention_dim"])))

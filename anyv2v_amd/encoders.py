@@ -251,6 +251,21 @@ def _load_tower_files(folder: str):
     raise FileNotFoundError(f"no weights file in {folder}")
 
 
+def attach_native_text_encoder(pipe, root: str) -> bool:
+    """``<root>/text_encoder`` + ``<root>/tokenizer`` alone (Stable-Diffusion-style checkpoints have no image encoder: the ConsistI2V
+    and SEINE backends).  Returns True when attached."""
+    import os
+    from .clip import CLIPTextTower, CLIPTowerConfig
+    te, tk = os.path.join(root, "text_encoder"), os.path.join(root, "tokenizer")
+    if not (os.path.isdir(te) and os.path.isdir(tk)):
+        return False
+    from transformers import CLIPTokenizer
+    pipe.tokenizer = CLIPTokenizer.from_pretrained(tk)
+    tcfg, tsd = _load_tower_files(te)
+    pipe.text_encoder = NativeTextEncoder(CLIPTextTower(CLIPTowerConfig.from_hf(tcfg, "text"), tsd), pipe.tokenizer)
+    return True
+
+
 def attach_native_clip_encoders(pipe, root: str):
     """Load ``<root>/text_encoder``, ``<root>/tokenizer``, ``<root>/image_encoder`` (the sub-folders of the
     ``ali-vilab/i2vgen-xl`` checkpoint) onto the native towers when they exist locally.  Returns True when attached."""

@@ -117,14 +117,15 @@ def build_components(config, device, random_init_seed=None):
         vae = SyntheticVAE()
     text = None
     if os.path.isdir(os.path.join(sd_path, "text_encoder")):
-        holder = type("H", (), {})()
-        from .encoders import attach_native_clip_encoders
-        try:
-            attach_native_clip_encoders(holder, sd_path)
-            text = holder.text_encoder
-        except Exception as e:   # (SD 1.4 ships no image encoder: fall back below only if the text tower itself failed)
-            logger.warning(f"native CLIP text tower not loaded from {sd_path}: {e}")
+        import types
+        from .encoders import attach_native_text_encoder
+        holder = types.SimpleNamespace()
+        if not attach_native_text_encoder(holder, sd_path):
+            raise FileNotFoundError(f"{sd_path}/text_encoder exists but {sd_path}/tokenizer does not: cannot build the text encoder")
+        text = holder.text_encoder.to(device)
     if text is None:
+        if os.path.isfile(ckpt):
+            logger.warning(f"{ckpt}: UNet weights found but no text encoder under {sd_path!r} -- using the synthetic stand-in")
         text = SyntheticTextEncoder(dim=int(cfg["cross_attention_dim"]))
     return unet, vae, text
 

@@ -625,3 +625,42 @@ def test_fused_feed_forward_packing_and_dispatch(monkeypatch):
     wide.net[0].pack()
     wide.pack()
     assert wide._w2s is None
+
+
+def test_text_only_checkpoint_folders_get_the_native_text_tower(cpu_ops, tmp_path, monkeypatch):
+    """Stable-Diffusion-style checkpoints (ConsistI2V, SEINE's ``sd_path``) have ``text_encoder`` + ``tokenizer`` and no image encoder:
+    ``attach_native_text_encoder`` builds the native tower from them (``attach_native_clip_encoders`` would decline and the pipelines
+    used to fall back to the synthetic stand-in without a word)."""
+    transformers = pytest.importorskip("transformers")
+    import types
+
+    from safetensors.torch import save_file
+
+    from anyv2v_amd.encoders import NativeTextEncoder, attach_native_clip_encoders, attach_native_text_encoder
+    from hf_clip_reference import HFTextEncoder
+    tm, _vm, tcfg, _vcfg = _tiny_clip_pair(transformers)
+    d = tmp_path / "text_encoder"
+    d.mkdir()
+    (d / "config.json").write_text(tcfg.to_json_string())
+    save_file({k: v.contiguous() for k, v in tm.state_dict().items()}, str(d / "model.safetensors"))
+    holder = types.SimpleNamespace()
+    assert not attach_native_text_encoder(holder, str(tmp_path))          # no tokenizer folder yet
+    (tmp_path / "tokenizer").mkdir()
+
+    class Tok:
+        model_max_length = 16
+
+        def __call__(self, prompts, padding, max_length, truncation, return_tensors):
+            ids = torch.zeros(len(prompts), max_length, dtype=torch.long)
+            for i, p in enumerate(prompts):
+                t = [(ord(c) % 90) + 3 for c in p][: max_length - 1]
+                ids[i, : len(t)] = torch.tensor(t, dtype=torch.long)
+                ids[i, len(t)] = 2
+            return type("O", (), {"input_ids": ids})
+    monkeypatch.setattr(transformers.CLIPTokenizer, "from_pretrained", classmethod(lambda cls, path, **kw: Tok()))
+    assert attach_native_text_encoder(holder, str(tmp_path)) and isinstance(holder.text_encoder, NativeTextEncoder)
+    assert not attach_native_clip_encoders(types.SimpleNamespace(), str(tmp_path))   # (needs the image encoder too)
+    dev = torch.device("cpu")
+    a = holder.text_encoder.encode(["a robot", ""], dev, clip_skip=None)
+    b = HFTextEncoder(tm, Tok()).encode(["a robot", ""], dev, clip_skip=None)
+    assert a.shape == b.shape and (a.float() - b.float()).abs().max() <= 8e-3 * float(b.float().abs().max())
