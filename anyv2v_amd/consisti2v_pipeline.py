@@ -250,7 +250,10 @@ class ConditionalVideoEditingPipeline:
         return te
 
     def _first_frame_latent(self, path_or_image, height, width, crop, device):
-        """One first-frame image -> sampled, scaled VAE latent [1, 4, h, w] (``:796-833``)."""
+        """One first-frame image (path, PIL image, or -- ``first_frames`` -- an already pre-processed [1, 3, H, W] tensor) -> sampled,
+        scaled VAE latent [1, 4, h, w] (``:796-833``)."""
+        if torch.is_tensor(path_or_image):
+            return self.vae.encode_pixels(path_or_image.float(), device)
         img = path_or_image if isinstance(path_or_image, Image.Image) else Image.open(path_or_image).convert("RGB")
         return self.vae.encode_pixels(frame_to_pixels(img, height, width, crop), device)
 
@@ -302,8 +305,8 @@ class ConditionalVideoEditingPipeline:
         if use_frameinit or camera_motion is not None or guidance_rescale > 0.0 or eta != 0.0 or num_videos_per_prompt != 1:
             raise NotImplementedError("use_frameinit / camera_motion / guidance_rescale / eta / num_videos_per_prompt are not built "
                                       "(the AnyV2V runners leave them off)")
-        if first_frames is not None:
-            raise NotImplementedError("pass the first frame as a path or PIL image (first_frame_paths)")
+        if first_frames is not None and (not torch.is_tensor(first_frames) or first_frames.dim() != 4 or first_frames.shape[0] != 1):
+            raise NotImplementedError("first_frames: one pre-processed frame [1, 3, H, W] in [-1, 1] per call")
         if latents is not None and latents.shape[0] != 1:
             raise NotImplementedError(f"one clip per call: latents batch {latents.shape[0]}")
         return height, width
@@ -321,7 +324,7 @@ class ConditionalVideoEditingPipeline:
         eng = self._step_graphs(nb, latents, text_embeddings, frame_stride)
         eng.ehs.copy_(text_embeddings)
         eng.ff.copy_(ff_input)
-        for t in timesteps:
+        for step_i, t in enumerate(timesteps):
             t = int(t)
             if source is not None:
                 eng.x[0].copy_(source(t)[0], non_blocking=True)
@@ -333,7 +336,7 @@ class ConditionalVideoEditingPipeline:
             latents = ops.guided_step(e, latents, self.scheduler.coefficients(t), b_unc=branches[0], b_img=branches[1], b_txt=branches[2],
                                       g_img=g_img, g_txt=g_txt, prediction=pred)
             if on_step is not None:
-                on_step(t, latents)
+                on_step(step_i, t, latents)
         return latents
 
     def _step_graphs(self, nb, latents, ehs, frame_stride):
@@ -348,6 +351,13 @@ class ConditionalVideoEditingPipeline:
         while len(self._engines) > 3:  # (inversion / reconstruction, CFG sampling, PnP edit: every engine pins a graph pool)
             self._engines.pop(next(iter(self._engines)))
         return eng
+
+    @staticmethod
+    def _callback(callback, callback_steps):
+        """``callback(i, t, latents)`` every ``callback_steps`` steps (``pipeline_video_editing.py:697-700``)."""
+        if callback is None:
+            return None
+        return lambda i, t, x: callback(i, t, x) if i % (callback_steps or 1) == 0 else None
 
     @staticmethod
     def _branches(mode, offset=0):
@@ -391,9 +401,10 @@ class ConditionalVideoEditingPipeline:
         mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
         c2.clear_time(self)
         text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, mode, negative_prompt)
-        if first_frame_paths is None:
+        if first_frame_paths is None and first_frames is None:
             raise NotImplementedError("sampling without a first frame (first_frame_condition_mode 'none')")
-        clean = self._first_frame_latent(self._one(first_frame_paths, "first frames"), height, width, False, device)
+        clean = self._first_frame_latent(first_frames if first_frame_paths is None else self._one(first_frame_paths, "first frames"),
+                                         height, width, False, device)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]
         latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
@@ -402,7 +413,7 @@ class ConditionalVideoEditingPipeline:
         ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
         latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode),
                                 guidance_scale_img, guidance_scale_txt,
-                                on_step=(lambda t, x: callback(t, t, x)) if callback is not None else None)
+                                on_step=self._callback(callback, callback_steps))
         return self._finish(latents, clean, output_type, return_dict)
 
     # ------------------------------------------------------------------ ``invert`` (:715-968)
@@ -423,9 +434,10 @@ class ConditionalVideoEditingPipeline:
         mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
         c2.clear_time(self)
         text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, mode, negative_prompt)
-        if first_frame_paths is None:
+        if first_frame_paths is None and first_frames is None:
             raise NotImplementedError("inversion without a first frame (first_frame_condition_mode 'none')")
-        clean = self._first_frame_latent(self._one(first_frame_paths, "first frames"), height, width, True, device)
+        clean = self._first_frame_latent(first_frames if first_frame_paths is None else self._one(first_frame_paths, "first frames"),
+                                         height, width, True, device)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
                                        noise_sampling_method, noise_alpha)
@@ -434,10 +446,12 @@ class ConditionalVideoEditingPipeline:
         traj = LatentTrajectory()
         first = clean.unsqueeze(2).to(torch.float16)
 
-        def keep(t, x):
+        cb = self._callback(callback, callback_steps)
+
+        def keep(i, t, x):
             traj[t] = torch.cat([first, x], dim=2)
-            if callback is not None:
-                callback(t, t, x)
+            if cb is not None:
+                cb(i, t, x)
         latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode),
                                 guidance_scale_img, guidance_scale_txt, on_step=keep)
         ts = [int(t) for t in self.scheduler.timesteps]
@@ -499,7 +513,7 @@ class ConditionalVideoEditingPipeline:
         try:
             latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode, 1),
                                     guidance_scale_img, guidance_scale_txt, source=source,
-                                    on_step=(lambda t, x: callback(t, t, x)) if callback is not None else None)
+                                    on_step=self._callback(callback, callback_steps))
         finally:
             c2.clear_time(self)
         return self._finish(latents, clean, output_type, return_dict)

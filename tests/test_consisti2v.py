@@ -315,3 +315,31 @@ def test_full_width_unet_fixture_is_what_the_reference_code_produces():
     fx = torch.load(os.path.join(HERE, "golden", "consisti2v_unet_full.pt"))
     for k in ("full_nohook", "full_hook_t981"):
         assert float((out[k] - fx[k].float()).abs().max()) <= 2e-3 * float(fx[k].float().abs().max()), k
+
+
+def test_consisti2v_pipeline_callbacks_and_tensor_first_frames(monkeypatch):
+    """``callback(i, t, latents)`` every ``callback_steps`` steps (``pipeline_video_editing.py:697-700``) and ``first_frames`` (an already
+    pre-processed frame tensor) instead of ``first_frame_paths`` (``:816-826``)."""
+    emu.install(monkeypatch)
+    from anyv2v_amd import consisti2v as c2
+    from anyv2v_amd.consisti2v_pipeline import ConditionalVideoEditingPipeline, frame_to_pixels
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMInverseScheduler
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    j = spec.PIPE_JOB
+    frames, _ = spec.pipeline_frames()
+    tok = rp.ToyTokenizer()
+    pipe = ConditionalVideoEditingPipeline(vae=spec.ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(48), tok), tokenizer=tok,
+                                           unet=spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)),
+                                           scheduler=DDIMInverseScheduler(**CONSISTI2V_SCHEDULER_CONFIG))
+    lat0 = pipe.encode_vae_video(frames, pipe.device, height=j["height"], width=j["width"])
+    seen = []
+    kw = dict(prompt="", height=j["height"], width=j["width"], video_length=j["frames"], num_inference_steps=4, guidance_scale_txt=1.0,
+              guidance_scale_img=1.0, negative_prompt="", frame_stride=3, latents=lat0, output_type="latent")
+    a = pipe.invert(first_frame_paths=frames[0], callback=lambda i, t, x: seen.append((i, int(t), tuple(x.shape))), callback_steps=2, **kw).videos
+    assert [(i, t) for i, t, _ in seen] == [(0, 1), (2, 501)] and seen[0][2] == (1, 4, j["frames"] - 1, j["height"] // 8, j["width"] // 8)
+    b = pipe.invert(first_frames=frame_to_pixels(frames[0], j["height"], j["width"], True), **kw).videos
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        pipe.invert(first_frame_paths=frames[0], first_frames=torch.zeros(1, 3, j["height"], j["width"]), **kw)
