@@ -37,6 +37,25 @@ def shard_entries(entries: Sequence, rank: int, world: int) -> List:
     return [e for i, e in enumerate(active) if i % world == rank]
 
 
+def shard_by_clip(inv_entries: Sequence, edit_entries: Sequence, rank: int, world: int):
+    """Clip-wise dealing for the fused runner: the active inversion entries round-robin, and every edit entry to the rank that inverts
+    its clip (``video_name``), so that a rank holds whole clips and can pipeline them (``run_group_anyv2v.main_pipelined``); edits of a
+    clip nobody inverts here are dealt round-robin among themselves.  Returns (this rank's inversion entries, its edit entries)."""
+    inv = [e for e in inv_entries if e.get("active", True) is not False]
+    owner = {}
+    for i, e in enumerate(inv):
+        owner.setdefault(e.get("video_name"), i % world)
+    edits = [e for e in edit_entries if e.get("active", True) is not False]
+    mine, loose = [], 0
+    for e in edits:
+        r = owner.get(e.get("video_name"))
+        if r is None:
+            r, loose = loose % world, loose + 1
+        if r == rank:
+            mine.append(e)
+    return [e for i, e in enumerate(inv) if i % world == rank], mine
+
+
 def seed_for_entry(base_seed: int, entry_index: int) -> int:
     """The reference seeds once per process and draws per entry from the global RNG (``run_group_pnp_edit.py:124,213``),
     which ties results to the processing order.  Sharded runs re-seed per entry so that any rank reproduces the

@@ -27,7 +27,7 @@ from .pipeline import I2VGenXLPipeline
 from .utils import seed_everything
 
 
-def main_pipelined(inv_template, inv_list, edit_template, edit_list, device, logger, pipe):
+def main_pipelined(inv_template, inv_list, edit_template, edit_list, device, logger, pipe, shares=None):
     """One GPU, several clips: clip k + 1 is INVERTED while clip k is EDITED.  The two loops have no data in common (the edit reads
     the trajectory of its own clip, complete before it starts), so they run on two HIP streams -- stage 1 on ``pipe``, stage 2 on
     ``pipe.sibling()`` (same weights; own scheduler slot, step engines, graphs and split-K scratch) -- and the launches that do not
@@ -49,9 +49,10 @@ def main_pipelined(inv_template, inv_list, edit_template, edit_list, device, log
     stream_b = torch.cuda.Stream(device) if cuda else None
     on = (lambda st: torch.cuda.stream(st)) if cuda else (lambda st: contextlib.nullcontext())
     trajectories = {}
-    s1 = stage1.Stage1(inv_template, inv_list, device, logger, pipe=pipe, trajectories=trajectories)
+    inv_mine, edit_mine = shares if shares is not None else (None, None)
+    s1 = stage1.Stage1(inv_template, inv_list, device, logger, pipe=pipe, trajectories=trajectories, my_entries=inv_mine)
     pipe_b = pipe.sibling(ws_slot=1)
-    s2 = stage2.Stage2(edit_template, edit_list, device, logger, pipe=pipe_b, trajectories=trajectories)
+    s2 = stage2.Stage2(edit_template, edit_list, device, logger, pipe=pipe_b, trajectories=trajectories, my_entries=edit_mine)
     if cuda:
         stream_a.wait_stream(torch.cuda.current_stream(device))
         stream_b.wait_stream(torch.cuda.current_stream(device))
@@ -135,6 +136,13 @@ def main(inv_template, inv_list, edit_template, edit_list, device, logger, synth
         pipelined = os.environ.get("ANYV2V_PIPELINED", "1") == "1"
     if pipelined and world == 1:
         return main_pipelined(inv_template, inv_list, edit_template, edit_list, device, logger, pipe)
+    n_clips = len({e.get("video_name") for e in inv_list if e.get("active", True) is not False})
+    if pipelined and world > 1 and not frame_parallel and n_clips >= world:
+        # enough clips for every rank: deal whole clips (an inversion and its edits) instead of the entries of each stage, and let
+        # every rank pipeline its own clips; no rank waits for another's files, so the barrier between the stages is not needed
+        from .parallel import shard_by_clip
+        return main_pipelined(inv_template, inv_list, edit_template, edit_list, device, logger, pipe,
+                              shares=shard_by_clip(inv_list, edit_list, rank, world))
     trajectories = {}
     seed_everything(inv_template.seed)  # each stage starts from its template's seed, as two separate processes would
     stage1.main(inv_template, inv_list, device, logger, synthetic_encoders, random_init_seed, frame_parallel, pipe=pipe,

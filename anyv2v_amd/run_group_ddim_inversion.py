@@ -83,8 +83,9 @@ class Stage1:
     (files, reconstruction).  ``main`` simply exhausts them one after the other."""
 
     def __init__(self, template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None,
-                 frame_parallel=False, pipe=None, trajectories=None):
+                 frame_parallel=False, pipe=None, trajectories=None, my_entries=None):
         self.template_config, self.configs_list, self.device, self.logger = template_config, configs_list, device, logger
+        self._my_entries = my_entries     # this rank's share when the caller deals the entries itself (clip-wise dealing)
         self.trajectories = trajectories
         self.rank, self.local_rank, self.world = init_distributed()
         # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
@@ -111,7 +112,8 @@ class Stage1:
                 logger.info(f"Skipping config_entry: {config_entry}")
 
     def entries(self):
-        for config_entry in shard_entries(self.configs_list, self.e_rank, self.e_world):
+        mine = self._my_entries if self._my_entries is not None else shard_entries(self.configs_list, self.e_rank, self.e_world)
+        for config_entry in mine:
             yield self._entry(config_entry)
 
     def _entry(self, config_entry):

@@ -59,8 +59,9 @@ class Stage2:
     inversion), ``finish`` (the cross-rank gather).  ``main`` runs them in list order."""
 
     def __init__(self, template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None,
-                 frame_parallel=False, pipe=None, trajectories=None):
+                 frame_parallel=False, pipe=None, trajectories=None, my_entries=None):
         self.template_config, self.configs_list, self.device, self.logger = template_config, configs_list, device, logger
+        self._my_entries = my_entries     # this rank's share when the caller deals the entries itself (clip-wise dealing)
         self.trajectories = trajectories
         self.rank, self.local_rank, self.world = init_distributed()
         # --frame_parallel (long clips, SURVEY.md 8(f) F3): every rank works on EVERY entry, the clip's frames sharded over
@@ -83,7 +84,7 @@ class Stage2:
             if config_entry["active"] is False:
                 logger.info(f"Skipping config_entry: {config_entry}")
         self.my_latents, self.lat_shape = {}, None
-        self.my_entries = shard_entries(configs_list, self.e_rank, self.e_world)
+        self.my_entries = self._my_entries if self._my_entries is not None else shard_entries(configs_list, self.e_rank, self.e_world)
         # Several edits of one clip on this rank (the demo group config: 8 edits of one clip): keep the source branch's injected features
         # in HBM after the first edit, so that the further ones run [negative, editing] only (pipeline.SourceFeatureCache; exact).
         # ANYV2V_SOURCE_CACHE=0 switches it off.

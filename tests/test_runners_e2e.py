@@ -492,3 +492,43 @@ def test_pipelined_fused_runner_on_gpu_with_the_native_vae(tmp_path):
         _check_pipelined_equals_serial(tmp_path, "cuda", native_vae=True)
     finally:
         fused.attach_synthetic_encoders = saved
+
+
+def _clip_shard_worker(rank, world, port, base, tag, pipelined):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["ANYV2V_SOURCE_CACHE"] = "0"   # (see test_pipelined_fused_runner_writes_what_the_serial_one_writes)
+    torch.set_num_threads(2)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_emulation as emu
+    emu.install()
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    from anyv2v_amd import run_group_anyv2v as fused
+    inv, inv_list, ed, ed_list = _two_clip_job(base, tag)
+    fused.main(inv, inv_list, ed, ed_list, torch.device("cpu"), logging.getLogger("e2e"), synthetic_encoders=True, pipelined=pipelined)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_fused_runner_world2_deals_whole_clips_and_pipelines_them(tmp_path):
+    """Under torchrun with at least as many clips as ranks the fused runner deals whole clips (an inversion + its edits) to the ranks and
+    every rank pipelines its own; per-entry seeding makes the files equal to the stage-wise dealing's, and rank 0 gathers every
+    entry's latents in entry order either way."""
+    import filecmp
+    import torch.multiprocessing as mp
+    base = _make_workspace(tmp_path)
+    for tag, pipelined in (("w2s", False), ("w2p", True)):
+        mp.spawn(_clip_shard_worker, args=(2, _free_port(), base, tag, pipelined), nprocs=2, join=True)
+        os.replace(os.path.join(base, "gathered_latents.pt"), os.path.join(base, f"gathered_{tag}.pt"))
+    a, b = torch.load(os.path.join(base, "gathered_w2s.pt")), torch.load(os.path.join(base, "gathered_w2p.pt"))
+    assert tuple(a.shape) == (3, 4, N_FRAMES, SIZE // 8, SIZE // 8) and torch.equal(a, b)
+    for top in ("inversions", os.path.join("Results", "Prompt-Based-Editing")):
+        x, y = _tree(os.path.join(base, top, "mini-w2s")), _tree(os.path.join(base, top, "mini-w2p"))
+        assert sorted(x) == sorted(y) and len(x) > 0
+        for rel in x:
+            if rel.endswith(".pt"):
+                assert torch.equal(torch.load(x[rel]), torch.load(y[rel])), rel
+            else:
+                assert filecmp.cmp(x[rel], y[rel], shallow=False), rel
