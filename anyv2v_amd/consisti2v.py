@@ -1,11 +1,10 @@
-"""The ConsistI2V hook family: the decoder blocks that carry every PnP hook site of
-``consisti2v/pnp_utils.py:19-345`` -- ``VideoLDMCrossAttnUpBlock`` (``consisti2v/consisti2v/models/videoldm_unet_blocks.py:548-745``)
-with its ``ResnetBlock2D`` / ``TemporalResnetBlock`` / spatial and temporal ``Transformer2DConditionModel`` layers -- on the HIP
-kernels, plus the four registration functions with the reference's names and arguments.
-
-Scope: the blocks ``model.unet.up_blocks[1..3]`` the hooks index, not the whole ``VideoLDMUNet3DConditionModel`` (its released
-``unet/config.json`` is not in the reference tree; the encoder half, mid block and conditioning embeddings hold no hook site).
-Module tree and state-dict keys are the reference's, so a block of a real checkpoint loads unchanged.
+"""The ConsistI2V backend's model on the HIP kernels: the whole ``VideoLDMUNet3DConditionModel``
+(``consisti2v/consisti2v/models/videoldm_unet.py:68-1064``) -- encoder / mid / decoder blocks of
+``videoldm_unet_blocks.py:225-1158`` with their ``ResnetBlock2D`` / ``TemporalResnetBlock`` / spatial and temporal
+``Transformer2DConditionModel`` layers, time and frame-stride embeddings, first-frame conditioning by concatenation -- plus the four
+hook registration functions of ``consisti2v/pnp_utils.py:19-345`` with the reference's names and arguments (the hook sites are all in
+``unet.up_blocks[1..3]``).  Module tree and state-dict keys are the reference's, so a real checkpoint loads unchanged; the pipeline and
+the runners around it are ``anyv2v_amd/consisti2v_pipeline.py`` and ``consisti2v_run_*.py``.
 
 What differs from the I2VGen-XL family (``anyv2v_amd/unet.py``) and how it is computed here, all on the token layout
 ``X[(b f)(h w), C]``:
@@ -25,7 +24,8 @@ What differs from the I2VGen-XL family (``anyv2v_amd/unet.py``) and how it is co
   x + (1 - alpha) f(x); (1 - alpha) is folded into the last projection's weights at pack time.
 * GroupNorm of the temporal layers is the 4-D one (per frame), eps 1e-6.
 
-Performance is not tuned for this family (temporal attention at head_dim C / 8 runs on the generic small-attention kernels).
+Temporal attention has head_dim C / 8 = 40 / 80 / 160: the whole-sequence MFMA kernel (``small_attn_mfma_kernel``, 16 + 8 keys).
+Not tuned beyond that: no HIP-graph gain for this family (measured), no source-branch shortcuts.
 """
 from __future__ import annotations
 

@@ -1,11 +1,12 @@
-"""The SEINE hook family: the decoder blocks that carry the PnP hook sites of ``seine/pnp_utils.py:121-458`` --
-``CrossAttnUpBlock3D`` (``seine/models/unet_blocks.py:444-575``: ``ResnetBlock3D`` + ``Transformer3DModel`` per layer,
-``Upsample3D``) -- on the HIP kernels, plus the five registration functions with the reference's names and arguments
-(``register_time``, ``register_conv_injection``, ``register_spatial_attention_pnp``, ``register_cross_attention_pnp`` -- a hook
-I2VGen-XL has no analogue of -- and ``register_temp_attention_pnp``).
+"""The SEINE backend's model on the HIP kernels: the whole ``UNet3DConditionModel`` (``seine/models/unet.py:98-560``:
+``CrossAttnDownBlock3D`` / ``DownBlock3D`` / ``UNetMidBlock3DCrossAttn`` / ``UpBlock3D`` / ``CrossAttnUpBlock3D`` of
+``seine/models/unet_blocks.py``, each ``ResnetBlock3D`` + ``Transformer3DModel``) plus the five registration functions of
+``seine/pnp_utils.py:121-458`` with the reference's names and arguments (``register_time``, ``register_conv_injection``,
+``register_spatial_attention_pnp``, ``register_cross_attention_pnp`` -- a hook I2VGen-XL has no analogue of -- and
+``register_temp_attention_pnp``).  Module tree and state-dict keys are the reference's (``seine.pt``'s ``ema`` dict loads strictly); the
+runner classes and CLIs around it are ``anyv2v_amd/seine_pipeline.py`` and ``seine_run_*.py``.
 
-Scope as for ConsistI2V (``anyv2v_amd/consisti2v.py``): the block type of ``unet.up_blocks[1..3]``; module tree and state-dict keys
-are the reference's.  What this family adds over I2VGen-XL, on the token layout ``X[(b f)(h w), C]``:
+What this family adds over I2VGen-XL, on the token layout ``X[(b f)(h w), C]``:
 
 * one transformer block holds spatial self-attention, text cross-attention AND temporal self-attention (``attn1`` / ``attn2`` /
   ``attn_temp``, ``seine/models/attention.py:439-647``), the temporal one on the frame-strided view of the same tokens;
