@@ -16,8 +16,8 @@ Kept from the reference because a drop-in must produce the same numbers:
 * frame 0 of the start latents is the "noisy first frame" of the image-unconditional branch and otherwise dropped (``:1478-1480``):
   the UNet denoises ``video_length - 1`` frames and sees the clean first-frame latent as frame 0.
 
-Not built (the AnyV2V runners never enable them): ``use_frameinit`` (FFT noise re-initialisation, ``frameinit_utils.py``),
-``camera_motion``, ``guidance_rescale > 0``, ``eta > 0``, several clips per call, PnP with image guidance or without text guidance
+``use_frameinit`` (FFT noise re-initialisation, ``frameinit_utils.py``) is built (``init_filter``, host-side FFT once per clip).
+Not built (the AnyV2V runners never enable them): ``camera_motion``, ``guidance_rescale > 0``, ``eta > 0``, several clips per call, PnP with image guidance or without text guidance
 (the reference's hooks split the batch in three: ``consisti2v/pnp_utils.py:96,188,296``).
 """
 from __future__ import annotations
@@ -51,6 +51,48 @@ CONSISTI2V_UNET_CONFIG = dict(
 class AnimationPipelineOutput:
     def __init__(self, videos):
         self.videos = videos
+
+
+# ------------------------------------------------------------------------------------------------- FrameInit (frameinit_utils.py)
+def get_freq_filter(shape, device, filter_type, n, d_s, d_t):
+    """``consisti2v/consisti2v/utils/frameinit_utils.py:36-141``: low-pass mask over the (T, H, W) frequency volume, centred
+    (``fftshift`` order).  ``d^2 = ((d_s / d_t)(2t / T - 1))^2 + (2h / H - 1)^2 + (2w / W - 1)^2``; "gaussian": exp(-d^2 / (2 d_s^2)),
+    "butterworth": 1 / (1 + (d^2 / d_s^2)^n), "ideal": d^2 <= 2 d_s (the reference compares with ``d_s*2``, kept), "box": a centred box
+    of half-widths round(T // 2 * d_t), round(H // 2 * d_s) (the reference's function builds this mask and forgets to return it)."""
+    T, H, W = shape[-3], shape[-2], shape[-1]
+    mask = torch.zeros(shape)
+    if d_s == 0 or d_t == 0:
+        return mask.to(device)
+    if filter_type == "box":
+        ts, tt = round(int(H // 2) * d_s), round(T // 2 * d_t)
+        cf, cr, cc = T // 2, H // 2, W // 2
+        mask[..., cf - tt:cf + tt, cr - ts:cr + ts, cc - ts:cc + ts] = 1.0
+        return mask.to(device)
+    t = ((d_s / d_t) * (2 * torch.arange(T, dtype=torch.float64) / T - 1)) ** 2
+    h = (2 * torch.arange(H, dtype=torch.float64) / H - 1) ** 2
+    w = (2 * torch.arange(W, dtype=torch.float64) / W - 1) ** 2
+    d2 = t[:, None, None] + h[None, :, None] + w[None, None, :]
+    if filter_type == "gaussian":
+        vol = torch.exp(-1 / (2 * d_s ** 2) * d2)
+    elif filter_type == "butterworth":
+        vol = 1 / (1 + (d2 / d_s ** 2) ** n)
+    elif filter_type == "ideal":
+        vol = (d2 <= d_s * 2).double()
+    else:
+        raise NotImplementedError(filter_type)
+    return (mask + vol.float()).to(device)
+
+
+def freq_mix_3d(x, noise, LPF):
+    """``frameinit_utils.py:7-33``: low frequencies of the diffused first-frame video, high frequencies of the noise.  Once per clip on a
+    [1, 4, F, h, w] tensor: computed on the host."""
+    dev = x.device
+    x, noise, LPF = x.float().cpu(), noise.float().cpu(), LPF.float().cpu()
+    dims = (-3, -2, -1)
+    xf = torch.fft.fftshift(torch.fft.fftn(x, dim=dims), dim=dims)
+    nf = torch.fft.fftshift(torch.fft.fftn(noise, dim=dims), dim=dims)
+    mixed = xf * LPF + nf * (1 - LPF)
+    return torch.fft.ifftn(torch.fft.ifftshift(mixed, dim=dims), dim=dims).real.to(dev)
 
 
 # ------------------------------------------------------------------------------------------------- pre-processing
@@ -205,6 +247,24 @@ class ConditionalVideoEditingPipeline:
     def progress_bar(self, iterable=None, total=None):
         return iterable
 
+    @torch.no_grad()
+    def init_filter(self, video_length, height, width, filter_params):
+        """``pipeline_video_editing.py:208-227``."""
+        shape = [1, self.unet.config.in_channels, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor]
+        self.freq_filter = get_freq_filter(shape, device=self._execution_device, filter_type=filter_params.method,
+                                           n=filter_params.n if filter_params.method == "butterworth" else None,
+                                           d_s=filter_params.d_s, d_t=filter_params.d_t)
+
+    def _frameinit(self, latents, clean, video_length, noise_level):
+        """``:619-633``: the start noise's low frequencies replaced by those of the first frame, repeated over the clip and diffused to
+        ``noise_level``."""
+        if self.freq_filter is None:
+            raise ValueError("use_frameinit needs init_filter(video_length, height, width, filter_params) first")
+        static = clean.unsqueeze(2).repeat(1, 1, video_length, 1, 1)
+        t = torch.full((latents.shape[0],), int(noise_level)).long()
+        z_T = self.scheduler.add_noise(original_samples=static.to(latents.device), noise=latents, timesteps=t)
+        return freq_mix_3d(z_T.to(torch.float32), latents, LPF=self.freq_filter).to(latents.dtype)
+
     # ------------------------------------------------------------------ checks / encoders
     def check_inputs(self, prompt, height, width, callback_steps=1, first_frame_paths=None):
         """``pipeline_video_editing.py:390-406``."""
@@ -302,8 +362,8 @@ class ConditionalVideoEditingPipeline:
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps, first_frame_paths)
-        if use_frameinit or camera_motion is not None or guidance_rescale > 0.0 or eta != 0.0 or num_videos_per_prompt != 1:
-            raise NotImplementedError("use_frameinit / camera_motion / guidance_rescale / eta / num_videos_per_prompt are not built "
+        if camera_motion is not None or guidance_rescale > 0.0 or eta != 0.0 or num_videos_per_prompt != 1:
+            raise NotImplementedError("camera_motion / guidance_rescale / eta / num_videos_per_prompt are not built "
                                       "(the AnyV2V runners leave them off)")
         if first_frames is not None and (not torch.is_tensor(first_frames) or first_frames.dim() != 4 or first_frames.shape[0] != 1):
             raise NotImplementedError("first_frames: one pre-processed frame [1, 3, H, W] in [-1, 1] per call")
@@ -409,6 +469,8 @@ class ConditionalVideoEditingPipeline:
         self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]
         latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
                                        noise_sampling_method, noise_alpha)
+        if use_frameinit:
+            latents = self._frameinit(latents, clean, video_length, frameinit_noise_level)
         noisy, latents = latents[:, :, 0], latents[:, :, 1:]
         ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
         latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode),
@@ -441,6 +503,8 @@ class ConditionalVideoEditingPipeline:
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
                                        noise_sampling_method, noise_alpha)
+        if use_frameinit:
+            latents = self._frameinit(latents, clean, video_length, frameinit_noise_level)
         noisy, latents = latents[:, :, 0], latents[:, :, 1:]
         ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
         traj = LatentTrajectory()
@@ -505,6 +569,8 @@ class ConditionalVideoEditingPipeline:
         self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]
         latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
                                        noise_sampling_method, noise_alpha)
+        if use_frameinit:
+            latents = self._frameinit(latents, clean, video_length, frameinit_noise_level)
         noisy, latents = latents[:, :, 0], latents[:, :, 1:]
         ff = torch.cat([src_first] + self._ff_rows(mode, clean, noisy)).unsqueeze(2)
 

@@ -116,6 +116,13 @@ class _DDIMBase:
     def scale_model_input(self, sample, timestep=None):
         return sample
 
+    def add_noise(self, original_samples, noise, timesteps):
+        """``sqrt(a_t) x + sqrt(1 - a_t) noise`` per batch element (diffusers' ``add_noise``; the FrameInit path of the ConsistI2V
+        pipeline, ``pipeline_video_editing.py:622-631``).  Once per clip, on whatever device the tensors live."""
+        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=torch.float32)[timesteps.to(original_samples.device).long()]
+        shape = (-1,) + (1,) * (original_samples.dim() - 1)
+        return (ac.sqrt().view(shape) * original_samples.float() + (1 - ac).sqrt().view(shape) * noise.float()).to(original_samples.dtype)
+
     def _ratio(self) -> int:
         return self.config.num_train_timesteps // self.num_inference_steps
 

@@ -199,6 +199,11 @@ class ForwardDDIM:
     def scale_model_input(self, x, t):
         return x
 
+    def add_noise(self, original_samples, noise, timesteps):
+        """diffusers ``DDIMScheduler.add_noise``: sqrt(a_t) x + sqrt(1 - a_t) noise."""
+        a = self.ac[timesteps.long()].view(-1, *([1] * (original_samples.dim() - 1)))
+        return (a.sqrt() * original_samples.double() + (1 - a).sqrt() * noise.double()).to(original_samples.dtype)
+
     def step(self, model_output, timestep, sample, eta=0.0, generator=None):
         assert eta == 0.0
         t = int(timestep)

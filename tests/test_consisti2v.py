@@ -343,3 +343,70 @@ def test_consisti2v_pipeline_callbacks_and_tensor_first_frames(monkeypatch):
     assert torch.equal(a, b)
     with pytest.raises(ValueError):
         pipe.invert(first_frame_paths=frames[0], first_frames=torch.zeros(1, 3, j["height"], j["width"]), **kw)
+
+
+# ------------------------------------------------------------------------------------------------- FrameInit
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_frameinit_filters_and_mix_vs_the_references_own_functions():
+    """``consisti2v/consisti2v/utils/frameinit_utils.py`` imported verbatim (pure torch) vs ``get_freq_filter`` / ``freq_mix_3d``."""
+    import importlib.util
+    from anyv2v_amd.consisti2v_pipeline import freq_mix_3d, get_freq_filter
+    spec_ = importlib.util.spec_from_file_location("_ref_frameinit", os.path.join(ref_stubs.REFERENCE_ROOT, "consisti2v", "consisti2v", "utils",
+                                                                                  "frameinit_utils.py"))
+    ref = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(ref)
+    shape = [1, 4, 6, 8, 12]
+    for kind, n, d_s, d_t in (("gaussian", None, 0.25, 0.25), ("butterworth", 4, 0.25, 0.5), ("butterworth", 2, 0.5, 0.25), ("ideal", None, 0.3, 0.25),
+                              ("gaussian", None, 0.0, 0.25)):
+        a, b = get_freq_filter(shape, "cpu", kind, n, d_s, d_t), ref.get_freq_filter(shape, "cpu", kind, n, d_s, d_t)
+        assert a.shape == b.shape and torch.allclose(a, b, atol=1e-6), kind
+    g = torch.Generator().manual_seed(0)
+    x, noise = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    lpf = ref.get_freq_filter(shape, "cpu", "butterworth", 4, 0.25, 0.25)
+    assert torch.allclose(freq_mix_3d(x, noise, lpf), ref.freq_mix_3d(x, noise, lpf), atol=1e-5)
+    box = get_freq_filter(shape, "cpu", "box", None, 0.5, 0.5)       # (the reference's box filter returns None: the mask it builds is checked)
+    assert box.sum() == 4 * (2 * round(6 // 2 * 0.5)) * (2 * round(8 // 2 * 0.5)) ** 2 and box[0, 0, 3, 4, 6] == 1
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_native_consisti2v_sampling_with_frameinit_vs_the_reference_pipeline(monkeypatch, tmp_path):
+    """``__call__`` from fresh noise with ``use_frameinit`` (``pipeline_video_editing.py:469-711``: pyoco-mixed noise from a seeded generator,
+    ``init_filter``, ``add_noise`` at level 999, ``freq_mix_3d``, text guidance) -- the reference's class vs the native pipeline."""
+    import types
+    warnings.filterwarnings("ignore")
+    from anyv2v_amd import consisti2v as c2
+    from anyv2v_amd.consisti2v_pipeline import ConditionalVideoEditingPipeline
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMScheduler
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    j = spec.PIPE_JOB
+    frames, _ = spec.pipeline_frames()
+    first = str(tmp_path / "first.png")
+    frames[0].resize((j["width"], j["height"])).save(first)
+    fp = types.SimpleNamespace(method="butterworth", n=4, d_s=0.25, d_t=0.25)
+    kw = dict(prompt="a robot", first_frame_paths=first, height=j["height"], width=j["width"], video_length=j["frames"], num_inference_steps=3,
+              guidance_scale_txt=4.0, guidance_scale_img=1.0, negative_prompt="blurry", frame_stride=3, noise_sampling_method="pyoco_mixed",
+              use_frameinit=True, frameinit_noise_level=999)
+    unet_mod, _, _ = ref_stubs.load_reference_consisti2v_unet()
+    ref_unet = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).eval()
+    ref, pm, pnp, inv_mod = rcp.build_reference_pipeline(ref_unet, 48)
+    ref.scheduler = rcp.ForwardDDIM(ref.scheduler)
+    ref.init_filter(j["frames"], j["height"], j["width"], fp)
+    cap = []
+    orig = ref.decode_latents
+    ref.decode_latents = lambda lat, *a, **k: (cap.append(lat.detach().clone()), orig(lat, *a, **k))[1]
+    with torch.no_grad():
+        ref(generator=torch.Generator().manual_seed(3), **kw)
+    emu.install(monkeypatch)
+    tok = rp.ToyTokenizer()
+    nat = ConditionalVideoEditingPipeline(vae=spec.ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(48), tok), tokenizer=tok,
+                                          unet=spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)),
+                                          scheduler=DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG))
+    nat.init_filter(j["frames"], j["height"], j["width"], fp)
+    got = nat(generator=torch.Generator().manual_seed(3), output_type="latent", **kw).videos
+    ok, err = _close(got, cap[-1], 3e-2)
+    assert ok, err
+    with pytest.raises(ValueError):
+        ConditionalVideoEditingPipeline(vae=nat.vae, text_encoder=nat.text_encoder, tokenizer=tok, unet=nat.unet, scheduler=nat.scheduler)(
+            generator=torch.Generator().manual_seed(3), **kw)     # no init_filter
