@@ -17,7 +17,8 @@ Kept from the reference because a drop-in must produce the same numbers:
   the UNet denoises ``video_length - 1`` frames and sees the clean first-frame latent as frame 0.
 
 ``use_frameinit`` (FFT noise re-initialisation, ``frameinit_utils.py``) is built (``init_filter``, host-side FFT once per clip).
-Not built (the AnyV2V runners never enable them): ``camera_motion``, ``guidance_rescale > 0``, ``eta > 0``, several clips per call, PnP with image guidance or without text guidance
+``camera_motion`` (pan / zoom pseudo clips for FrameInit) is built as well.  Not built (the AnyV2V runners never enable them):
+``guidance_rescale > 0``, ``eta > 0``, several clips per call, PnP with image guidance or without text guidance
 (the reference's hooks split the batch in three: ``consisti2v/pnp_utils.py:96,188,296``).
 """
 from __future__ import annotations
@@ -120,6 +121,33 @@ def _center_crop(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
         raise ValueError(f"frame of {H} x {W} is smaller than the {h} x {w} crop")
     top, left = int(round((H - h) / 2.0)), int(round((W - w) / 2.0))
     return x[..., top:top + h, left:left + w]
+
+
+def camera_motion_frames(x: torch.Tensor, motion: str, num_frames: int, crop_width: int, ratio: float = 1.5) -> torch.Tensor:
+    """``pan_right`` / ``pan_left`` / ``zoom_in`` / ``zoom_out`` (``pipeline_video_editing.py:63-121``): a pseudo clip [f, 3, h, w] cut out
+    of one pre-processed frame [3, H, W] -- a crop window that slides (pan) or shrinks / grows around the centre and is resized back
+    (zoom; bilinear, no antialiasing).  ``zoom_out`` hands float crop sizes to ``torchvision``'s crop in the reference (floor division
+    by the float ``ratio``), which only runs where slices accept them; the sizes are truncated to int here."""
+    H, W = x.shape[-2:]
+    out = []
+    for i in range(num_frames):
+        if motion == "pan_right":
+            sx = int((W - crop_width) * (i / num_frames))
+            out.append(x[..., :, sx:sx + crop_width])
+        elif motion == "pan_left":
+            sx = int((W - crop_width) * (1 - (i / num_frames)))
+            out.append(x[..., :, sx:sx + crop_width])
+        elif motion in ("zoom_in", "zoom_out"):
+            m = min(W, H)
+            if motion == "zoom_in":
+                cs = m - int((m - m // ratio) * (i / num_frames))
+            else:
+                cs = int(m // ratio + int((m - m // ratio) * (i / num_frames)))
+            sx, sy = int((W - cs) // 2), int((H - cs) // 2)
+            out.append(_resize(x[..., sy:sy + cs, sx:sx + cs], (crop_width, crop_width)))
+        else:
+            raise NotImplementedError(f"camera_motion: {motion} is not implemented.")
+    return torch.stack(out)
 
 
 def frame_to_pixels(img: Image.Image, height: int, width: int, crop: bool) -> torch.Tensor:
@@ -260,7 +288,7 @@ class ConditionalVideoEditingPipeline:
         ``noise_level``."""
         if self.freq_filter is None:
             raise ValueError("use_frameinit needs init_filter(video_length, height, width, filter_params) first")
-        static = clean.unsqueeze(2).repeat(1, 1, video_length, 1, 1)
+        static = self._motion_latents if getattr(self, "_motion_latents", None) is not None else clean.unsqueeze(2).repeat(1, 1, video_length, 1, 1)
         t = torch.full((latents.shape[0],), int(noise_level)).long()
         z_T = self.scheduler.add_noise(original_samples=static.to(latents.device), noise=latents, timesteps=t)
         return freq_mix_3d(z_T.to(torch.float32), latents, LPF=self.freq_filter).to(latents.dtype)
@@ -312,10 +340,19 @@ class ConditionalVideoEditingPipeline:
     def _first_frame_latent(self, path_or_image, height, width, crop, device):
         """One first-frame image (path, PIL image, or -- ``first_frames`` -- an already pre-processed [1, 3, H, W] tensor) -> sampled,
         scaled VAE latent [1, 4, h, w] (``:796-833``)."""
+        self._motion_latents = None
         if torch.is_tensor(path_or_image):
             return self.vae.encode_pixels(path_or_image.float(), device)
         img = path_or_image if isinstance(path_or_image, Image.Image) else Image.open(path_or_image).convert("RGB")
-        return self.vae.encode_pixels(frame_to_pixels(img, height, width, crop), device)
+        motion, n = getattr(self, "_camera_motion", None), getattr(self, "_video_length", None)
+        if motion is None:
+            return self.vae.encode_pixels(frame_to_pixels(img, height, width, crop), device)
+        # camera motion (``:553-577``): Resize(height) for a pan, Resize(2 * height) for a zoom, no centre crop; the pseudo clip's frames are
+        # encoded together and its first latent is the conditioning frame, the whole of it the FrameInit layout
+        x = (_resize(_to_tensor(img), height if motion.startswith("pan") else height * 2) - 0.5) / 0.5
+        lat = self.vae.encode_pixels(camera_motion_frames(x, motion, n, width), device)        # [f, 4, h, w]
+        self._motion_latents = lat.permute(1, 0, 2, 3)[None].contiguous()
+        return lat[:1]
 
     def encode_vae_video(self, video: List[Image.Image], device, height: int = 576, width: int = 1024):
         """``:1226-1258``: every frame encoded on its own (one posterior sample per frame) -> [1, 4, F, h, w]."""
@@ -362,9 +399,9 @@ class ConditionalVideoEditingPipeline:
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps, first_frame_paths)
-        if camera_motion is not None or guidance_rescale > 0.0 or eta != 0.0 or num_videos_per_prompt != 1:
-            raise NotImplementedError("camera_motion / guidance_rescale / eta / num_videos_per_prompt are not built "
-                                      "(the AnyV2V runners leave them off)")
+        if guidance_rescale > 0.0 or eta != 0.0 or num_videos_per_prompt != 1:
+            raise NotImplementedError("guidance_rescale / eta / num_videos_per_prompt are not built (the AnyV2V runners leave them off)")
+        self._camera_motion = camera_motion
         if first_frames is not None and (not torch.is_tensor(first_frames) or first_frames.dim() != 4 or first_frames.shape[0] != 1):
             raise NotImplementedError("first_frames: one pre-processed frame [1, 3, H, W] in [-1, 1] per call")
         if latents is not None and latents.shape[0] != 1:
@@ -457,6 +494,7 @@ class ConditionalVideoEditingPipeline:
                  frameinit_noise_level: int = 999, camera_motion: str = None, ddim_init_latents_t_idx: Optional[int] = 0, **kwargs):
         height, width = self._common(prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt,
                                      eta, guidance_rescale, use_frameinit, camera_motion)
+        self._video_length = video_length
         device = self._execution_device
         mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
         c2.clear_time(self)
@@ -492,6 +530,7 @@ class ConditionalVideoEditingPipeline:
         latent as frame 0) written to ``output_dir/ddim_latents_{t}.pt``.  ``videos``: [1, n_steps, C, F, h, w], noisiest first."""
         height, width = self._common(prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt,
                                      eta, guidance_rescale, use_frameinit, camera_motion)
+        self._video_length = video_length
         device = self._execution_device
         mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
         c2.clear_time(self)
@@ -550,6 +589,7 @@ class ConditionalVideoEditingPipeline:
         ``anyv2v_amd.consisti2v.register_*`` copy the source row's features into the other two on their schedules."""
         height, width = self._common(prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt,
                                      eta, guidance_rescale, use_frameinit, camera_motion)
+        self._video_length = video_length
         device = self._execution_device
         mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
         if mode != "text":

@@ -134,7 +134,9 @@ def load_reference_consisti2v_pipeline():
     m("torchvision")
     m("torchvision.io", read_video=None)
     tf = m("torchvision.transforms", Compose=_Compose, ToTensor=_ToTensor, Resize=_Resize, CenterCrop=_CenterCrop, Normalize=_Normalize)
-    tf.functional = m("torchvision.transforms.functional")
+    # (crop = slicing, resize of a tensor with antialias=None = plain bilinear: the camera-motion helpers, pipeline_video_editing.py:63-121)
+    tf.functional = m("torchvision.transforms.functional", crop=lambda img, top, left, height, width: img[..., top:top + height, left:left + width],
+                      resize=lambda img, size, antialias=None: _Resize(size)(img))
     m("diffusers")
     m("diffusers.utils", is_accelerate_available=lambda: False, deprecate=lambda *a, **k: None, BaseOutput=BaseOutput,
       logging=types.SimpleNamespace(get_logger=lambda *a, **k: _Logger()), load_image=lambda p: PIL.Image.open(p).convert("RGB"))

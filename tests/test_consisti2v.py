@@ -410,3 +410,55 @@ def test_native_consisti2v_sampling_with_frameinit_vs_the_reference_pipeline(mon
     with pytest.raises(ValueError):
         ConditionalVideoEditingPipeline(vae=nat.vae, text_encoder=nat.text_encoder, tokenizer=tok, unet=nat.unet, scheduler=nat.scheduler)(
             generator=torch.Generator().manual_seed(3), **kw)     # no init_filter
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("motion", ["pan_left", "pan_right", "zoom_in"])
+def test_native_consisti2v_camera_motion_with_frameinit_vs_the_reference_pipeline(monkeypatch, tmp_path, motion):
+    """``camera_motion`` (``pipeline_video_editing.py:63-121,553-594``): the pseudo clip cut out of the first frame, its latents as the
+    FrameInit layout, its first latent as the conditioning frame -- reference class vs native pipeline, sampling from seeded noise.
+    (``zoom_out`` passes float crop sizes to torchvision's crop in the reference and cannot run there.)"""
+    import types
+    warnings.filterwarnings("ignore")
+    from PIL import Image
+    from anyv2v_amd import consisti2v as c2
+    from anyv2v_amd.consisti2v_pipeline import ConditionalVideoEditingPipeline
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMScheduler
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    j = spec.PIPE_JOB
+    frames, _ = spec.pipeline_frames()
+    first = str(tmp_path / "first.png")
+    frames[0].resize((3 * j["width"] // 2, j["height"] + 24), resample=Image.BICUBIC).save(first)     # wider and taller than the target
+    fp = types.SimpleNamespace(method="gaussian", n=None, d_s=0.25, d_t=0.25)
+    kw = dict(prompt="a robot", first_frame_paths=first, height=j["height"], width=j["height"], video_length=j["frames"], num_inference_steps=2,
+              guidance_scale_txt=1.0, guidance_scale_img=1.0, negative_prompt="", frame_stride=3, use_frameinit=True, camera_motion=motion)
+    unet_mod, _, _ = ref_stubs.load_reference_consisti2v_unet()
+    ref_unet = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).eval()
+    ref, pm, pnp, inv_mod = rcp.build_reference_pipeline(ref_unet, 48)
+    ref.scheduler = rcp.ForwardDDIM(ref.scheduler)
+    ref.init_filter(j["frames"], j["height"], j["height"], fp)
+    cap = []
+    orig = ref.decode_latents
+    ref.decode_latents = lambda lat, *a, **k: (cap.append(lat.detach().clone()), orig(lat, *a, **k))[1]
+    with torch.no_grad():
+        ref(generator=torch.Generator().manual_seed(3), **kw)
+    emu.install(monkeypatch)
+    tok = rp.ToyTokenizer()
+    nat = ConditionalVideoEditingPipeline(vae=spec.ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(48), tok), tokenizer=tok,
+                                          unet=spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)),
+                                          scheduler=DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG))
+    nat.init_filter(j["frames"], j["height"], j["height"], fp)
+    got = nat(generator=torch.Generator().manual_seed(3), output_type="latent", **kw).videos
+    ok, err = _close(got, cap[-1], 2e-2)
+    assert ok, err
+
+
+def test_camera_motion_zoom_out_cuts_growing_windows():
+    from anyv2v_amd.consisti2v_pipeline import camera_motion_frames
+    x = torch.arange(3 * 90 * 120, dtype=torch.float32).view(3, 90, 120) / 1000
+    z = camera_motion_frames(x, "zoom_out", 4, 32)
+    assert tuple(z.shape) == (4, 3, 32, 32)
+    # window sizes 60, 67, 75, 82 around the centre: the corner pixel moves outwards
+    assert z[0, 0, 0, 0] > z[1, 0, 0, 0] > z[3, 0, 0, 0]
