@@ -21,7 +21,7 @@ def _assert_all(results):
 
 def test_hip_library_loaded_and_mfma_layouts():
     from anyv2v_amd import _lib
-    assert _lib.load().anyv2v_version() >= 102
+    assert _lib.load().anyv2v_version() >= 103
     _assert_all(gc.check_selftest())
 
 
