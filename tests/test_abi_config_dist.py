@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/anyv2v_hip.h but not exported"
     assert set(decl) == set(_lib.SYMBOLS), "ctypes binding table and header disagree"
-    assert _lib.load().anyv2v_version() >= 102
+    assert _lib.load().anyv2v_version() >= 103
 
 
 def test_abi_argument_validation_without_gpu():
@@ -78,6 +78,15 @@ def test_abi_argument_validation_without_gpu():
     assert lib.anyv2v_ff_geglu_f16(ctypes.byref(f), None) == -2 and b"only C = 320" in lib.anyv2v_last_error()
     f.C, f.H, f.ldx, f.ldy = 320, 1280, 324, 320
     assert lib.anyv2v_ff_geglu_f16(ctypes.byref(f), None) == -1 and b"ldx" in lib.anyv2v_last_error()
+    # round 4: guidance + step (+ noise) -- null pointers, branch indices, prediction types that are singular at the given alpha
+    assert lib.anyv2v_guided_step_f16(None, 8, -1, -1, 0, 1.0, 1.0, 1, 0.5, 0.5, 0.5, 0.5, 16, 16, None) == -1
+    assert b"guided_step" in lib.anyv2v_last_error()
+    assert lib.anyv2v_guided_step_f16(16, 8, -1, 1, 0, 1.0, 1.0, 1, 0.5, 0.5, 0.5, 0.5, 16, 16, None) == -1      # image branch without an unconditional one
+    assert lib.anyv2v_guided_step_f16(16, 8, -1, -1, 0, 1.0, 1.0, 3, 0.5, 0.5, 0.5, 0.5, 16, 16, None) == -1     # unknown prediction type
+    assert lib.anyv2v_guided_step_f16(16, 8, -1, -1, 0, 1.0, 1.0, 1, 0.0, 1.0, 0.5, 0.5, 16, 16, None) == -1     # epsilon at alpha = 0
+    assert b"singular" in lib.anyv2v_last_error()
+    assert lib.anyv2v_guided_step_noise_f16(16, 8, -1, -1, 0, 1.0, 1.0, 1, 0.5, 0.5, 0.5, 0.5, 16, 16, None, 0.3, None) == -1   # sigma without noise
+    assert b"guided_step_noise" in lib.anyv2v_last_error()
     assert lib.anyv2v_set_batch_hint(0, 1) != 0 and lib.anyv2v_set_batch_hint(3, 2) == 0 and lib.anyv2v_set_batch_hint(1, 1) == 0
     with pytest.raises(_lib.HipKernelError):
         _lib.check(-1, "x")
