@@ -13,7 +13,6 @@ from pathlib import Path
 import torch
 
 from . import consisti2v as c2
-from .config import OmegaConf
 from .consisti2v_pipeline import ConditionalVideoEditingPipeline, inverse_scheduler_from_pretrained
 from .consisti2v_run_ddim_inversion import MODEL_ID, load_config, load_video_frames, save_videos_grid
 from .schedulers import DDIMScheduler

@@ -12,7 +12,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anyv2v_amd import consisti2v as c2  # noqa: E402
 from anyv2v_amd.consisti2v_pipeline import ConditionalVideoEditingPipeline  # noqa: E402
 from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMInverseScheduler, DDIMScheduler  # noqa: E402
-from anyv2v_amd.utils import LatentTrajectory  # noqa: E402
 
 
 def main():
