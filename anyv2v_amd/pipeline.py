@@ -94,7 +94,7 @@ class _StepEngine:
     step is overwritten by the caller with the source trajectory before each step.
     """
 
-    def __init__(self, pipe, sample, cond, b_unc, b_cond, guidance, dup_slots, shared_stem=False, batch_hint=None):
+    def __init__(self, pipe, sample, cond, b_unc, b_cond, guidance, dup_slots, shared_stem=False, batch_hint=None, lat_slots=None):
         self.pipe, self.unet = pipe, pipe.unet
         # (num, den): this engine runs a subset of another engine's branches ([negative, editing] of a three-branch edit step) and
         # must make the same launch choices -- ops.batch_hint
@@ -103,6 +103,8 @@ class _StepEngine:
         self.cond = cond
         self.b_unc, self.b_cond, self.guidance = b_unc, b_cond, float(guidance)
         self.lat_slot = sample.shape[0] - 1
+        # several clips inverted in one batch (``invert_clips``): every slot is a latent of its own, stepped without guidance
+        self.lat_slots = None if lat_slots is None else list(lat_slots)
         self.dup_slots = list(dup_slots)
         self.coef = torch.zeros(4, dtype=torch.float32, device=sample.device)
         self.graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
@@ -167,6 +169,11 @@ class _StepEngine:
         # drop_src_tail: the engine's slot 0 is the PnP source branch, whose prediction the update below never reads -- the forward
         # stops computing it behind the last hook site and returns the rows of slots [1:] (unet._forward_core)
         vtok = self.unet._forward_core(self.ctx, self.sample, drop_source_tail=self.drop_src_tail)
+        if self.lat_slots is not None:
+            for L in self.lat_slots:
+                lat = self.sample[L:L + 1]
+                ops.cfg_ddim_step(vtok, -1, L, 1.0, self.coef, lat, lat)
+            return
         L = self.lat_slot
         lat = self.sample[L:L + 1]
         off = 1 if vtok.shape[0] != self.sample.shape[0] * self.sample.shape[2] * self.sample.shape[3] * self.sample.shape[4] else 0
@@ -436,7 +443,7 @@ class I2VGenXLPipeline:
             self.unet.pack()  # (weights loaded / moved since the last call: new packed tensors, engines of the old ones are stale)
         key = (tag, self.unet._pack_gen, tuple(sample.shape), str(sample.device), tuple(cond["encoder_hidden_states"].shape), kw.get("b_unc"),
                kw.get("b_cond"), float(kw.get("guidance")), tuple(kw.get("dup_slots")), bool(kw.get("shared_stem", False)),
-               _use_graphs(), pnp_utils.has_foreign_hooks(self.unet), id(self.unet))
+               _use_graphs(), pnp_utils.has_foreign_hooks(self.unet), id(self.unet), kw.get("lat_slots"))
         eng = self._engines.pop(key, None)
         if eng is None or not eng.rebind(sample, cond):
             eng = _StepEngine(self, sample, cond, **kw)
@@ -518,6 +525,49 @@ class I2VGenXLPipeline:
         if not return_dict:
             return inverted
         return StableVideoDiffusionInversionPipelineOutput(inverted_latents=inverted)
+
+    @torch.no_grad()
+    def invert_clips(self, clips, height: int, width: int, num_frames: int = 16, num_inference_steps: int = 50, target_fps: int = 16,
+                     clip_skip: Optional[int] = 1, output_dirs=None, background_save: bool = False):
+        """Several clips inverted in ONE batch (guidance 1, the inversion configuration of the reference's runner): ``clips`` = list of
+        dicts ``prompt``, ``image`` (first frame), ``latents`` [1, 4, F, h, w] (``encode_vae_video``), optionally ``negative_prompt``.
+        The UNet forward runs over B = len(clips) rows -- each row its own clip with its own conditioning --, so every weight is read
+        once per step for all of them and the low-resolution launches carry B times the rows: an inversion-bound job (the template's
+        500 steps) gains what a B = 1 launch loses against a B = 3 one.  Returns one ``LatentTrajectory`` per clip; the numbers
+        differ from ``invert`` at rounding level (other launch plans at other row counts), not bit for bit."""
+        device = self._execution_device
+        self._guidance_scale = 1.0
+        pnp_utils.clear_time(self)
+        n = len(clips)
+        pes, ies, ils, lats = [], [], [], []
+        for c in clips:
+            pe, _npe, ie, il = self._conditioning(c.get("prompt", ""), c["image"], height, width, num_frames, c.get("negative_prompt"), None, None,
+                                                  target_fps, clip_skip, None, None)
+            self._single_clip(pe, 1)
+            pes.append(pe)
+            ies.append(ie)
+            ils.append(il)
+            lats.append(self.prepare_latents(1, self.unet.config.in_channels, num_frames, height, width, torch.float16, device, None,
+                                             c["latents"]).to(torch.float16))
+        sample = torch.cat(lats).contiguous()
+        cond = dict(encoder_hidden_states=torch.cat(pes).contiguous(), fps=torch.tensor([target_fps] * n, device=device),
+                    image_latents=torch.cat(ils).contiguous(), image_embeddings=torch.cat(ies).contiguous())
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        ts = [int(t) for t in self.scheduler.timesteps.tolist()]
+        eng = self._engine(f"inv{n}", sample, cond, b_unc=-1, b_cond=n - 1, guidance=1.0, dup_slots=(), lat_slots=tuple(range(n)))
+        sample = eng.sample
+        t_table = torch.tensor(ts, dtype=torch.float32, device=device)[:, None].expand(-1, n).contiguous()
+        coef_table = self.scheduler.coefficient_table(ts, device)
+        trajs = [LatentTrajectory() for _ in range(n)]
+        for i, t in enumerate(ts):
+            eng.step(t_table[i], coef_table[i], key=("inv",))
+            for k in range(n):
+                trajs[k][t] = sample[k:k + 1].clone()
+        if output_dirs is not None:
+            for tr, d in zip(trajs, output_dirs):
+                if d is not None:
+                    tr.save(d, background=background_save)
+        return trajs
 
     # ------------------------------------------------------------------ A3: plain CFG sampling (:652-888)
     @torch.no_grad()

@@ -123,7 +123,7 @@ def main_pipelined(inv_template, inv_list, edit_template, edit_list, device, log
 
 
 def main(inv_template, inv_list, edit_template, edit_list, device, logger, synthetic_encoders=False, random_init_seed=None,
-         frame_parallel=False, pipelined=None):
+         frame_parallel=False, pipelined=None, batch_clips=1):
     rank, local_rank, world = init_distributed()
     pipe = I2VGenXLPipeline.from_pretrained(inv_template.get("model_path", stage1.MODEL_ID), torch_dtype=torch.float16,
                                             variant="fp16", random_init_seed=random_init_seed)
@@ -134,6 +134,8 @@ def main(inv_template, inv_list, edit_template, edit_list, device, logger, synth
         pipe.unet.set_frame_parallel(FrameParallel())
     if pipelined is None:
         pipelined = os.environ.get("ANYV2V_PIPELINED", "1") == "1"
+    if batch_clips and int(batch_clips) > 1:
+        pipelined = False   # batched inversions (Stage1.run_batched) run stage 1 over all clips first; the edits follow from HBM
     if pipelined and world == 1:
         return main_pipelined(inv_template, inv_list, edit_template, edit_list, device, logger, pipe)
     n_clips = len({e.get("video_name") for e in inv_list if e.get("active", True) is not False})
@@ -146,7 +148,7 @@ def main(inv_template, inv_list, edit_template, edit_list, device, logger, synth
     trajectories = {}
     seed_everything(inv_template.seed)  # each stage starts from its template's seed, as two separate processes would
     stage1.main(inv_template, inv_list, device, logger, synthetic_encoders, random_init_seed, frame_parallel, pipe=pipe,
-                trajectories=trajectories)
+                trajectories=trajectories, batch_clips=batch_clips)
     if world > 1 and not frame_parallel:
         # Sharded mode deals the entries of each stage independently: a rank may edit a clip that another rank inverted (or have no
         # inversion work at all) and then reads its ddim_latents files -- which must be complete on disk first.  Join this rank's
@@ -170,6 +172,9 @@ def cli(argv=None):
     ap.add_argument("--synthetic_encoders", action="store_true")
     ap.add_argument("--random_init_seed", type=int, default=None)
     ap.add_argument("--frame_parallel", action="store_true")
+    ap.add_argument("--batch_clips", type=int, default=1,
+                    help="invert up to N clips of the same geometry in one batch (for inversion-bound jobs, e.g. the template's 500 steps; "
+                         "implies stage 1 before stage 2)")
     ap.add_argument("--serial", action="store_true", help="stage 1 over all clips, then stage 2 (default on one GPU: clip k + 1 is "
                                                           "inverted while clip k is edited, on two streams)")
     args = ap.parse_args(argv)
@@ -185,7 +190,7 @@ def cli(argv=None):
         torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
     main(inv_t, inv_l, ed_t, ed_l, device, logger, args.synthetic_encoders, args.random_init_seed, args.frame_parallel,
-         pipelined=False if args.serial else None)
+         pipelined=False if args.serial else None, batch_clips=args.batch_clips)
 
 
 if __name__ == "__main__":

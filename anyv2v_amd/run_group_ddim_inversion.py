@@ -116,10 +116,10 @@ class Stage1:
         for config_entry in mine:
             yield self._entry(config_entry)
 
-    def _entry(self, config_entry):
-        template_config, logger, pipe = self.template_config, self.logger, self.pipe
-        rank, world, fp_mode, writer = self.rank, self.world, self.fp_mode, self.writer
-        ddim_scheduler = self.ddim_scheduler
+    def _prepare(self, config_entry):
+        """Config, frames and seeds of one entry; None when the entry is skipped (complete on disk)."""
+        template_config, logger = self.template_config, self.logger
+        rank, world, fp_mode = self.rank, self.world, self.fp_mode
         entry_idx = self.all_active.index(config_entry)
         logger.info(f"[rank {rank}/{world}] Processing config_entry: {config_entry}")
         config = OmegaConf.merge(template_config, OmegaConf.create(config_entry))
@@ -134,7 +134,7 @@ class Stage1:
             skip = flag[0]
         if skip:
             logger.info(f"### Skipping !!! {config.output_dir} already exists. ")
-            return
+            return None
         logger.info(f"config: {OmegaConf.to_yaml(config)}")
         try:
             logger.info(f"Loading frames from: {config.video_frames_path}")
@@ -152,17 +152,14 @@ class Stage1:
         if config.inverse_config.null_image_inversion:
             logger.info("### Inverse a null image!")
             first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
-        seed_everything(seed_for_entry(template_config.seed, entry_idx) if self.e_world > 1 else template_config.seed)
-        g = torch.Generator().manual_seed(template_config.seed)
-        # launched, not read back: the files are written below (``write=False`` keeps the trajectory in HBM only for now)
-        ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, self.inverse_scheduler, g, write=False)
-        traj = pipe._last_trajectory
-        latents_dir = os.path.abspath(str(config.inverse_config.output_dir))
-        if self.trajectories is not None:
-            self.trajectories[latents_dir] = traj
-        rng = _RngState(self.device)
-        yield latents_dir
-        rng.restore()
+        seed = seed_for_entry(template_config.seed, entry_idx) if self.e_world > 1 else template_config.seed
+        return dict(config=config, first_frame=first_frame, frame_list=frame_list, seed=seed,
+                    latents_dir=os.path.abspath(str(config.inverse_config.output_dir)))
+
+    def _finish(self, p, traj, g):
+        """Files of one inverted clip (background writer) and its reconstruction."""
+        config, logger, pipe, writer, ddim_scheduler = p["config"], self.logger, self.pipe, self.writer, self.ddim_scheduler
+        latents_dir, first_frame = p["latents_dir"], p["first_frame"]
         if writer:
             # ddim_latents_{t}.pt, reference format, from a background thread (every reader in anyv2v_amd.utils joins it first)
             traj.save(config.inverse_config.output_dir, background=True)
@@ -187,12 +184,75 @@ class Stage1:
                 logger.info(f"Saved reconstructed video to {config.output_dir}")
         traj.wait()
 
+    def _entry(self, config_entry):
+        p = self._prepare(config_entry)
+        if p is None:
+            return
+        pipe = self.pipe
+        seed_everything(p["seed"])
+        g = torch.Generator().manual_seed(self.template_config.seed)
+        # launched, not read back: the files are written below (``write=False`` keeps the trajectory in HBM only for now)
+        ddim_inversion(p["config"].inverse_config, p["first_frame"], p["frame_list"], pipe, self.inverse_scheduler, g, write=False)
+        traj = pipe._last_trajectory
+        if self.trajectories is not None:
+            self.trajectories[p["latents_dir"]] = traj
+        rng = _RngState(self.device)
+        yield p["latents_dir"]
+        rng.restore()
+        self._finish(p, traj, g)
+
+    def run_batched(self, batch_clips: int):
+        """``--batch_clips N``: up to N consecutive entries of the same geometry / step count (guidance 1) are inverted in ONE batch
+        (``pipe.invert_clips``: every weight read once per step for all of them).  Per-entry seeding and VAE sampling as in the one-by-one
+        path; the trajectories differ from it at rounding level (other launch plans at other row counts)."""
+        mine = self._my_entries if self._my_entries is not None else shard_entries(self.configs_list, self.e_rank, self.e_world)
+        prepared = [p for p in (self._prepare(e) for e in mine) if p is not None]
+
+        def key(p):
+            c = p["config"].inverse_config
+            return (tuple(c.image_size), int(c.n_frames), int(c.n_steps), int(c.target_fps), float(c.cfg) == 1.0)
+        i = 0
+        while i < len(prepared):
+            group = [prepared[i]]
+            while len(group) < batch_clips and i + len(group) < len(prepared) and key(prepared[i + len(group)]) == key(group[0]) and key(group[0])[-1]:
+                group.append(prepared[i + len(group)])
+            i += len(group)
+            pipe = self.pipe
+            g = torch.Generator().manual_seed(self.template_config.seed)
+            if len(group) == 1 or not key(group[0])[-1]:
+                for p in group:
+                    seed_everything(p["seed"])
+                    ddim_inversion(p["config"].inverse_config, p["first_frame"], p["frame_list"], pipe, self.inverse_scheduler, g, write=False)
+                    trajs = [pipe._last_trajectory]
+                    if self.trajectories is not None:
+                        self.trajectories[p["latents_dir"]] = trajs[0]
+                    self._finish(p, trajs[0], g)
+                continue
+            c0 = group[0]["config"].inverse_config
+            pipe.scheduler = self.inverse_scheduler
+            clips = []
+            for p in group:
+                seed_everything(p["seed"])
+                c = p["config"].inverse_config
+                lat0 = pipe.encode_vae_video(p["frame_list"], device=pipe._execution_device, height=c.image_size[1], width=c.image_size[0])
+                clips.append(dict(prompt=c.prompt, negative_prompt=c.negative_prompt, image=p["first_frame"], latents=lat0))
+            self.logger.info(f"inverting {len(group)} clips in one batch: {[p['config'].video_name for p in group]}")
+            trajs = pipe.invert_clips(clips, height=c0.image_size[1], width=c0.image_size[0], num_frames=c0.n_frames,
+                                      num_inference_steps=c0.n_steps, target_fps=c0.target_fps)
+            for p, traj in zip(group, trajs):
+                if self.trajectories is not None:
+                    self.trajectories[p["latents_dir"]] = traj
+                self._finish(p, traj, g)
+
 
 def main(template_config, configs_list, device, logger, synthetic_encoders=False, random_init_seed=None, frame_parallel=False,
-         pipe=None, trajectories=None):
+         pipe=None, trajectories=None, batch_clips=1):
     """``pipe``: reuse a pipeline that is already built (``run_group_anyv2v``: both stages in one process); ``trajectories``: dict
-    filled with {absolute latents directory: LatentTrajectory} of every inversion run here (the in-HBM hand-off to stage 2)."""
+    filled with {absolute latents directory: LatentTrajectory} of every inversion run here (the in-HBM hand-off to stage 2);
+    ``batch_clips``: see ``Stage1.run_batched``."""
     stage = Stage1(template_config, configs_list, device, logger, synthetic_encoders, random_init_seed, frame_parallel, pipe, trajectories)
+    if batch_clips and int(batch_clips) > 1 and not stage.fp_mode:
+        return stage.run_batched(int(batch_clips))
     for entry in stage.entries():
         for _ in entry:
             pass
@@ -207,6 +267,8 @@ def cli(argv=None):
     parser.add_argument("--frame_parallel", action="store_true",
                         help="under torchrun: shard every clip's frames over the ranks instead of dealing clips to ranks")
     parser.add_argument("--random_init_seed", type=int, default=None, help="random UNet weights (no checkpoint offline)")
+    parser.add_argument("--batch_clips", type=int, default=1,
+                        help="invert up to N consecutive clips of the same geometry in one batch (inversion-bound jobs: the 500-step template)")
     args = parser.parse_args(argv)
     template_config = OmegaConf.load(args.template_config)
     logging_level = logging.DEBUG if template_config.debug else logging.INFO
@@ -224,7 +286,8 @@ def cli(argv=None):
         torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
     seed_everything(template_config.seed)
-    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed, args.frame_parallel)
+    main(template_config, configs_list, device, logger, args.synthetic_encoders, args.random_init_seed, args.frame_parallel,
+         batch_clips=args.batch_clips)
 
 
 if __name__ == "__main__":

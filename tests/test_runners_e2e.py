@@ -532,3 +532,40 @@ def test_fused_runner_world2_deals_whole_clips_and_pipelines_them(tmp_path):
                 assert torch.equal(torch.load(x[rel]), torch.load(y[rel])), rel
             else:
                 assert filecmp.cmp(x[rel], y[rel], shallow=False), rel
+
+
+def _check_batched_inversion_job(tmp_path, device):
+    """The two-clip, three-edit job with ``batch_clips=2`` (both inversions in one B = 2 forward per step) against the one-by-one serial
+    run: same files, trajectories and edited latents equal up to the rounding of another launch plan."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if device == "cpu":
+        import cpu_ops_emulation as emu
+        emu.install()
+        os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    base = _make_workspace(tmp_path)
+    from anyv2v_amd import run_group_anyv2v as fused
+    log = logging.getLogger("e2e")
+    for tag, bc in (("one", 1), ("two", 2)):
+        inv, inv_list, ed, ed_list = _two_clip_job(base, tag)
+        inv.device = ed.device = device
+        trajs = fused.main(inv, inv_list, ed, ed_list, torch.device(device), log, synthetic_encoders=True, pipelined=False, batch_clips=bc)
+        assert len(trajs) == 2
+    for top in ("inversions", os.path.join("Results", "Prompt-Based-Editing")):
+        a, b = _tree(os.path.join(base, top, "mini-one")), _tree(os.path.join(base, top, "mini-two"))
+        assert sorted(a) == sorted(b) and len(a) > 0
+        for rel in a:
+            if rel.endswith(".pt"):
+                x, y = torch.load(a[rel]).float(), torch.load(b[rel]).float()
+                assert float((x - y).abs().max()) <= 3e-2 * float(x.abs().max()), rel
+
+
+def test_batched_inversion_job_matches_the_one_by_one_run(tmp_path, monkeypatch):
+    monkeypatch.setenv("ANYV2V_SOURCE_CACHE", "0")
+    _check_batched_inversion_job(tmp_path, "cpu")
+
+
+@pytest.mark.gpu
+def test_batched_inversion_job_on_gpu(tmp_path):
+    _check_batched_inversion_job(tmp_path, "cuda")
