@@ -199,8 +199,10 @@ class DDPMScheduler(_DDIMBase):
     ``timesteps``, ``step(noise_pred, t, x)["prev_sample"]``; variance type "fixed_small", no sample clipping): the ancestral step
     ``x' = c0 x0 + ct x + sqrt(var) n`` with ``c0 = sqrt(a_prev) beta_t / (1 - a_t)``, ``ct = sqrt(alpha_t) (1 - a_prev) / (1 - a_t)``,
     ``var = (1 - a_prev) / (1 - a_t) beta_t`` (0 at t = 0), ``alpha_t = a_t / a_prev``, ``a_prev`` = 1 below timestep 0.  The noise is
-    drawn from the global RNG (or ``generator``) in the sample's dtype on the sample's device, as ``randn_tensor`` does.  UNPINNED:
-    diffusers is not in the reference tree; restated from the 0.15.0 release the reference pins (``seine/requirement.txt:5``)."""
+    drawn from the global RNG (or ``generator``) in the sample's dtype on the sample's device, as ``randn_tensor`` does.  diffusers is
+    not in the reference tree (restated from the 0.15.0 release the reference pins, ``seine/requirement.txt:5``), but the process is:
+    the coefficients are pinned to the posterior mean / FIXED_SMALL variance of ``seine/diffusion/gaussian_diffusion.py`` on the
+    respaced timesteps (``tests/test_seine.py::test_ddpm_step_is_pinned_to_the_references_own_gaussian_diffusion``)."""
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         self._check_n(num_inference_steps)

@@ -273,3 +273,45 @@ def test_seine_cli_runners_end_to_end(monkeypatch, tmp_path):
 @pytest.mark.gpu
 def test_seine_cli_runners_on_gpu(tmp_path):
     check_seine_cli_outputs(*run_seine_cli_stages(tmp_path / "a", "cuda:0"))
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_ddpm_step_is_pinned_to_the_references_own_gaussian_diffusion():
+    """diffusers' ``DDPMScheduler`` is not in the reference tree, but SEINE vendors the process it implements:
+    ``seine/diffusion/gaussian_diffusion.py`` (``q_posterior_mean_variance`` ``:235-255``, ``p_mean_variance`` ``:257-390``, FIXED_SMALL
+    variance) with ``respace.SpacedDiffusion`` (``:66-93``: the betas of a sub-sequence of timesteps).  On the 50 timesteps the edit visits
+    its posterior mean and variance ARE the ancestral step: ``schedulers.DDPMScheduler``'s coefficients are checked against them."""
+    import importlib.util
+    import sys
+    from anyv2v_amd.schedulers import SEINE_SCHEDULER_CONFIG, DDPMScheduler
+    root = os.path.join(ref_stubs.REFERENCE_ROOT, "seine", "diffusion")
+    spec_ = importlib.util.spec_from_file_location("_ref_seine_diffusion", os.path.join(root, "__init__.py"), submodule_search_locations=[root])
+    mod = importlib.util.module_from_spec(spec_)
+    sys.modules["_ref_seine_diffusion"] = mod
+    try:
+        spec_.loader.exec_module(mod)
+        gd = sys.modules["_ref_seine_diffusion.gaussian_diffusion"]
+        sched = DDPMScheduler(**SEINE_SCHEDULER_CONFIG)
+        sched.set_timesteps(50)
+        ts = sorted(int(t) for t in sched.timesteps)
+        assert ts == list(range(0, 1000, 20))
+        diff = mod.SpacedDiffusion(use_timesteps=ts, betas=gd.get_named_beta_schedule("linear", 1000), model_mean_type=gd.ModelMeanType.EPSILON,
+                                   model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+        g = torch.Generator().manual_seed(0)
+        x, eps = torch.randn(2, 4, 3, 5, 5, generator=g, dtype=torch.float64), torch.randn(2, 4, 3, 5, 5, generator=g, dtype=torch.float64)
+        for i, t in enumerate(ts):
+            if i not in (0, 1, 7, 25, 49):
+                continue
+            out = diff.p_mean_variance(lambda xx, tt: eps, x, torch.tensor([i, i]), clip_denoised=False)
+            sa_t, sb_t, cx, ce, sigma = sched.ancestral_coefficients(t)
+            x0 = (x - sb_t * eps) / sa_t
+            mean = cx * x0 + ce * eps
+            assert torch.allclose(mean, out["mean"], rtol=1e-4, atol=1e-5), t      # (fp32 alpha table here, as in diffusers; fp64 numpy there)
+            assert torch.allclose(x0, out["pred_xstart"], rtol=1e-4, atol=1e-5), t
+            if t > 0:
+                assert abs(sigma ** 2 - float(out["variance"].flatten()[0])) <= 5e-4 * sigma ** 2, t   # (1 - a_prev of an fp32 table next to 1: 1.6e-4 at t = 20)
+            else:
+                assert sigma == 0.0     # (p_sample masks the noise at t = 0, gaussian_diffusion.py:431-433)
+    finally:
+        for k in [k for k in sys.modules if k.startswith("_ref_seine_diffusion")]:
+            del sys.modules[k]
