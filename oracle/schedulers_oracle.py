@@ -3,7 +3,8 @@
 Follows the vendored ``/root/reference/consisti2v/ddim_inverse_scheduler.py``:
 betas ``:49-90`` (squaredcos_cap_v2), zero-terminal-SNR rescale ``:94-127``,
 timesteps ``:253-289``, inverse step ``:329-369``.  The forward ``DDIMScheduler``
-(diffusers 0.26.3, not vendored) is the mirror image.  Config in
+(diffusers 0.26.3, not vendored) is the mirror image -- and is pinned to the reference's own
+``seine/diffusion/gaussian_diffusion.py::ddim_sample`` on the respaced timesteps (``tests/test_oracle.py``).  Config in
 effect is the one logged at ``i2vgen-xl/demo.ipynb:1208-1226``.
 
 Deliberately written with float64 numpy + explicit loops so it shares no code with

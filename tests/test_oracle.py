@@ -400,3 +400,46 @@ def test_chunked_oracle_equals_plain_oracle():
         pnp_oracle.clear_hooks(unet)
     with torch.no_grad():
         assert torch.equal(unet(inp["sample"], 981, **kw)[0], plain)
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_forward_ddim_step_is_pinned_to_the_references_own_gaussian_diffusion():
+    """The forward ``DDIMScheduler`` (diffusers) is not vendored -- until now "the mirror image of the vendored inverse scheduler" by
+    restatement only.  The reference tree does hold an independent implementation of the same step: ``GaussianDiffusion.ddim_sample``
+    (``seine/diffusion/gaussian_diffusion.py:547-607``, eta 0) on ``respace.SpacedDiffusion``.  With the I2VGen-XL betas (cosine, zero
+    terminal SNR) respaced to the 50 sampling timesteps and the v-prediction turned into its x0 form, its ``sample`` must be what
+    ``oracle.schedulers_oracle.ddim_step`` and the product's ``DDIMScheduler.coefficients`` produce."""
+    import importlib.util
+    import sys
+    from anyv2v_amd.schedulers import DDIMScheduler
+    from oracle import schedulers_oracle as so
+    root = os.path.join(ref_stubs.REFERENCE_ROOT, "seine", "diffusion")
+    spec_ = importlib.util.spec_from_file_location("_ref_seine_diffusion2", os.path.join(root, "__init__.py"), submodule_search_locations=[root])
+    mod = importlib.util.module_from_spec(spec_)
+    sys.modules["_ref_seine_diffusion2"] = mod
+    try:
+        spec_.loader.exec_module(mod)
+        gd = sys.modules["_ref_seine_diffusion2.gaussian_diffusion"]
+        sched = DDIMScheduler()
+        sched.set_timesteps(50)
+        ts = sorted(int(t) for t in sched.timesteps)                       # 1, 21, ..., 981
+        betas = sched.betas.double().numpy()
+        diff = mod.SpacedDiffusion(use_timesteps=ts, betas=betas, model_mean_type=gd.ModelMeanType.START_X,
+                                   model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+        ac = so.alphas_cumprod()
+        g = torch.Generator().manual_seed(1)
+        x, v = torch.randn(2, 4, 3, 5, 5, generator=g, dtype=torch.float64), torch.randn(2, 4, 3, 5, 5, generator=g, dtype=torch.float64)
+        for i, t in enumerate(ts):
+            if i not in (0, 1, 10, 30, 49):
+                continue
+            a_t = float(sched.alphas_cumprod[t])
+            x0 = a_t ** 0.5 * x - (1 - a_t) ** 0.5 * v                      # v-prediction -> x0 (ddim_inverse_scheduler.py:350-352)
+            ref = diff.ddim_sample(lambda xx, tt: x0, x, torch.tensor([i, i]), clip_denoised=False, eta=0.0)["sample"]
+            sa_t, sb_t, sa_p, sb_p = sched.coefficients(t)
+            prod = sa_p * (sa_t * x - sb_t * v) + sb_p * (sa_t * v + sb_t * x)
+            assert torch.allclose(prod, ref, rtol=2e-4, atol=2e-5), ("product coefficients", t)
+            orc = torch.from_numpy(np.asarray(so.ddim_step(v.numpy(), t, x.numpy(), 50, ac)))
+            assert torch.allclose(orc, ref, rtol=2e-4, atol=2e-5), ("oracle ddim_step", t)
+    finally:
+        for k in [k for k in sys.modules if k.startswith("_ref_seine_diffusion2")]:
+            del sys.modules[k]
