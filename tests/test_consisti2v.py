@@ -462,3 +462,42 @@ def test_camera_motion_zoom_out_cuts_growing_windows():
     assert tuple(z.shape) == (4, 3, 32, 32)
     # window sizes 60, 67, 75, 82 around the centre: the corner pixel moves outwards
     assert z[0, 0, 0, 0] > z[1, 0, 0, 0] > z[3, 0, 0, 0]
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_epsilon_forward_ddim_step_is_pinned_to_the_references_gaussian_diffusion():
+    """The forward DDIM step of this backend (epsilon prediction, linear betas) -- the product's ``DDIMScheduler.coefficients`` and the
+    stand-in the reference pipeline harness steps with (``oracle.ref_consisti2v_pipeline.ForwardDDIM``) -- against the in-tree
+    ``seine/diffusion/gaussian_diffusion.py::ddim_sample`` on ``SpacedDiffusion`` (eta 0), 50 steps with ``steps_offset`` 1."""
+    import importlib.util
+    import sys
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMScheduler
+    from oracle import ref_consisti2v_pipeline as rcp
+    root = os.path.join(ref_stubs.REFERENCE_ROOT, "seine", "diffusion")
+    spec_ = importlib.util.spec_from_file_location("_ref_seine_diffusion3", os.path.join(root, "__init__.py"), submodule_search_locations=[root])
+    mod = importlib.util.module_from_spec(spec_)
+    sys.modules["_ref_seine_diffusion3"] = mod
+    try:
+        spec_.loader.exec_module(mod)
+        gd = sys.modules["_ref_seine_diffusion3.gaussian_diffusion"]
+        sched = DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG)
+        sched.set_timesteps(50)
+        ts = sorted(int(t) for t in sched.timesteps)
+        diff = mod.SpacedDiffusion(use_timesteps=ts, betas=sched.betas.double().numpy(), model_mean_type=gd.ModelMeanType.EPSILON,
+                                   model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+        inv = ref_stubs.load_reference_inverse_scheduler().DDIMInverseScheduler(**rcp.SCHED_CFG)
+        fwd = rcp.ForwardDDIM(inv)
+        fwd.set_timesteps(50)
+        g = torch.Generator().manual_seed(2)
+        x, e = torch.randn(2, 4, 3, 5, 5, generator=g, dtype=torch.float64), torch.randn(2, 4, 3, 5, 5, generator=g, dtype=torch.float64)
+        for i, t in enumerate(ts):
+            if i not in (0, 1, 10, 30, 49):
+                continue
+            ref = diff.ddim_sample(lambda xx, tt: e, x, torch.tensor([i, i]), clip_denoised=False, eta=0.0)["sample"]
+            sa_t, sb_t, sa_p, sb_p = sched.coefficients(t)
+            prod = sa_p * (x - sb_t * e) / sa_t + sb_p * e
+            assert torch.allclose(prod, ref, rtol=2e-4, atol=2e-5), ("product", t)
+            assert torch.allclose(fwd.step(e, t, x).prev_sample, ref, rtol=2e-4, atol=2e-5), ("harness stand-in", t)
+    finally:
+        for k in [k for k in sys.modules if k.startswith("_ref_seine_diffusion3")]:
+            del sys.modules[k]
