@@ -483,6 +483,23 @@ class ConditionalVideoEditingPipeline:
             return video
         return AnimationPipelineOutput(videos=video)
 
+    _crop_first_frame = False     # (``pipeline_video_editing.py:588-589``: plain Resize((height, width)); the animation pipelines crop)
+
+    def _sample(self, clean, latents, text_embeddings, mode, video_length, height, width, num_inference_steps, t_idx, generator,
+                noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride, g_img, g_txt, on_step):
+        """Timesteps, start latents (given, or drawn; FrameInit), first-frame rows, the guided loop (``:603-704``) -> [1, C, F - 1, h, w]."""
+        device = self._execution_device
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        self.scheduler.timesteps = self.scheduler.timesteps[t_idx:]
+        latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
+                                       noise_sampling_method, noise_alpha)
+        if use_frameinit:
+            latents = self._frameinit(latents, clean, video_length, frameinit_noise_level)
+        noisy, latents = latents[:, :, 0], latents[:, :, 1:]
+        ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
+        return self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode), g_img, g_txt,
+                             on_step=on_step)
+
     # ------------------------------------------------------------------ ``__call__`` (:469-711)
     @torch.no_grad()
     def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None, width: Optional[int] = None,
@@ -502,18 +519,10 @@ class ConditionalVideoEditingPipeline:
         if first_frame_paths is None and first_frames is None:
             raise NotImplementedError("sampling without a first frame (first_frame_condition_mode 'none')")
         clean = self._first_frame_latent(first_frames if first_frame_paths is None else self._one(first_frame_paths, "first frames"),
-                                         height, width, False, device)
-        self.scheduler.set_timesteps(num_inference_steps, device=device)
-        self.scheduler.timesteps = self.scheduler.timesteps[ddim_init_latents_t_idx:]
-        latents = self.prepare_latents(1, self.unet.config.in_channels, video_length, height, width, torch.float16, device, generator, latents,
-                                       noise_sampling_method, noise_alpha)
-        if use_frameinit:
-            latents = self._frameinit(latents, clean, video_length, frameinit_noise_level)
-        noisy, latents = latents[:, :, 0], latents[:, :, 1:]
-        ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
-        latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode),
-                                guidance_scale_img, guidance_scale_txt,
-                                on_step=self._callback(callback, callback_steps))
+                                         height, width, self._crop_first_frame, device)
+        latents = self._sample(clean, latents, text_embeddings, mode, video_length, height, width, num_inference_steps, ddim_init_latents_t_idx,
+                               generator, noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride,
+                               guidance_scale_img, guidance_scale_txt, self._callback(callback, callback_steps))
         return self._finish(latents, clean, output_type, return_dict)
 
     # ------------------------------------------------------------------ ``invert`` (:715-968)
@@ -623,6 +632,61 @@ class ConditionalVideoEditingPipeline:
         finally:
             c2.clear_time(self)
         return self._finish(latents, clean, output_type, return_dict)
+
+
+class ConditionalAnimationPipeline(ConditionalVideoEditingPipeline):
+    """ConsistI2V's image-to-video sampler (``consisti2v/consisti2v/pipelines/pipeline_conditional_animation.py:462-703``): the editing
+    pipeline's ``__call__`` with the first frame pre-processed as Resize(height) + CenterCrop((height, width)) (``:539-540``) and always
+    from the first timestep.  It has no ``invert`` / ``sample_with_pnp``."""
+    _crop_first_frame = True
+
+    def __call__(self, *args, **kwargs):
+        if kwargs.pop("ddim_init_latents_t_idx", 0):
+            raise TypeError("ConditionalAnimationPipeline samples from the first timestep (ddim_init_latents_t_idx is the editing pipeline's)")
+        return super().__call__(*args, **kwargs)
+
+    def invert(self, *args, **kwargs):
+        raise AttributeError("invert is ConditionalVideoEditingPipeline's")
+
+    def sample_with_pnp(self, *args, **kwargs):
+        raise AttributeError("sample_with_pnp is ConditionalVideoEditingPipeline's")
+
+
+class AutoregressiveAnimationPipeline(ConditionalAnimationPipeline):
+    """Long clips, chunk by chunk (``pipeline_autoregress_animation.py:401-615``): ``autoregress_steps`` samplings of ``video_length``
+    frames, each from fresh noise of the one generator, each conditioned on (and, with FrameInit, laid out after) the LAST latent frame
+    of the chunk before; chunks overlap by that frame, so the result has ``video_length * n - n + 1`` frames, decoded in one go."""
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale_txt: float = 7.5, guidance_scale_img: float = 2.0,
+                 negative_prompt=None, num_videos_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "tensor", return_dict: bool = True, callback=None,
+                 callback_steps: Optional[int] = 1, first_frame_paths=None, first_frames=None, noise_sampling_method: str = "vanilla",
+                 noise_alpha: float = 1.0, guidance_rescale: float = 0.0, frame_stride: Optional[int] = None, autoregress_steps: int = 3,
+                 use_frameinit: bool = False, frameinit_noise_level: int = 999, **kwargs):
+        if kwargs.get("ddim_init_latents_t_idx", 0) or kwargs.get("camera_motion") is not None:
+            raise TypeError("AutoregressiveAnimationPipeline has no ddim_init_latents_t_idx / camera_motion (the reference's **kwargs would drop them)")
+        height, width = self._common(prompt, height, width, callback_steps, first_frame_paths, first_frames, latents, num_videos_per_prompt,
+                                     eta, guidance_rescale, use_frameinit, None)
+        self._video_length = video_length
+        device = self._execution_device
+        mode = self._guidance_mode(guidance_scale_txt, guidance_scale_img)
+        c2.clear_time(self)
+        text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, mode, negative_prompt)
+        if first_frame_paths is None and first_frames is None:
+            raise NotImplementedError("sampling without a first frame (first_frame_condition_mode 'none')")
+        clean = self._first_frame_latent(first_frames if first_frame_paths is None else self._one(first_frame_paths, "first frames"),
+                                         height, width, True, device)
+        chunks = [clean.unsqueeze(2).to(torch.float16)]
+        for _ in range(int(autoregress_steps)):
+            x = self._sample(clean, latents, text_embeddings, mode, video_length, height, width, num_inference_steps, 0, generator,
+                             noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride, guidance_scale_img,
+                             guidance_scale_txt, self._callback(callback, callback_steps))
+            chunks.append(x)
+            clean, latents = x[:, :, -1].to(clean.dtype), None     # (``:599-603``: given start latents serve the first chunk only)
+        full = torch.cat(chunks, dim=2)
+        return self._finish(full[:, :, 1:], full[:, :, 0], output_type, return_dict)
 
 
 def _first(v):

@@ -95,8 +95,11 @@ class _Normalize:
 
 
 # ----------------------------------------------------------------------------------------------- module loading
-def load_reference_consisti2v_pipeline():
-    """(pipeline module, unet module, pnp_utils module, utils module) -- everything from the reference's ``consisti2v/`` tree."""
+def load_reference_consisti2v_pipeline(name="pipeline_video_editing"):
+    """(pipeline module, unet module, pnp_utils module, utils module) -- everything from the reference's ``consisti2v/`` tree.
+    ``name``: the file under ``consisti2v/consisti2v/pipelines/`` (``pipeline_conditional_animation``,
+    ``pipeline_autoregress_animation`` -- that one imports ``..models.unet``, a module the reference does not have: the name is bound
+    to the VideoLDM UNet, the only class its ``__init__`` annotates with)."""
     import PIL.Image
     import transformers  # noqa: F401  (the pipeline file imports CLIP class names from the real package)
 
@@ -158,15 +161,16 @@ def load_reference_consisti2v_pipeline():
             p.__path__ = []
             sys.modules[pkg + sub] = p
         sys.modules[pkg + ".models.videoldm_unet"] = unet_mod
+        sys.modules[pkg + ".models.unet"] = types.SimpleNamespace(UNet3DConditionModel=unet_mod.VideoLDMUNet3DConditionModel)
         spec = importlib.util.spec_from_file_location(pkg + ".utils.frameinit_utils",
                                                       os.path.join(root, "consisti2v", "utils", "frameinit_utils.py"))
         fi = importlib.util.module_from_spec(spec)
         sys.modules[pkg + ".utils.frameinit_utils"] = fi
         spec.loader.exec_module(fi)
-        spec = importlib.util.spec_from_file_location(pkg + ".pipelines.pipeline_video_editing",
-                                                      os.path.join(root, "consisti2v", "pipelines", "pipeline_video_editing.py"))
+        spec = importlib.util.spec_from_file_location(pkg + ".pipelines." + name,
+                                                      os.path.join(root, "consisti2v", "pipelines", name + ".py"))
         pm = importlib.util.module_from_spec(spec)
-        sys.modules[pkg + ".pipelines.pipeline_video_editing"] = pm
+        sys.modules[pkg + ".pipelines." + name] = pm
         spec.loader.exec_module(pm)
     finally:
         for k in set(sys.modules) - before:
@@ -223,14 +227,17 @@ class ForwardDDIM:
         return types.SimpleNamespace(prev_sample=(a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps).to(sample.dtype))
 
 
-def build_reference_pipeline(unet, dim):
-    """The reference's ``ConditionalVideoEditingPipeline`` (its real ``__init__``) around a reference UNet and the toy components.
-    Returns (pipeline, pipeline module, pnp_utils module, inverse-scheduler module)."""
-    pm, unet_mod, pnp, utils = load_reference_consisti2v_pipeline()
+_PIPELINE_FILES = {"ConditionalVideoEditingPipeline": "pipeline_video_editing", "ConditionalAnimationPipeline": "pipeline_conditional_animation",
+                   "AutoregressiveAnimationPipeline": "pipeline_autoregress_animation"}
+
+
+def build_reference_pipeline(unet, dim, cls="ConditionalVideoEditingPipeline"):
+    """The reference's ``ConditionalVideoEditingPipeline`` (or one of its two animation pipelines; its real ``__init__``) around a
+    reference UNet and the toy components.  Returns (pipeline, pipeline module, pnp_utils module, inverse-scheduler module)."""
+    pm, unet_mod, pnp, utils = load_reference_consisti2v_pipeline(_PIPELINE_FILES[cls])
     inv_mod = ref_stubs.load_reference_inverse_scheduler()
     inv = inv_mod.DDIMInverseScheduler(**SCHED_CFG)
-    pipe = pm.ConditionalVideoEditingPipeline(vae=ToyVAE(), text_encoder=rp.ToyTextEncoder(dim), tokenizer=rp.ToyTokenizer(), unet=unet,
-                                              scheduler=inv)
+    pipe = getattr(pm, cls)(vae=ToyVAE(), text_encoder=rp.ToyTextEncoder(dim), tokenizer=rp.ToyTokenizer(), unet=unet, scheduler=inv)
     return pipe, pm, pnp, inv_mod
 
 

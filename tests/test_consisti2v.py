@@ -455,6 +455,68 @@ def test_native_consisti2v_camera_motion_with_frameinit_vs_the_reference_pipelin
     assert ok, err
 
 
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("cls", ["ConditionalAnimationPipeline", "AutoregressiveAnimationPipeline"])
+def test_native_consisti2v_animation_pipelines_vs_the_references_own_classes(monkeypatch, tmp_path, cls):
+    """ConsistI2V's two samplers next to the editing pipeline (``pipeline_conditional_animation.py:462-703``,
+    ``pipeline_autoregress_animation.py:401-615``), their files imported verbatim: a first frame of ANOTHER aspect ratio (Resize(height) +
+    CenterCrop), text + image guidance (three rows, the image-unconditional one on the noisy first frame), FrameInit, pyoco noise; the
+    autoregressive one two chunks long (the second conditioned on the last latent frame of the first, fresh noise of the same generator)."""
+    import types
+    warnings.filterwarnings("ignore")
+    from PIL import Image
+    from anyv2v_amd import consisti2v as c2
+    from anyv2v_amd import consisti2v_pipeline as cp
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMScheduler
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    j = spec.PIPE_JOB
+    frames, _ = spec.pipeline_frames()
+    first = str(tmp_path / "first.png")
+    frames[0].resize((j["width"] + 40, j["height"] + 8), resample=Image.BICUBIC).save(first)
+    fp = types.SimpleNamespace(method="butterworth", n=4, d_s=0.25, d_t=0.25)
+    kw = dict(prompt="a robot", first_frame_paths=first, height=j["height"], width=j["width"], video_length=j["frames"], num_inference_steps=2,
+              guidance_scale_txt=3.0, guidance_scale_img=1.5, negative_prompt="blurry", frame_stride=3, noise_sampling_method="pyoco_progressive",
+              noise_alpha=0.7, use_frameinit=True, frameinit_noise_level=900)
+    n_frames = j["frames"]
+    if cls == "AutoregressiveAnimationPipeline":
+        kw["autoregress_steps"] = 2
+        n_frames = 2 * j["frames"] - 1
+    unet_mod, _, _ = ref_stubs.load_reference_consisti2v_unet()
+    ref_unet = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).eval()
+    ref, pm, pnp, inv_mod = rcp.build_reference_pipeline(ref_unet, 48, cls)
+    assert type(ref).__name__ == cls and not hasattr(ref, "invert")
+    ref.scheduler = rcp.ForwardDDIM(ref.scheduler)
+    ref.init_filter(j["frames"], j["height"], j["width"], fp)
+    cap = []
+    orig = ref.decode_latents
+    ref.decode_latents = lambda lat, *a, **k: (cap.append(lat.detach().clone()), orig(lat, *a, **k))[1]
+    with torch.no_grad():
+        ref_video = ref(generator=torch.Generator().manual_seed(5), **kw).videos
+    assert cap[-1].shape[2] == n_frames
+    emu.install(monkeypatch)
+    tok = rp.ToyTokenizer()
+    nat = getattr(cp, cls)(vae=spec.ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(48), tok), tokenizer=tok,
+                           unet=spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)),
+                           scheduler=DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG))
+    nat.init_filter(j["frames"], j["height"], j["width"], fp)
+    got = nat(generator=torch.Generator().manual_seed(5), output_type="latent", **kw).videos
+    assert got.shape == cap[-1].shape
+    ok, err = _close(got[:, :, 0], cap[-1][:, :, 0], 2e-3)      # the cropped first frame's latent
+    assert ok, err
+    ok, err = _close(got, cap[-1], 3e-2)
+    assert ok, err
+    video = nat(generator=torch.Generator().manual_seed(5), **kw).videos
+    assert tuple(video.shape) == tuple(ref_video.shape)
+    ok, err = _close(video, ref_video, 3e-2)
+    assert ok, err
+    with pytest.raises(TypeError):
+        nat(generator=torch.Generator().manual_seed(5), ddim_init_latents_t_idx=1, **kw)
+    with pytest.raises(AttributeError):
+        nat.invert(prompt="", video_length=j["frames"])
+
+
 def test_camera_motion_zoom_out_cuts_growing_windows():
     from anyv2v_amd.consisti2v_pipeline import camera_motion_frames
     x = torch.arange(3 * 90 * 120, dtype=torch.float32).view(3, 90, 120) / 1000
