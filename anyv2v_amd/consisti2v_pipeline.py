@@ -17,8 +17,9 @@ Kept from the reference because a drop-in must produce the same numbers:
   the UNet denoises ``video_length - 1`` frames and sees the clean first-frame latent as frame 0.
 
 ``use_frameinit`` (FFT noise re-initialisation, ``frameinit_utils.py``) is built (``init_filter``, host-side FFT once per clip).
-``camera_motion`` (pan / zoom pseudo clips for FrameInit) is built as well.  Not built (the AnyV2V runners never enable them):
-``guidance_rescale > 0``, ``eta > 0``, several clips per call, PnP with image guidance or without text guidance
+``camera_motion`` (pan / zoom pseudo clips for FrameInit) is built as well, and so are ``guidance_rescale`` (text guidance) and
+``eta`` (forward DDIM scheduler).  Not built (the AnyV2V runners never need them): several clips per call
+(``num_videos_per_prompt``, prompt lists), PnP with image guidance or without text guidance
 (the reference's hooks split the batch in three: ``consisti2v/pnp_utils.py:96,188,296``).
 """
 from __future__ import annotations
@@ -399,8 +400,8 @@ class ConditionalVideoEditingPipeline:
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps, first_frame_paths)
-        if guidance_rescale > 0.0 or eta != 0.0 or num_videos_per_prompt != 1:
-            raise NotImplementedError("guidance_rescale / eta / num_videos_per_prompt are not built (the AnyV2V runners leave them off)")
+        if num_videos_per_prompt != 1:
+            raise NotImplementedError("num_videos_per_prompt > 1 is not built (the AnyV2V runners leave it at 1)")
         self._camera_motion = camera_motion
         if first_frames is not None and (not torch.is_tensor(first_frames) or first_frames.dim() != 4 or first_frames.shape[0] != 1):
             raise NotImplementedError("first_frames: one pre-processed frame [1, 3, H, W] in [-1, 1] per call")
@@ -408,16 +409,23 @@ class ConditionalVideoEditingPipeline:
             raise NotImplementedError(f"one clip per call: latents batch {latents.shape[0]}")
         return height, width
 
-    def _denoise(self, latents, ff_input, text_embeddings, timesteps, frame_stride, branches, g_img, g_txt, source=None, on_step=None):
+    def _denoise(self, latents, ff_input, text_embeddings, timesteps, frame_stride, branches, g_img, g_txt, source=None, on_step=None,
+                 eta=0.0, generator=None, guidance_rescale=0.0):
         """``latents`` [1, C, F - 1, h, w]; ``ff_input`` [nb, C, 1, h, w]; ``branches`` = (b_unc, b_img, b_txt) of the guided rows;
         ``source(t)`` -> the source branch's latents at t (PnP: row 0 of the batch).
 
         One step = the UNet forward over all rows (static input buffers, ``_StepGraphs``) + one guided-step kernel.  The forward can
-        be replayed as a HIP graph per injection state (ANYV2V_CONSISTI2V_GRAPHS=1); measured, that does not pay for this family."""
+        be replayed as a HIP graph per injection state (ANYV2V_CONSISTI2V_GRAPHS=1); measured, that does not pay for this family.
+
+        Two options no AnyV2V runner switches on: ``guidance_rescale`` (``:50-61,685-688``: the guided prediction rescaled towards the
+        standard deviation of the text branch; a few torch reductions per step, then the step kernel on the combined prediction) and
+        ``eta`` (``:373-388``: handed to a scheduler whose step takes it, i.e. the forward DDIM scheduler; the variance noise comes
+        from ``generator``)."""
         nb = ff_input.shape[0]
         n_guided = nb - (1 if source is not None else 0)
         latents = latents.to(torch.float16).contiguous()
         pred = self.scheduler.prediction
+        stochastic = eta != 0.0 and isinstance(self.scheduler, DDIMScheduler)   # (``prepare_extra_step_kwargs``: only a step that takes eta gets it)
         eng = self._step_graphs(nb, latents, text_embeddings, frame_stride)
         eng.ehs.copy_(text_embeddings)
         eng.ff.copy_(ff_input)
@@ -430,8 +438,21 @@ class ConditionalVideoEditingPipeline:
                 eng.x[b].copy_(latents[0])
             eng.t_buf.fill_(float(t))
             e = eng.run(c2.injection_state(self) if source is not None else None)
-            latents = ops.guided_step(e, latents, self.scheduler.coefficients(t), b_unc=branches[0], b_img=branches[1], b_txt=branches[2],
-                                      g_img=g_img, g_txt=g_txt, prediction=pred)
+            b_unc, b_img, b_txt, gi, gt = branches[0], branches[1], branches[2], g_img, g_txt
+            if guidance_rescale > 0.0 and b_unc >= 0:
+                if b_img >= 0:
+                    raise NotImplementedError("guidance_rescale under image guidance (the reference reads an unbound name there: text guidance only)")
+                eu, et = e[b_unc].float(), e[b_txt].float()
+                cfg = eu + g_txt * (et - eu)
+                cfg = cfg * (guidance_rescale * (et.std() / cfg.std()) + (1.0 - guidance_rescale))
+                e, b_unc, b_txt, gt = cfg.to(torch.float16)[None].contiguous(), -1, 0, 1.0
+            if stochastic:
+                sa_t, sb_t, cx, ce, sigma = self.scheduler.eta_coefficients(t, eta)
+                latents = ops.guided_step(e, latents, (sa_t, sb_t, cx, ce), b_unc=b_unc, b_img=b_img, b_txt=b_txt, g_img=gi, g_txt=gt,
+                                          prediction=pred, noise=self.scheduler.draw_noise(latents, generator).contiguous(), sigma=sigma)
+            else:
+                latents = ops.guided_step(e, latents, self.scheduler.coefficients(t), b_unc=b_unc, b_img=b_img, b_txt=b_txt, g_img=gi,
+                                          g_txt=gt, prediction=pred)
             if on_step is not None:
                 on_step(step_i, t, latents)
         return latents
@@ -486,7 +507,8 @@ class ConditionalVideoEditingPipeline:
     _crop_first_frame = False     # (``pipeline_video_editing.py:588-589``: plain Resize((height, width)); the animation pipelines crop)
 
     def _sample(self, clean, latents, text_embeddings, mode, video_length, height, width, num_inference_steps, t_idx, generator,
-                noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride, g_img, g_txt, on_step):
+                noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride, g_img, g_txt, on_step, eta=0.0,
+                guidance_rescale=0.0):
         """Timesteps, start latents (given, or drawn; FrameInit), first-frame rows, the guided loop (``:603-704``) -> [1, C, F - 1, h, w]."""
         device = self._execution_device
         self.scheduler.set_timesteps(num_inference_steps, device=device)
@@ -498,7 +520,7 @@ class ConditionalVideoEditingPipeline:
         noisy, latents = latents[:, :, 0], latents[:, :, 1:]
         ff = torch.cat(self._ff_rows(mode, clean, noisy)).unsqueeze(2)
         return self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode), g_img, g_txt,
-                             on_step=on_step)
+                             on_step=on_step, eta=eta, generator=generator, guidance_rescale=guidance_rescale)
 
     # ------------------------------------------------------------------ ``__call__`` (:469-711)
     @torch.no_grad()
@@ -522,7 +544,7 @@ class ConditionalVideoEditingPipeline:
                                          height, width, self._crop_first_frame, device)
         latents = self._sample(clean, latents, text_embeddings, mode, video_length, height, width, num_inference_steps, ddim_init_latents_t_idx,
                                generator, noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride,
-                               guidance_scale_img, guidance_scale_txt, self._callback(callback, callback_steps))
+                               guidance_scale_img, guidance_scale_txt, self._callback(callback, callback_steps), eta, guidance_rescale)
         return self._finish(latents, clean, output_type, return_dict)
 
     # ------------------------------------------------------------------ ``invert`` (:715-968)
@@ -565,7 +587,7 @@ class ConditionalVideoEditingPipeline:
             if cb is not None:
                 cb(i, t, x)
         latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode),
-                                guidance_scale_img, guidance_scale_txt, on_step=keep)
+                                guidance_scale_img, guidance_scale_txt, on_step=keep, guidance_rescale=guidance_rescale)
         ts = [int(t) for t in self.scheduler.timesteps]
         if output_dir is not None:
             traj.save(output_dir, background=background_save)
@@ -628,7 +650,8 @@ class ConditionalVideoEditingPipeline:
         try:
             latents = self._denoise(latents, ff, text_embeddings, self.scheduler.timesteps, frame_stride, self._branches(mode, 1),
                                     guidance_scale_img, guidance_scale_txt, source=source,
-                                    on_step=self._callback(callback, callback_steps))
+                                    on_step=self._callback(callback, callback_steps), eta=eta, generator=generator,
+                                    guidance_rescale=guidance_rescale)
         finally:
             c2.clear_time(self)
         return self._finish(latents, clean, output_type, return_dict)
@@ -682,7 +705,7 @@ class AutoregressiveAnimationPipeline(ConditionalAnimationPipeline):
         for _ in range(int(autoregress_steps)):
             x = self._sample(clean, latents, text_embeddings, mode, video_length, height, width, num_inference_steps, 0, generator,
                              noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride, guidance_scale_img,
-                             guidance_scale_txt, self._callback(callback, callback_steps))
+                             guidance_scale_txt, self._callback(callback, callback_steps), eta, guidance_rescale)
             chunks.append(x)
             clean, latents = x[:, :, -1].to(clean.dtype), None     # (``:599-603``: given start latents serve the first chunk only)
         full = torch.cat(chunks, dim=2)

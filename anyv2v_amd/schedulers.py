@@ -139,6 +139,9 @@ class _DDIMBase:
     def coefficients(self, timestep: int):
         raise NotImplementedError
 
+    def eta_coefficients(self, timestep: int, eta: float):
+        raise NotImplementedError(f"eta > 0 is the forward DDIM scheduler's option, not {type(self).__name__}'s")
+
     def coefficient_table(self, timesteps, device) -> torch.Tensor:
         """[len(timesteps), 4] fp32 device table {sqrt(a_t), sqrt(1-a_t), sqrt(a_p), sqrt(1-a_p)} for the fused step."""
         rows = [self.coefficients(int(t)) for t in timesteps]
@@ -149,7 +152,13 @@ class _DDIMBase:
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         if eta != 0.0:
-            raise NotImplementedError("eta > 0 (stochastic DDIM) is not used by AnyV2V and not implemented")
+            # stochastic DDIM (Song et al. eq. 12/16; unused by AnyV2V's runners): x' = sqrt(a_p) x0 + sqrt(1 - a_p - s^2) eps + s n
+            sa_t, sb_t, cx, ce, sigma = self.eta_coefficients(int(timestep), eta)
+            e = model_output.to(torch.float16).contiguous()
+            noise = variance_noise if variance_noise is not None else self.draw_noise(e, generator)
+            prev = ops.guided_step(e.view(1, -1), sample.to(torch.float16).contiguous(), (sa_t, sb_t, cx, ce), b_txt=0,
+                                   prediction=self.prediction, noise=noise.to(e).contiguous(), sigma=sigma)
+            return SchedulerOutput(prev) if return_dict else (prev,)
         sa_t, sb_t, sa_p, sb_p = self.coefficients(int(timestep))
         if self.prediction == ops.PRED_V:
             prev = ops.ddim_step(model_output, sample, sa_t, sb_t, sa_p, sb_p)
@@ -177,6 +186,21 @@ class DDIMScheduler(_DDIMBase):
         prev = timestep - self._ratio()
         a_t, a_p = self._abar(timestep), self._abar(prev)
         return (math.sqrt(a_t), math.sqrt(1.0 - a_t), math.sqrt(a_p), math.sqrt(1.0 - a_p))
+
+    def eta_coefficients(self, timestep: int, eta: float):
+        """(sa_t, sb_t, c_x0, c_eps, sigma) of ``ops.guided_step(..., noise=, sigma=)`` for ``eta > 0``: sigma = eta sqrt((1 - a_p) /
+        (1 - a_t)) sqrt(1 - a_t / a_p), c_eps = sqrt(1 - a_p - sigma^2) (pinned to ``seine/diffusion/gaussian_diffusion.py:583-599``)."""
+        prev = timestep - self._ratio()
+        a_t, a_p = self._abar(timestep), self._abar(prev)
+        sigma = float(eta) * math.sqrt((1.0 - a_p) / (1.0 - a_t)) * math.sqrt(max(1.0 - a_t / a_p, 0.0))
+        return (math.sqrt(a_t), math.sqrt(1.0 - a_t), math.sqrt(a_p), math.sqrt(max(1.0 - a_p - sigma * sigma, 0.0)), sigma)
+
+    noise_on_host = True    # eta > 0: the variance noise is drawn on the host (a seed means the same sample on any device)
+
+    def draw_noise(self, like: torch.Tensor, generator=None):
+        if self.noise_on_host or (generator is not None and generator.device.type == "cpu"):
+            return torch.randn(like.shape, generator=generator, dtype=torch.float32).to(device=like.device, dtype=like.dtype)
+        return torch.randn(like.shape, generator=generator, device=like.device, dtype=like.dtype)
 
 
 class DDIMInverseScheduler(_DDIMBase):

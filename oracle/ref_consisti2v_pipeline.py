@@ -211,7 +211,9 @@ class ForwardDDIM:
         return (a.sqrt() * original_samples.double() + (1 - a).sqrt() * noise.double()).to(original_samples.dtype)
 
     def step(self, model_output, timestep, sample, eta=0.0, generator=None):
-        assert eta == 0.0
+        """``eta > 0``: diffusers' variance ``(1 - a_prev) / (1 - a_t) (1 - a_t / a_prev)``, direction ``sqrt(1 - a_prev - s^2) eps``,
+        noise of the model output's shape from ``generator`` (``randn_tensor``) -- the formula of
+        ``seine/diffusion/gaussian_diffusion.py:583-599``, which ``tests/test_consisti2v.py`` pins this stand-in to."""
         t = int(timestep)
         prev = t - self.config.num_train_timesteps // self.n
         a_t = self.ac[t]
@@ -224,6 +226,10 @@ class ForwardDDIM:
             x0, eps = a_t.sqrt() * x - (1 - a_t).sqrt() * e, a_t.sqrt() * e + (1 - a_t).sqrt() * x
         else:
             raise NotImplementedError(pt)
+        if eta:
+            s = eta * ((1 - a_p) / (1 - a_t)).sqrt() * (1 - a_t / a_p).sqrt()
+            noise = torch.randn(model_output.shape, generator=generator, dtype=torch.float32).double()
+            return types.SimpleNamespace(prev_sample=(a_p.sqrt() * x0 + (1 - a_p - s * s).clamp(min=0).sqrt() * eps + s * noise).to(sample.dtype))
         return types.SimpleNamespace(prev_sample=(a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps).to(sample.dtype))
 
 

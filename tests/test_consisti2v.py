@@ -517,6 +517,73 @@ def test_native_consisti2v_animation_pipelines_vs_the_references_own_classes(mon
         nat.invert(prompt="", video_length=j["frames"])
 
 
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("eta", [0.0, 0.5])
+def test_native_consisti2v_guidance_rescale_and_eta_vs_the_reference_pipeline(monkeypatch, tmp_path, eta):
+    """``guidance_rescale`` (``pipeline_video_editing.py:50-61,685-688``) and ``eta`` (``:373-388`` -> the scheduler's step; the variance
+    noise from the call's generator, after the start noise) through ``__call__`` under text guidance -- reference class vs native."""
+    warnings.filterwarnings("ignore")
+    from anyv2v_amd import consisti2v as c2
+    from anyv2v_amd.consisti2v_pipeline import ConditionalVideoEditingPipeline
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMScheduler
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    j = spec.PIPE_JOB
+    frames, _ = spec.pipeline_frames()
+    first = str(tmp_path / "first.png")
+    frames[0].resize((j["width"], j["height"])).save(first)
+    kw = dict(prompt="a robot", first_frame_paths=first, height=j["height"], width=j["width"], video_length=j["frames"], num_inference_steps=3,
+              guidance_scale_txt=6.0, guidance_scale_img=1.0, negative_prompt="blurry", frame_stride=3, guidance_rescale=0.7, eta=eta)
+    unet_mod, _, _ = ref_stubs.load_reference_consisti2v_unet()
+    ref_unet = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).eval()
+    ref, pm, pnp, inv_mod = rcp.build_reference_pipeline(ref_unet, 48)
+    ref.scheduler = rcp.ForwardDDIM(ref.scheduler)
+    cap = []
+    orig = ref.decode_latents
+    ref.decode_latents = lambda lat, *a, **k: (cap.append(lat.detach().clone()), orig(lat, *a, **k))[1]
+    with torch.no_grad():
+        ref(generator=torch.Generator().manual_seed(3), **kw)
+        plain = dict(kw, guidance_rescale=0.0, eta=0.0)
+        ref(generator=torch.Generator().manual_seed(3), **plain)
+    assert (cap[0] - cap[1]).abs().max() > 0.05                 # the options do something at this size
+    emu.install(monkeypatch)
+    tok = rp.ToyTokenizer()
+    nat = ConditionalVideoEditingPipeline(vae=spec.ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(48), tok), tokenizer=tok,
+                                          unet=spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)),
+                                          scheduler=DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG))
+    got = nat(generator=torch.Generator().manual_seed(3), output_type="latent", **kw).videos
+    ok, err = _close(got, cap[0], 3e-2)
+    assert ok, err
+    with pytest.raises(NotImplementedError):                    # (the reference raises NameError there)
+        nat(generator=torch.Generator().manual_seed(3), output_type="latent", **dict(kw, guidance_scale_img=2.0))
+
+
+def test_ddim_scheduler_step_with_eta_draws_from_the_generator(monkeypatch):
+    """``DDIMScheduler.step(eta=)``: the coefficients of ``eta_coefficients`` + variance noise from ``generator`` (or ``variance_noise``);
+    the inverse scheduler refuses eta."""
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMInverseScheduler, DDIMScheduler
+    emu.install(monkeypatch)
+    sched = DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG)
+    sched.set_timesteps(10)
+    g = torch.Generator().manual_seed(1)
+    x, e = torch.randn(1, 4, 3, 4, 4, generator=g).half(), torch.randn(1, 4, 3, 4, 4, generator=g).half()
+    t = int(sched.timesteps[3])
+    sa_t, sb_t, cx, ce, sigma = sched.eta_coefficients(t, 0.8)
+    assert sigma > 0 and abs(cx ** 2 + ce ** 2 + sigma ** 2 - 1.0) < 1e-6
+    n = torch.randn(e.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float32)
+    want = cx * (x.float() - sb_t * e.float()) / sa_t + ce * e.float() + sigma * n.half().float()
+    got = sched.step(e, t, x, eta=0.8, generator=torch.Generator().manual_seed(5)).prev_sample
+    assert torch.allclose(got.float(), want, atol=4e-3)
+    got2 = sched.step(e, t, x, eta=0.8, variance_noise=n).prev_sample
+    assert torch.equal(got, got2)
+    assert torch.equal(sched.step(e, t, x).prev_sample, sched.step(e, t, x, eta=0.0).prev_sample)
+    inv = DDIMInverseScheduler(**CONSISTI2V_SCHEDULER_CONFIG)
+    inv.set_timesteps(10)
+    with pytest.raises(NotImplementedError):
+        inv.step(e, int(inv.timesteps[2]), x, eta=0.5)
+
+
 def test_camera_motion_zoom_out_cuts_growing_windows():
     from anyv2v_amd.consisti2v_pipeline import camera_motion_frames
     x = torch.arange(3 * 90 * 120, dtype=torch.float32).view(3, 90, 120) / 1000
@@ -560,6 +627,19 @@ def test_epsilon_forward_ddim_step_is_pinned_to_the_references_gaussian_diffusio
             prod = sa_p * (x - sb_t * e) / sa_t + sb_p * e
             assert torch.allclose(prod, ref, rtol=2e-4, atol=2e-5), ("product", t)
             assert torch.allclose(fwd.step(e, t, x).prev_sample, ref, rtol=2e-4, atol=2e-5), ("harness stand-in", t)
+            # eta > 0 (``gaussian_diffusion.py:583-599``; its noise is ``randn_like`` of the global RNG: same seed, same draw)
+            torch.manual_seed(40 + i)
+            ref = diff.ddim_sample(lambda xx, tt: e, x, torch.tensor([i, i]), clip_denoised=False, eta=0.6)["sample"]
+            torch.manual_seed(40 + i)
+            noise = torch.randn_like(x)
+            sa_t, sb_t, cx, ce, sigma = sched.eta_coefficients(t, 0.6)
+            prod = cx * (x - sb_t * e) / sa_t + ce * e + (sigma * noise if i else 0.0)
+            assert torch.allclose(prod, ref, rtol=2e-4, atol=2e-5), ("product, eta", t)
+            if i:       # (at the last step diffusers still adds s * n; s = 0 there with alpha_prev = 1, not with this family's final alpha)
+                g2 = torch.Generator().manual_seed(9)
+                n2 = torch.randn(e.shape, generator=torch.Generator().manual_seed(9), dtype=torch.float32).double()
+                want = cx * (x - sb_t * e) / sa_t + ce * e + sigma * n2
+                assert torch.allclose(fwd.step(e, t, x, eta=0.6, generator=g2).prev_sample, want, rtol=2e-4, atol=2e-5), ("harness stand-in, eta", t)
     finally:
         for k in [k for k in sys.modules if k.startswith("_ref_seine_diffusion3")]:
             del sys.modules[k]
