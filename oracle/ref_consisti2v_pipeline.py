@@ -315,3 +315,26 @@ def run_reference_job(unet_cfg, fill_weights, frames, edited, height, width, n_i
                 rec_lat=rec_lat, edit_video=edit_video, edit_lat=edit_lat, out_dir=out_dir, first_path=first_path, edited_path=edited_path,
                 frames_dir=fdir, neg=neg, edit_prompt=edit_prompt, ratios=tuple(ratios), n_steps=n_steps, n_inv_steps=n_inv_steps,
                 t_idx=t_idx, cfg_txt=cfg_txt, frame_stride=frame_stride)
+
+
+@torch.no_grad()
+def run_reference_sampling(unet_cfg, fill_weights, cases, first_frame, filter_params, seed, work_dir):
+    """``cases``: {name: (pipeline class name, call kwargs)} -- each class of ``_PIPELINE_FILES`` (its own file, imported verbatim)
+    sampling from a seeded generator with ``first_frame`` (a PIL image, written as PNG: the pipelines open paths); FrameInit cases get
+    ``init_filter(filter_params)``.  Returns {name: the latents handed to ``decode_latents``}."""
+    unet_mod, _, _ = ref_stubs.load_reference_consisti2v_unet()
+    path = os.path.join(str(work_dir), "first_frame.png")
+    first_frame.save(path)
+    out = {}
+    for name, (cls, kw) in cases.items():
+        unet = fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**unet_cfg)).eval()
+        pipe, _, _, _ = build_reference_pipeline(unet, unet_cfg["cross_attention_dim"], cls)
+        pipe.scheduler = ForwardDDIM(pipe.scheduler)
+        if kw.get("use_frameinit"):
+            pipe.init_filter(kw["video_length"], kw["height"], kw["width"], types.SimpleNamespace(**filter_params))
+        cap = []
+        orig = pipe.decode_latents
+        pipe.decode_latents = lambda lat, *a, _o=orig, _c=cap, **k: (_c.append(lat.detach().clone()), _o(lat, *a, **k))[1]
+        pipe(first_frame_paths=path, generator=torch.Generator().manual_seed(seed), **kw)
+        out[name] = cap[-1]
+    return out

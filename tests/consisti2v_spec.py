@@ -257,3 +257,59 @@ def native_pipeline_job(device, trajectory_from=None, work_dir=None):
     out["edit_video"] = pipe.sample_with_pnp(latents=traj[t0].clone(), output_type="tensor", **common).videos
     out["pipe"] = pipe
     return out
+
+
+# ------------------------------------------------------------------------------------------------- sampling cases (consisti2v_sampling.pt)
+# the samplers / options next to the two runner stages: both animation pipelines and guidance_rescale + eta, from seeded noise
+SAMPLING_SEED = 5
+
+
+def sampling_cases():
+    """{name: (pipeline class name, call kwargs without the first frame / generator)}."""
+    j = PIPE_JOB
+    base = dict(prompt="a robot", height=j["height"], width=j["width"], video_length=j["frames"], num_inference_steps=2, negative_prompt="blurry",
+                frame_stride=3)
+    anim = dict(base, guidance_scale_txt=3.0, guidance_scale_img=1.5, noise_sampling_method="pyoco_progressive", noise_alpha=0.7,
+                use_frameinit=True, frameinit_noise_level=900)
+    return {"animation": ("ConditionalAnimationPipeline", anim),
+            "autoregressive": ("AutoregressiveAnimationPipeline", dict(anim, autoregress_steps=2)),
+            "rescale_eta": ("ConditionalVideoEditingPipeline", dict(base, num_inference_steps=3, guidance_scale_txt=6.0, guidance_scale_img=1.0,
+                                                                    guidance_rescale=0.7, eta=0.5))}
+
+
+SAMPLING_FILTER = dict(method="butterworth", n=4, d_s=0.25, d_t=0.25)
+
+
+def sampling_first_frame():
+    """A first frame of another aspect ratio than the target (the animation pipelines resize the short side and centre-crop)."""
+    from PIL import Image
+    j = PIPE_JOB
+    frames, _ = pipeline_frames()
+    return frames[0].resize((j["width"] + 40, j["height"] + 8), resample=Image.BICUBIC)
+
+
+def native_sampling(device, names=None):
+    """Every sampling case on the native pipelines -> {name: latents [1, 4, F', h, w]}."""
+    import types
+    from anyv2v_amd import consisti2v as c2
+    from anyv2v_amd import consisti2v_pipeline as cp
+    from anyv2v_amd.schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMScheduler
+    from hf_clip_reference import HFTextEncoder
+    from oracle import ref_consisti2v_pipeline as rcp
+    from oracle import ref_pipeline as rp
+    j = PIPE_JOB
+    dim = UNET_CFG["cross_attention_dim"]
+    unet = fill_weights(c2.VideoLDMUNet3DConditionModel(**UNET_CFG)).to(device)
+    tok = rp.ToyTokenizer()
+    first = sampling_first_frame()
+    out = {}
+    for name, (cls, kw) in sampling_cases().items():
+        if names is not None and name not in names:
+            continue
+        pipe = getattr(cp, cls)(vae=ToyVaeAdapter(rcp.ToyVAE()), text_encoder=HFTextEncoder(rp.ToyTextEncoder(dim), tok), tokenizer=tok,
+                                unet=unet, scheduler=DDIMScheduler(**CONSISTI2V_SCHEDULER_CONFIG))
+        pipe._device = torch.device(device)
+        if kw.get("use_frameinit"):
+            pipe.init_filter(j["frames"], j["height"], j["width"], types.SimpleNamespace(**SAMPLING_FILTER))
+        out[name] = pipe(first_frame_paths=first, generator=torch.Generator().manual_seed(SAMPLING_SEED), output_type="latent", **kw).videos
+    return out

@@ -283,6 +283,24 @@ def gen_consisti2v_pipeline():
           float((fx["edit_lat"].float() - fx["rec_lat"].float()).abs().max()))
 
 
+def gen_consisti2v_sampling():
+    """``consisti2v_sampling.pt`` (``--consisti2v-sampling``): the reference's ``ConditionalAnimationPipeline``,
+    ``AutoregressiveAnimationPipeline`` and (with ``guidance_rescale`` + ``eta``) ``ConditionalVideoEditingPipeline`` classes sampling
+    from seeded noise -- ``tests/consisti2v_spec.sampling_cases``."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import consisti2v_spec as spec
+    from oracle import ref_consisti2v_pipeline as rcp
+    with tempfile.TemporaryDirectory() as tmp:
+        got = rcp.run_reference_sampling(spec.UNET_CFG, spec.fill_weights, spec.sampling_cases(), spec.sampling_first_frame(),
+                                         spec.SAMPLING_FILTER, spec.SAMPLING_SEED, tmp)
+    fx = {k: v.detach().to(torch.float16).contiguous() for k, v in got.items()}
+    fx["spec"] = dict(cases={k: [c, dict(kw)] for k, (c, kw) in spec.sampling_cases().items()}, seed=spec.SAMPLING_SEED,
+                      filter=dict(spec.SAMPLING_FILTER))
+    torch.save(fx, os.path.join(HERE, "consisti2v_sampling.pt"))
+    print("consisti2v_sampling.pt", {k: tuple(v.shape) for k, v in fx.items() if k != "spec"})
+
+
 def gen_seine():
     """``seine_decoder_hooks.pt`` (``--seine``): the reference's own ``CrossAttnUpBlock3D`` (``seine/models/unet_blocks.py:444-575``
     with ``seine/models/attention.py`` / ``resnet.py`` below it, ``oracle.ref_stubs.load_reference_seine_decoder``) as stand-ins
@@ -386,6 +404,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--consisti2v-pipeline" in sys.argv:
         gen_consisti2v_pipeline()
+    if "--consisti2v-sampling" in sys.argv:
+        gen_consisti2v_sampling()
         sys.exit(0)
     if "--pipeline" in sys.argv:
         gen_ref_pipeline("mini")

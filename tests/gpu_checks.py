@@ -2307,6 +2307,17 @@ def check_consisti2v_pipeline():
     return out
 
 
+def check_consisti2v_sampling():
+    """ConsistI2V's samplers next to the runner stages -- ``ConditionalAnimationPipeline``, ``AutoregressiveAnimationPipeline`` (two
+    chunks) and ``guidance_rescale`` + ``eta`` on the editing pipeline -- on the kernels vs the fixture the REFERENCE's own classes
+    produced on the CPU in fp32 (``make_golden.py --consisti2v-sampling``); seeded noise, drawn on the host on both sides."""
+    import consisti2v_spec as spec
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "consisti2v_sampling.pt"))
+    got = spec.native_sampling(DEV)
+    return [_res(f"consisti2v sampling: {name} ({spec.sampling_cases()[name][0]})", lat.float().cpu(), fx[name].float(), 3e-2)
+            for name, lat in got.items()]
+
+
 def check_seine_hooks():
     """the SEINE hook family (``anyv2v_amd/seine.py``) on the kernels vs the fixture the REFERENCE's own
     ``CrossAttnUpBlock3D`` + ``seine/pnp_utils.py`` produced on the CPU in fp32 (``make_golden.py --seine``): un-hooked, and with

@@ -584,6 +584,36 @@ def test_ddim_scheduler_step_with_eta_draws_from_the_generator(monkeypatch):
         inv.step(e, int(inv.timesteps[2]), x, eta=0.5)
 
 
+SAMPLING_TOL = 3e-2
+
+
+def test_native_consisti2v_sampling_cases_vs_reference_fixture(monkeypatch):
+    """``tests/golden/consisti2v_sampling.pt`` (the reference's three pipeline classes sampling from seeded noise: both animation
+    pipelines, ``guidance_rescale`` + ``eta``) vs the native pipelines on the emulated kernels; the GPU run compares with the same file."""
+    warnings.filterwarnings("ignore")
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "consisti2v_sampling.pt"))
+    assert fx["spec"]["cases"] == {k: [c, dict(kw)] for k, (c, kw) in spec.sampling_cases().items()} and fx["spec"]["seed"] == spec.SAMPLING_SEED
+    emu.install(monkeypatch)
+    got = spec.native_sampling("cpu")
+    assert set(got) == set(spec.sampling_cases())
+    for name, lat in got.items():
+        assert lat.shape == fx[name].shape, name
+        ok, err = _close(lat, fx[name], SAMPLING_TOL)
+        assert ok, (name, err)
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_sampling_fixture_is_what_the_reference_classes_produce(tmp_path):
+    from oracle import ref_consisti2v_pipeline as rcp
+    warnings.filterwarnings("ignore")
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "consisti2v_sampling.pt"))
+    cases = {k: v for k, v in spec.sampling_cases().items() if k != "animation"}     # (the third is re-run by the class-level test above)
+    got = rcp.run_reference_sampling(spec.UNET_CFG, spec.fill_weights, cases, spec.sampling_first_frame(), spec.SAMPLING_FILTER,
+                                     spec.SAMPLING_SEED, tmp_path)
+    for name, lat in got.items():
+        assert torch.equal(lat.half(), fx[name]), name
+
+
 def test_camera_motion_zoom_out_cuts_growing_windows():
     from anyv2v_amd.consisti2v_pipeline import camera_motion_frames
     x = torch.arange(3 * 90 * 120, dtype=torch.float32).view(3, 90, 120) / 1000

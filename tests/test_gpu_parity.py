@@ -254,6 +254,11 @@ def test_consisti2v_pipeline_vs_the_references_own_pipeline_class():
     _assert_all(gc.check_consisti2v_pipeline())
 
 
+def test_consisti2v_samplers_and_options_vs_the_references_own_classes():
+    """Both animation pipelines and ``guidance_rescale`` + ``eta`` on the kernels vs the reference's own classes (fixture)."""
+    _assert_all(gc.check_consisti2v_sampling())
+
+
 def test_seine_hook_family_vs_the_references_own_blocks_and_hooks():
     """SEINE's decoder blocks + PnP hooks (incl. the cross-attention hook) on the kernels vs a fixture produced by the
     reference's own code."""
