@@ -2314,7 +2314,8 @@ def check_consisti2v_sampling():
     import consisti2v_spec as spec
     fx = torch.load(os.path.join(ROOT, "tests", "golden", "consisti2v_sampling.pt"))
     got = spec.native_sampling(DEV)
-    return [_res(f"consisti2v sampling: {name} ({spec.sampling_cases()[name][0]})", lat.float().cpu(), fx[name].float(), 3e-2)
+    tol = dict(animation=8e-3, autoregressive=8e-3, rescale_eta=2e-2)      # (3 x measured, profiles/r04_consisti2v_sampling_gpu.txt)
+    return [_res(f"consisti2v sampling: {name} ({spec.sampling_cases()[name][0]})", lat.float().cpu(), fx[name].float(), tol[name])
             for name, lat in got.items()]
 
 
