@@ -16,13 +16,12 @@ from __future__ import annotations
 
 import logging
 import os
-from types import SimpleNamespace
-from typing import Dict, List, Optional, Union
+from typing import Dict, Optional, Union
 
 import torch
 
 from . import ops, pnp_utils
-from .schedulers import DDIMInverseScheduler, DDIMScheduler
+from .schedulers import DDIMScheduler
 from .unet import I2VGenXLUNet, I2VGenXLUNetConfig
 from .utils import LatentTrajectory, load_ddim_latents_at_t
 

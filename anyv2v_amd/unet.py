@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, MODE_CONV2D, MODE_LINEAR, MODE_TEMPORAL
+from .ops import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, MODE_CONV2D, MODE_TEMPORAL
 
 
 @dataclass

@@ -13,7 +13,7 @@ single 512-wide attention head of the mid block runs as logits GEMM (fp32 out) -
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Optional
 
 import torch
 import torch.nn as nn

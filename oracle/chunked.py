@@ -22,8 +22,6 @@ from __future__ import annotations
 
 import torch
 
-from . import unet_oracle as uo
-
 _SAVED = "_chunked_saved_forward"
 
 

@@ -66,8 +66,6 @@ def install_stubs():
         def __init__(self, **kw):
             self.__dict__.update(kw)
 
-    import dataclasses
-
     def _baseoutput_dc(cls):
         return cls
 

@@ -23,7 +23,7 @@ network on CPU in seconds; ``UNetConfig.i2vgen_xl()`` is the real 1.42 B model.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
 import torch

@@ -3,7 +3,6 @@ fixtures generated from the reference's own code.  All calls go through the C AB
 import os
 
 import pytest
-import torch
 
 import gpu_checks as gc
 

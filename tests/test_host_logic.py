@@ -3,7 +3,6 @@ emulation of the C-ABI ops (tests/cpu_ops_emulation.py), compared with the oracl
 golden fixtures.  This validates token-layout wiring, weight packing, the per-clip conditioning cache, PnP
 aliasing and dead-compute elimination, and the step engine -- everything except the HIP kernels themselves, which
 the `-m gpu` tests cover through the real C ABI."""
-import math
 import os
 
 import numpy as np

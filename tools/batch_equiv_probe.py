@@ -3,7 +3,6 @@ three-branch forward?  Full model, 16 f x 512^2, every hook site injected: the o
 module of both forwards is compared in network order.  gpurun_out/batch_equiv_probe.txt"""
 import os
 import sys
-import types
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
