@@ -533,7 +533,7 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
     AV_RB(0, 0);
     AV_RB(0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    int q = 0, npiece = 0;
+    int npiece = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -546,7 +546,6 @@ __device__ __forceinline__ void mma_tile_big(f4 (&acc)[MF][10], const char* as, 
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][nf], af[ks][mf], acc[mf][nf], 0, 0, 0);
-            q += MF;
             __builtin_amdgcn_sched_barrier(0);
             // (activation fragment of the next K-step first: group (1, 0) then waits for all but the weight read behind it)
             if (ks == 0 && nf >= 10 - MF) AV_RA(1, nf - (10 - MF));
