@@ -614,6 +614,25 @@ def test_sampling_fixture_is_what_the_reference_classes_produce(tmp_path):
         assert torch.equal(lat.half(), fx[name]), name
 
 
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_shipped_configs_resolve_to_the_references_values():
+    """``configs/consisti2v/pipeline_{256,512}/*.yaml`` are laid out differently from the reference's files but hold the same keys and
+    values; the I2VGen-XL group templates likewise, except ``device`` (the reference pins GPUs 7 / 4 of its own node)."""
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    load = lambda p: yaml.safe_load(open(p))
+    for size in (256, 512):
+        for name in (f"ddim_inversion_{size}.yaml", "pnp_edit.yaml"):
+            mine = load(os.path.join(root, "configs", "consisti2v", f"pipeline_{size}", name))
+            ref = load(os.path.join(ref_stubs.REFERENCE_ROOT, "consisti2v", "configs", f"pipeline_{size}", name))
+            assert mine == ref, (size, name)
+    for stage in ("group_ddim_inversion", "group_pnp_edit"):
+        mine = load(os.path.join(root, "configs", stage, "template.yaml"))
+        ref = load(os.path.join(ref_stubs.REFERENCE_ROOT, "i2vgen-xl", "configs", stage, "template.yaml"))
+        assert mine.pop("device") == "cuda:0" and ref.pop("device").startswith("cuda:")
+        assert mine == ref, stage
+
+
 def test_camera_motion_zoom_out_cuts_growing_windows():
     from anyv2v_amd.consisti2v_pipeline import camera_motion_frames
     x = torch.arange(3 * 90 * 120, dtype=torch.float32).view(3, 90, 120) / 1000

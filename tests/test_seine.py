@@ -315,3 +315,14 @@ def test_ddpm_step_is_pinned_to_the_references_own_gaussian_diffusion():
     finally:
         for k in [k for k in sys.modules if k.startswith("_ref_seine_diffusion")]:
             del sys.modules[k]
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+def test_shipped_configs_resolve_to_the_references_values():
+    """``configs/seine/*.yaml``: another layout than the reference's files, the same keys and values."""
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("ddim_inversion.yaml", "pnp_edit.yaml"):
+        mine = yaml.safe_load(open(os.path.join(root, "configs", "seine", name)))
+        ref = yaml.safe_load(open(os.path.join(ref_stubs.REFERENCE_ROOT, "seine", "configs", name)))
+        assert mine == ref, name
