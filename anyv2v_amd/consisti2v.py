@@ -38,7 +38,7 @@ from torch import nn
 from . import ops
 from .ops import MODE_TEMPORAL
 from .unet import (Conv2d, Conv3dTemporal, Downsample2D, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU,
-                   Upsample2D, pnp_on)
+                   Upsample2D, pnp_on, upsample_tokens)
 
 ROTARY_THETA = 10000.0  # rotary_embedding.py:76 (freqs_for="lang")
 
@@ -405,7 +405,8 @@ class VideoLDMCrossAttnUpBlock(_BlockBase):
         self._packed = False
         return out
 
-    def run(self, ctx, x, skips: List[torch.Tensor]):
+    def run(self, ctx, x, skips: List[torch.Tensor], out_hw=None):
+        """``out_hw``: the reference's ``upsample_size`` (``videoldm_unet_blocks.py:703,744``): the size of the next block's skip connections."""
         cond = self.first_frame_condition_mode not in ("none", "input_only")
         for resnet, conv3d, attn, tattn in zip(self.resnets, self.conv3ds, self.attentions, self.tempo_attns):
             x = resnet.run(ctx, x, skips.pop(), ctx.H, ctx.W)
@@ -413,11 +414,11 @@ class VideoLDMCrossAttnUpBlock(_BlockBase):
             x = attn.run(ctx, x, condition_on_first_frame=cond)
             x = tattn.run(ctx, x)
         if self.upsamplers is not None:
-            x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
-            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
+            x, Ho, Wo = upsample_tokens(self.upsamplers[0].conv, x, ctx.H, ctx.W, out_hw)
+            ctx.set_hw(Ho, Wo)
         return x
 
-    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, **unused):
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, upsample_size=None, **unused):
         """The reference's call (``videoldm_unet_blocks.py:696-745``): ``hidden_states`` [(b f), C, H, W], the skip tensors of the
         encoder (last one is consumed first), ``temb`` [(b f), D] and ``encoder_hidden_states`` [(b f), L, D] -- both repeated per
         frame by the reference's UNet; the first frame's copy of each batch element is read here."""
@@ -437,9 +438,9 @@ class VideoLDMCrossAttnUpBlock(_BlockBase):
         ehs = encoder_hidden_states.to(torch.float16)[::F]
         ctx.L = ehs.shape[1]
         ctx.context = ehs.reshape(B * ctx.L, -1).contiguous()
-        y = self.run(ctx, tok(hidden_states), [tok(s) for s in res_hidden_states_tuple])
-        Ho, Wo = (2 * H, 2 * W) if self.upsamplers is not None else (H, W)
-        return y.view(N, Ho, Wo, -1).permute(0, 3, 1, 2)
+        y = self.run(ctx, tok(hidden_states), [tok(s) for s in res_hidden_states_tuple],
+                     out_hw=None if upsample_size is None else tuple(int(v) for v in upsample_size[-2:]))
+        return y.view(N, ctx.H, ctx.W, -1).permute(0, 3, 1, 2)
 
 
 # ------------------------------------------------------------------------------------------------- the other blocks of the UNet
@@ -482,7 +483,7 @@ class VideoLDMCrossAttnDownBlock(_BlockBase):
             outs.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
-            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            ctx.set_hw((ctx.H - 1) // 2 + 1, (ctx.W - 1) // 2 + 1)     # (stride 2, padding 1: odd sizes round up)
             outs.append(x)
         return x, outs
 
@@ -508,7 +509,7 @@ class VideoLDMDownBlock(_BlockBase):
             outs.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
-            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            ctx.set_hw((ctx.H - 1) // 2 + 1, (ctx.W - 1) // 2 + 1)     # (stride 2, padding 1: odd sizes round up)
             outs.append(x)
         return x, outs
 
@@ -558,12 +559,12 @@ class VideoLDMUpBlock(_BlockBase):
         self.conv3ds = nn.ModuleList([TemporalResnetBlock(out_channels) for _ in range(num_layers)])
         self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
 
-    def run(self, ctx, x, skips: List[torch.Tensor]):
+    def run(self, ctx, x, skips: List[torch.Tensor], out_hw=None):
         for resnet, conv3d in zip(self.resnets, self.conv3ds):
             x = conv3d.run(ctx, resnet.run(ctx, x, skips.pop(), ctx.H, ctx.W))
         if self.upsamplers is not None:
-            x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
-            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
+            x, Ho, Wo = upsample_tokens(self.upsamplers[0].conv, x, ctx.H, ctx.W, out_hw)
+            ctx.set_hw(Ho, Wo)
         return x
 
 
@@ -706,15 +707,19 @@ class VideoLDMUNet3DConditionModel(nn.Module):
         ops.ncfhw_to_tokens(sample.to(torch.float16).contiguous(), xin, col0=0)
         x = self.conv_in.tokens(xin, H, W)
         skips = [x]
+        sizes = [(H, W)]     # per resolution level: the up path returns to exactly these (``upsample_size``, ``videoldm_unet.py:726-734,990-1010``)
         for blk in self.down_blocks:
             blk.enter(ctx)
             x, outs = blk.run(ctx, x)
             skips.extend(outs)
+            if blk.downsamplers is not None:
+                sizes.append((ctx.H, ctx.W))
         self.mid_block.enter(ctx)
         x = self.mid_block.run(ctx, x)
         for blk in self.up_blocks:
             blk.enter(ctx)
-            x = blk.run(ctx, x, skips)
+            sizes.pop()
+            x = blk.run(ctx, x, skips, out_hw=sizes[-1] if sizes else None)
         x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, H * W, groups=self.groups,
                           eps=self.conv_norm_out.eps, silu=True)
         vtok = torch.empty((x.shape[0], 8), dtype=torch.float16, device=dev)

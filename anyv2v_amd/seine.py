@@ -30,7 +30,8 @@ from torch import nn
 
 from . import ops
 from .consisti2v import ROTARY_THETA, _Ctx, _RotaryFreqs, _sched
-from .unet import Conv2d, Downsample2D, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU, Upsample2D, pnp_on
+from .unet import (Conv2d, Downsample2D, FeedForward, GroupNorm, Identity, LayerNorm, Linear, ResnetBlock2D, SiLU, Upsample2D, pnp_on,
+                   upsample_tokens)
 
 
 class CrossAttention(nn.Module):
@@ -243,18 +244,19 @@ class CrossAttnUpBlock3D(_SeineBlock):
         self._packed = False
         return out
 
-    def run(self, ctx, x, skips: List[torch.Tensor]):
+    def run(self, ctx, x, skips: List[torch.Tensor], out_hw=None):
+        """``out_hw``: ``upsample_size`` of the reference (``unet_blocks.py:530,572``): the size of the skip connections the next block pops."""
         for resnet, attn in zip(self.resnets, self.attentions):
             x = resnet.run(ctx, x, skips.pop(), ctx.H, ctx.W)
             x = attn.run(ctx, x)
         if self.upsamplers is not None:
-            x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
-            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
+            x, Ho, Wo = upsample_tokens(self.upsamplers[0].conv, x, ctx.H, ctx.W, out_hw)
+            ctx.set_hw(Ho, Wo)
         return x
 
-    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, **unused):
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, upsample_size=None, **unused):
         """The reference's call (``unet_blocks.py:524-575``): ``hidden_states`` and the skip tensors [b, c, f, h, w], ``temb`` [b, D],
-        ``encoder_hidden_states`` [b, L, D]."""
+        ``encoder_hidden_states`` [b, L, D]; ``upsample_size`` = (f, h, w) or (h, w) of the next block's skip connections."""
         if not self._packed:
             self.pack()
         B, C, F, H, W = hidden_states.shape
@@ -268,9 +270,9 @@ class CrossAttnUpBlock3D(_SeineBlock):
         ehs = encoder_hidden_states.to(torch.float16)
         ctx.L = ehs.shape[1]
         ctx.context = ehs.reshape(B * ctx.L, -1).contiguous()
-        y = self.run(ctx, tok(hidden_states), [tok(s) for s in res_hidden_states_tuple])
-        Ho, Wo = (2 * H, 2 * W) if self.upsamplers is not None else (H, W)
-        return y.view(B, F, Ho, Wo, -1).permute(0, 4, 1, 2, 3)
+        y = self.run(ctx, tok(hidden_states), [tok(s) for s in res_hidden_states_tuple],
+                     out_hw=None if upsample_size is None else tuple(int(v) for v in upsample_size[-2:]))
+        return y.view(B, F, ctx.H, ctx.W, -1).permute(0, 4, 1, 2, 3)
 
 
 # ------------------------------------------------------------------------------------------------- the other blocks, the UNet
@@ -302,7 +304,7 @@ class CrossAttnDownBlock3D(_SeineBlock):
             outs.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
-            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            ctx.set_hw((ctx.H - 1) // 2 + 1, (ctx.W - 1) // 2 + 1)     # (stride 2, padding 1: odd sizes round up)
             outs.append(x)
         return x, outs
 
@@ -324,7 +326,7 @@ class DownBlock3D(_SeineBlock):
             outs.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0].conv.tokens(x, ctx.H, ctx.W)
-            ctx.set_hw(ctx.H // 2, ctx.W // 2)
+            ctx.set_hw((ctx.H - 1) // 2 + 1, (ctx.W - 1) // 2 + 1)     # (stride 2, padding 1: odd sizes round up)
             outs.append(x)
         return x, outs
 
@@ -363,12 +365,12 @@ class UpBlock3D(_SeineBlock):
             self.resnets.append(_res3d(rin + skip, out_channels, temb_channels, resnet_groups, resnet_eps))
         self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
 
-    def run(self, ctx, x, skips: List[torch.Tensor]):
+    def run(self, ctx, x, skips: List[torch.Tensor], out_hw=None):
         for resnet in self.resnets:
             x = resnet.run(ctx, x, skips.pop(), ctx.H, ctx.W)
         if self.upsamplers is not None:
-            x = self.upsamplers[0].conv.tokens(x, ctx.H, ctx.W, up=True)
-            ctx.set_hw(2 * ctx.H, 2 * ctx.W)
+            x, Ho, Wo = upsample_tokens(self.upsamplers[0].conv, x, ctx.H, ctx.W, out_hw)
+            ctx.set_hw(Ho, Wo)
         return x
 
 
@@ -483,15 +485,19 @@ class UNet3DConditionModel(nn.Module):
         ops.ncfhw_to_tokens(sample.to(torch.float16).contiguous(), xin, col0=0)
         x = self.conv_in.tokens(xin, H, W)
         skips = [x]
+        sizes = [(H, W)]     # per resolution level: the up path returns to exactly these (``upsample_size``, ``unet.py:393-401,485-500``)
         for blk in self.down_blocks:
             blk.enter(ctx)
             x, outs = blk.run(ctx, x)
             skips.extend(outs)
+            if blk.downsamplers is not None:
+                sizes.append((ctx.H, ctx.W))
         self.mid_block.enter(ctx)
         x = self.mid_block.run(ctx, x)
         for blk in self.up_blocks:
             blk.enter(ctx)
-            x = blk.run(ctx, x, skips)
+            sizes.pop()
+            x = blk.run(ctx, x, skips, out_hw=sizes[-1] if sizes else None)
         # (conv_norm_out is a plain GroupNorm on [b, c, f, h, w]: statistics over all frames of a batch element)
         x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, F * H * W, groups=self.groups,
                           eps=self.conv_norm_out.eps, silu=True)

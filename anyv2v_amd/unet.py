@@ -708,7 +708,7 @@ class DownBlock3D(nn.Module):
             outs.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0].conv.tokens(x, H, W)
-            H, W = H // 2, W // 2
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1     # stride 2, padding 1: odd sizes round up
             outs.append(x)
         return x, outs, H, W
 
@@ -753,7 +753,9 @@ class UpBlock3D(nn.Module):
                 self.temp_attentions.append(TransformerTemporalModel(heads, cfg.attention_head_dim, cout, g))
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
 
-    def run(self, ctx, x, skips: List[torch.Tensor], H, W):
+    def run(self, ctx, x, skips: List[torch.Tensor], H, W, out_hw=None):
+        """``out_hw``: the size the upsampler has to deliver -- that of the skip connections the next block pops ([3P] diffusers
+        ``forward_upsample_size``: a latent size that is not a multiple of 8 does not come back from three ceil-halvings by doubling)."""
         for i in range(len(self.resnets)):
             skip = skips.pop()
             x = self.resnets[i].run(ctx, x, skip, H, W)  # torch.cat([x, skip], 1) folded into the kernels
@@ -762,9 +764,42 @@ class UpBlock3D(nn.Module):
                 x = self.attentions[i].run(ctx, x, H, W)
                 x = self.temp_attentions[i].run(ctx, x, H, W)
         if self.upsamplers is not None:
-            x = self.upsamplers[0].conv.tokens(x, H, W, up=True)  # nearest x2 folded into the conv gather
-            H, W = 2 * H, 2 * W
+            x, H, W = upsample_tokens(self.upsamplers[0].conv, x, H, W, out_hw)
         return x, H, W
+
+
+def upsample_tokens(conv, x, H, W, out_hw=None):
+    """``Upsample2D``: nearest x 2 (``out_hw`` None or exactly the double: folded into the conv's gather) or nearest to exactly ``out_hw``,
+    then the 3 x 3 convolution -> (tokens, Ho, Wo).  For Ho in (2 H - 1, 2 H) the source index floor(o H / Ho) is o >> 1 either way, but
+    the conv's zero padding starts at Ho, not at 2 H: the resized image is materialised (one gather) and convolved plainly."""
+    if out_hw is None or tuple(out_hw) == (2 * H, 2 * W):
+        return conv.tokens(x, H, W, up=True), 2 * H, 2 * W
+    Ho, Wo = out_hw
+    if Ho not in (2 * H - 1, 2 * H) or Wo not in (2 * W - 1, 2 * W):
+        raise ValueError(f"upsample {H} x {W} -> {Ho} x {Wo}: not the size of a skip connection of this UNet")
+    n_img = x.shape[0] // (H * W)
+    up = torch.empty((n_img * Ho * Wo, x.shape[1]), dtype=x.dtype, device=x.device)
+    ops.gather_rows(x, 0, _nearest_rows(n_img, H, W, Ho, Wo, x.device), up, 0, x.shape[1])
+    return conv.tokens(up, Ho, Wo), Ho, Wo
+
+
+_NEAREST_ROWS = {}
+
+
+def _nearest_rows(n_img, H, W, Ho, Wo, device):
+    """int32 [n_img Ho Wo]: the token of the [n_img, H, W] grid that nearest-neighbour resizing to (Ho, Wo) reads (``F.interpolate``
+    with ``size=``: floor(o * H / Ho))."""
+    key = (n_img, H, W, Ho, Wo, str(device))
+    idx = _NEAREST_ROWS.get(key)
+    if idx is None:
+        if len(_NEAREST_ROWS) > 64:
+            _NEAREST_ROWS.clear()
+        yi = (torch.arange(Ho) * H) // Ho
+        xi = (torch.arange(Wo) * W) // Wo
+        one = (yi[:, None] * W + xi[None, :]).reshape(-1)
+        idx = (torch.arange(n_img)[:, None] * (H * W) + one[None, :]).reshape(-1).to(device=device, dtype=torch.int32).contiguous()
+        _NEAREST_ROWS[key] = idx
+    return idx
 
 
 class I2VGenXLTransformerTemporalEncoder(nn.Module):
@@ -1035,9 +1070,12 @@ class I2VGenXLUNet(nn.Module):
             x = self.transformer_in.run(ctx, x, H, W)
             skips = [x]
         h_, w_ = H, W
+        sizes = [(H, W)]      # per resolution level; the up path returns to exactly these (odd sizes round up on the way down)
         for bi, blk in enumerate(self.down_blocks):
             x, outs, h_, w_ = blk.run(ctx, x, h_, w_, stem_ctx=stem if bi == 0 else None)
             skips.extend(outs)
+            if blk.downsamplers is not None:
+                sizes.append((h_, w_))
         x = self.mid_block.run(ctx, x, h_, w_)
         # PnP step whose source-branch prediction is discarded (pipeline_i2vgen_xl.py:1136,1160-1162): behind the last hook site --
         # the self-attention of up_blocks[3].temp_attentions[2] -- the source rows are dead; the rest of the forward runs on
@@ -1047,7 +1085,8 @@ class I2VGenXLUNet(nn.Module):
         ctx.drop_tail_at = last if drop else None
         try:   # (the last hook site switches the process-global batch hint to (3, 2): restore it on EVERY exit)
             for blk in self.up_blocks:
-                x, h_, w_ = blk.run(ctx, x, skips, h_, w_)
+                sizes.pop()
+                x, h_, w_ = blk.run(ctx, x, skips, h_, w_, out_hw=sizes[-1] if sizes else None)
             ctx.drop_tail_at = None
             x = ops.groupnorm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, ctx.stats, H * W,
                               groups=self.conv_norm_out.num_groups, eps=self.conv_norm_out.eps, silu=True)

@@ -167,8 +167,7 @@ def load_reference_consisti2v_models(attention_base=None, package="_ref_consisti
                 super().__init__(channels)
 
             def forward(self, x, output_size=None, scale=1.0):
-                assert output_size is None
-                return super().forward(x)
+                return super().forward(x, output_size)      # ([3P] nearest x 2, or nearest to ``output_size``: oracle/unet_oracle.py)
 
         class Transformer2DModelOutput:
             def __init__(self, sample):

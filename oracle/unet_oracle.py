@@ -215,8 +215,14 @@ class Upsample2D(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
-    def forward(self, x, scale=1.0):
-        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    def forward(self, x, output_size=None):
+        """[3P] diffusers ``Upsample2D.forward(hidden_states, output_size)``: nearest x2, or -- when the UNet forwards the size of the
+        skip connection it is about to meet -- nearest to exactly that size (in-tree copies of the same rule:
+        ``seine/models/resnet.py:44-64``)."""
+        if output_size is None:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        else:
+            x = F.interpolate(x, size=tuple(output_size), mode="nearest")
         return self.conv(x)
 
 
@@ -353,7 +359,7 @@ class UpBlock3D(nn.Module):
                 self.temp_attentions.append(TransformerTemporalModel(heads, cfg.attention_head_dim, cout, g))
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
 
-    def forward(self, x, skips: List[torch.Tensor], temb, ctx, num_frames):
+    def forward(self, x, skips: List[torch.Tensor], temb, ctx, num_frames, upsample_size=None):
         for i, (resnet, tconv) in enumerate(zip(self.resnets, self.temp_convs)):
             x = torch.cat([x, skips.pop()], dim=1)
             x = resnet(x, temb)
@@ -362,7 +368,7 @@ class UpBlock3D(nn.Module):
                 x = self.attentions[i](x, ctx)
                 x = self.temp_attentions[i](x, num_frames)
         if self.upsamplers is not None:
-            x = self.upsamplers[0](x)
+            x = self.upsamplers[0](x, upsample_size)
         return x
 
 
@@ -486,9 +492,15 @@ class I2VGenXLUNetOracle(nn.Module):
             skips.extend(outs)
         # 7: mid
         x = self.mid_block(x, emb, ctx, Fr)
-        # 8: up
-        for blk in self.up_blocks:
-            x = blk(x, skips, emb, ctx, Fr)
+        # 8: up.  [3P] a latent size that is not a multiple of 2 ** (number of upsamplers) = 8 does not come back from three
+        # ceil-halvings by doubling: the UNet then hands every up block the spatial size of the skip connection the NEXT block pops
+        # first (``forward_upsample_size`` / ``upsample_size``; in-tree copies of the rule: ``seine/models/unet.py:393-401,485-500``,
+        # ``consisti2v/consisti2v/models/videoldm_unet.py:726-734,990-1010``)
+        forward_size = any(s % (2 ** (len(self.up_blocks) - 1)) != 0 for s in (H, W))
+        for bi, blk in enumerate(self.up_blocks):
+            n_pop = len(blk.resnets)
+            size = tuple(skips[-n_pop - 1].shape[2:]) if (forward_size and bi != len(self.up_blocks) - 1) else None
+            x = blk(x, skips, emb, ctx, Fr, upsample_size=size)
         # 9: post
         x = self.conv_out(self.conv_act(self.conv_norm_out(x)))
         x = x[None, :].reshape((-1, Fr) + x.shape[1:]).permute(0, 2, 1, 3, 4)

@@ -1204,8 +1204,9 @@ def check_foreign_hooks(source="oracle"):
 def config1_inputs(cfg, B, Fr=8, hw=32, seed=8888):
     """BASELINE config 1 inputs: random latents, frame-position planes, seed 8888."""
     g = torch.Generator().manual_seed(seed)
-    sample = torch.randn(B, 4, Fr, hw, hw, generator=g)
-    il = torch.randn(B, 4, Fr, hw, hw, generator=g)
+    h, w = (hw, hw) if isinstance(hw, int) else hw
+    sample = torch.randn(B, 4, Fr, h, w, generator=g)
+    il = torch.randn(B, 4, Fr, h, w, generator=g)
     for i in range(1, Fr):
         il[:, :, i] = i / (Fr - 1)
     ehs = torch.randn(B, 77, cfg.cross_attention_dim, generator=g)
@@ -1243,7 +1244,9 @@ def check_unet_vs_oracle(cfg_name="mini", B=3, Fr=4, hw=8, with_pnp=True, tol=3e
         out.append(_calibrated(name, vn, vo, v16) if calibrate else _res(name, vn.cpu(), vo, tol))
         return t_cpu
 
-    t_cpu = compare(f"unet {cfg_name} B{B} F{Fr} {hw}x{hw} step vs oracle", 981)
+    hw_ = (hw, hw) if isinstance(hw, int) else tuple(hw)
+    hw = f"{hw_[0]}x{hw_[1]}"
+    t_cpu = compare(f"unet {cfg_name} B{B} F{Fr} {hw} step vs oracle", 981)
     if report is not None:
         report[f"cpu_oracle_seconds_{cfg_name}_B{B}"] = t_cpu
     if with_pnp and B == 3:
@@ -1255,7 +1258,7 @@ def check_unet_vs_oracle(cfg_name="mini", B=3, Fr=4, hw=8, with_pnp=True, tol=3e
                 pnp_oracle.register_time(oracle, t)
                 if calibrate:
                     pnp_oracle.register_time(o16, t)
-                compare(f"unet {cfg_name} B3 F{Fr} {hw}x{hw} PnP step t={t} vs oracle", t)
+                compare(f"unet {cfg_name} B3 F{Fr} {hw} PnP step t={t} vs oracle", t)
             # shared stem: with branches 1 and 2 fed the same latent / image latents (as the edit loop does), the stem up to
             # the first cross-attention may run on [source, shared]; same result as the full three-branch stem
             smp = inp16["sample"].clone()
@@ -1267,7 +1270,7 @@ def check_unet_vs_oracle(cfg_name="mini", B=3, Fr=4, hw=8, with_pnp=True, tol=3e
                 pnp_utils.register_time(pipe, t)
                 outs = []
                 for shared in (False, True):
-                    ctx = native._prepare_clip(3, Fr, hw, hw, kw_s["encoder_hidden_states"], kw_s["fps"], kw_s["image_latents"],
+                    ctx = native._prepare_clip(3, Fr, hw_[0], hw_[1], kw_s["encoder_hidden_states"], kw_s["fps"], kw_s["image_latents"],
                                                kw_s["image_embeddings"])
                     ctx.t_buf.fill_(float(t))
                     ctx.shared_stem = shared

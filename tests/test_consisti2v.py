@@ -615,6 +615,30 @@ def test_sampling_fixture_is_what_the_reference_classes_produce(tmp_path):
 
 
 @pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("hw", [(9, 10), (12, 12)])
+def test_native_consisti2v_unet_at_latent_sizes_that_are_not_multiples_of_8_vs_the_references_class(monkeypatch, hw):
+    """``videoldm_unet.py:726-734,990-1010`` (``forward_upsample_size``): the reference's own UNet class vs the native one at sizes that
+    three ceil-halvings do not give back by doubling."""
+    warnings.filterwarnings("ignore")
+    from anyv2v_amd import consisti2v as c2
+    unet_mod, _, _ = ref_stubs.load_reference_consisti2v_unet()
+    ref = spec.fill_weights(unet_mod.VideoLDMUNet3DConditionModel(**spec.UNET_CFG)).eval()
+    emu.install(monkeypatch)
+    nat = spec.fill_weights(c2.VideoLDMUNet3DConditionModel(**spec.UNET_CFG))
+    F = spec.UNET_CFG["n_frames"]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, F - 1, *hw, generator=g).half().float()
+    ehs = torch.randn(2, 5, spec.UNET_CFG["cross_attention_dim"], generator=g).half().float()
+    ff = torch.randn(2, 4, 1, *hw, generator=g).half().float()
+    with torch.no_grad():
+        want = ref(x, 981, encoder_hidden_states=ehs, first_frame_latents=ff, frame_stride=3).sample
+        got = nat(x.half(), 981, encoder_hidden_states=ehs.half(), first_frame_latents=ff.half(), frame_stride=3).sample
+    assert got.shape == want.shape
+    err = float((got.float() - want).abs().max() / want.abs().max())
+    assert err < 8e-3, err
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
 def test_shipped_configs_resolve_to_the_references_values():
     """``configs/consisti2v/pipeline_{256,512}/*.yaml`` are laid out differently from the reference's files but hold the same keys and
     values; the I2VGen-XL group templates likewise, except ``device`` (the reference pins GPUs 7 / 4 of its own node)."""

@@ -253,6 +253,13 @@ def test_consisti2v_pipeline_vs_the_references_own_pipeline_class():
     _assert_all(gc.check_consisti2v_pipeline())
 
 
+def test_unet_at_latent_sizes_that_are_not_multiples_of_8_vs_oracle():
+    """Latent sizes that three ceil-halvings do not give back by doubling (``forward_upsample_size``): stride-2 convolutions on odd
+    sizes, the gather + plain convolution on the way up, ragged attention lengths -- vs the fp32 oracle, PnP hooks on."""
+    res = gc.check_unet_vs_oracle("mini", 1, 2, (9, 10), with_pnp=False) + gc.check_unet_vs_oracle("mini", 3, 2, (12, 9))
+    _assert_all(res)
+
+
 def test_consisti2v_samplers_and_options_vs_the_references_own_classes():
     """Both animation pipelines and ``guidance_rescale`` + ``eta`` on the kernels vs the reference's own classes (fixture)."""
     _assert_all(gc.check_consisti2v_sampling())

@@ -164,6 +164,38 @@ def test_front_end_callable_perform_anyv2v(tmp_path):
     _check_front_end_callable(tmp_path, "cpu")
 
 
+def test_front_end_takes_a_clip_whose_size_is_not_a_multiple_of_64(tmp_path):
+    """``gradio_demo.py:129`` / ``predict.py:153``: the front ends run a clip at ITS size.  160 x 88 pixels are 20 x 11 latents; 11 -> 6 -> 3 -> 2
+    does not come back by doubling, so the UNet resizes to the skip connections' sizes on the way up (diffusers ``forward_upsample_size``)."""
+    base = _make_workspace(tmp_path)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_emulation as emu
+    emu.install()
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    torch.set_grad_enabled(False)
+    from anyv2v_amd.api import AnyV2V_I2VGenXL
+    from anyv2v_amd.mp4 import read_mp4
+    from anyv2v_amd.utils import export_to_video
+    W, H = 160, 88
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = [Image.fromarray(np.stack([(xx * 2 + 10 * i) % 256, (yy * 3) % 256, ((xx + yy) + 30 * i) % 256], -1).astype(np.uint8))
+              for i in range(N_FRAMES)]
+    src = export_to_video(frames, os.path.join(base, "wide.mp4"), fps=8)
+    ed = AnyV2V_I2VGenXL(model_path=os.path.join(base, "model"), device="cpu", tmp_dir=os.path.join(base, "tmp"), synthetic_encoders=True)
+    args = dict(video_path=src, video_prompt="a robot", video_negative_prompt="blurry",
+                edited_first_frame_path=os.path.join(base, "demo", "clip", "edited_first_frame", "e.png"), conv_inj=0.25, spatial_inj=0.5,
+                temp_inj=0.75, num_inference_steps=N_STEPS, guidance_scale=9.0, ddim_init_latents_t_idx=0, ddim_inversion_steps=N_STEPS, seed=7)
+    vid, fps = read_mp4(ed.perform_anyv2v(**args))
+    assert len(vid) == N_FRAMES and vid[0].size == (W, H) and fps == 8.0
+    a = np.stack([np.asarray(f) for f in vid]).astype(np.float32)
+    assert np.isfinite(a).all() and a.std() > 5.0
+    lat = torch.load(os.path.join(base, "tmp", "AnyV2V", "ddim_latents", os.listdir(os.path.join(base, "tmp", "AnyV2V", "ddim_latents"))[0]))
+    assert tuple(lat.shape[-2:]) == (H // 8, W // 8)
+    vid2, _ = read_mp4(ed.perform_anyv2v(**args))       # same seed -> same video
+    assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(vid, vid2))
+
+
 @pytest.mark.gpu
 def test_front_end_callable_on_gpu(tmp_path):
     assert torch.cuda.is_available()

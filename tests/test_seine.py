@@ -318,6 +318,29 @@ def test_ddpm_step_is_pinned_to_the_references_own_gaussian_diffusion():
 
 
 @pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("hw", [(9, 10), (12, 12), (13, 9)])
+def test_native_seine_unet_at_latent_sizes_that_are_not_multiples_of_8_vs_the_references_class(monkeypatch, hw):
+    """``seine/models/unet.py:393-401,485-500`` + ``resnet.py:44-64``: a latent size that three ceil-halvings do not give back by doubling
+    makes the UNet hand every up block the size of the skip connections ahead (nearest-neighbour resize to exactly that size).  The
+    reference's own class vs the native UNet; the same rule serves the I2VGen-XL and ConsistI2V UNets (``unet.upsample_tokens``)."""
+    warnings.filterwarnings("ignore")
+    from anyv2v_amd import seine as sn
+    att, ublocks, res, pnp, Rotary = ref_stubs.load_reference_seine_decoder(with_unet=True)
+    ref = spec.fill_weights(ublocks.unet.UNet3DConditionModel(**spec.UNET_CFG), spec.WEIGHT_SEED).eval()
+    emu.install(monkeypatch)
+    nat = spec.fill_weights(sn.UNet3DConditionModel(**spec.UNET_CFG), spec.WEIGHT_SEED)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 9, spec.UNET_F, *hw, generator=g).half().float()
+    ehs = torch.randn(2, spec.TOKENS, spec.CROSS, generator=g).half().float()
+    with torch.no_grad():
+        want = ref(x, 981, encoder_hidden_states=ehs).sample
+        got = nat(x.half(), 981, encoder_hidden_states=ehs.half()).sample
+    assert got.shape == want.shape
+    err = float((got.float() - want).abs().max() / want.abs().max())
+    assert err < 8e-3, err
+
+
+@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
 def test_shipped_configs_resolve_to_the_references_values():
     """``configs/seine/*.yaml``: another layout than the reference's files, the same keys and values."""
     import yaml
