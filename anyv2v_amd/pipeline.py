@@ -408,6 +408,16 @@ class I2VGenXLPipeline:
             raise ValueError(f"got a batch of {prompt_embeds.shape[0]} prompts: one clip per call (the batch dimension holds the "
                              "CFG / PnP branches of that clip)")
 
+    def _forward_sampler_options(self, eta, cross_attention_kwargs):
+        """``__call__`` / ``sample_with_pnp`` (``pipeline_i2vgen_xl.py:798,868`` / ``:1095,1173``): ``eta`` goes to ``scheduler.step`` when
+        that takes it -- the forward DDIM scheduler does (stochastic DDIM), the inverse one does not (``invert`` drops it, as here).
+        The fused guidance + DDIM step of the step engines is the deterministic one; AnyV2V never sets either option, and silently
+        ignoring them would change the sample."""
+        if eta not in (None, 0, 0.0) and isinstance(self.scheduler, DDIMScheduler):
+            raise ValueError(f"eta={eta}: the step engines run deterministic DDIM (eta = 0) only")
+        if cross_attention_kwargs:
+            raise ValueError("cross_attention_kwargs (LoRA scale, ...) are not supported by the native attention processors")
+
     # ------------------------------------------------------------------ conditioning assembly
     def _conditioning(self, prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                       negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents):
@@ -588,6 +598,7 @@ class I2VGenXLPipeline:
         pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                                              negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
         self._single_clip(pe, num_videos_per_prompt)
+        self._forward_sampler_options(eta, cross_attention_kwargs)
         cfg_on = self.do_classifier_free_guidance
         pnp_utils.clear_time(self)  # plain CFG sampling (DDIM reconstruction) runs hook-free
         if cfg_on:
@@ -638,6 +649,7 @@ class I2VGenXLPipeline:
         pe, npe, ie, il = self._conditioning(prompt, image, height, width, num_frames, negative_prompt, prompt_embeds,
                                              negative_prompt_embeds, target_fps, clip_skip, image_embeddings, image_latents)
         self._single_clip(pe, num_videos_per_prompt)
+        self._forward_sampler_options(eta, cross_attention_kwargs)
         # source (ddim inversion) branch: its own prompt, first frame, positive image embedding (:1027-1091)
         if ddim_inv_prompt_embeds is None:
             ddim_inv_prompt_embeds = _clip_text(self._need("text_encoder"), self._need("tokenizer"), ddim_inv_prompt,

@@ -265,6 +265,17 @@ def test_pipeline_input_checks():
         p.check_inputs(None, None, 512, 512)
     with pytest.raises(FileNotFoundError):
         I2VGenXLPipeline.from_pretrained("ali-vilab/i2vgen-xl")  # no weights, no seed -> loud
+    # options the reference hands to the forward DDIM step / the attention processors: refused, not dropped
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    p.scheduler = DDIMScheduler()
+    p._forward_sampler_options(0.0, None)
+    p._forward_sampler_options(None, {})
+    with pytest.raises(ValueError, match="eta"):
+        p._forward_sampler_options(0.5, None)
+    with pytest.raises(ValueError, match="cross_attention_kwargs"):
+        p._forward_sampler_options(0.0, {"scale": 0.5})
+    p.scheduler = DDIMInverseScheduler()
+    p._forward_sampler_options(0.5, None)          # (the reference's inverse scheduler takes no eta: dropped there too)
 
 
 def test_native_vae_host_logic_and_state_dict(cpu_ops):
