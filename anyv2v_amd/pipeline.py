@@ -769,10 +769,18 @@ class I2VGenXLPipeline:
     def _finish(self, latents, output_type, decode_chunk_size, return_dict):
         if output_type == "latent":
             return I2VGenXLPipelineOutput(frames=latents)
-        video = self.decode_latents(latents, decode_chunk_size=decode_chunk_size)
-        # "pil": one list of PIL frames per video, as ``tensor2vid`` returns (``pipeline_i2vgen_xl.py:79-97``; the runners
-        # index ``.frames[0]``, ``run_group_ddim_inversion.py:77``)
-        frames = [self._need("vae").to_pil(video)] if output_type == "pil" else video
+        if output_type not in ("pil", "np", "pt"):
+            raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt', 'pil]")     # (``tensor2vid``, :94-95)
+        video = self.decode_latents(latents, decode_chunk_size=decode_chunk_size)          # [1, 3, F, H, W] in [-1, 1]
+        # ``tensor2vid`` (``pipeline_i2vgen_xl.py:79-97``) over ``VaeImageProcessor.postprocess``: "pil" -- one list of PIL frames per
+        # video (the runners index ``.frames[0]``, ``run_group_ddim_inversion.py:77``); "pt" -- [b, f, c, h, w] in [0, 1]; "np" -- the
+        # same as float32 numpy [b, f, h, w, c]
+        if output_type == "pil":
+            frames = [self._need("vae").to_pil(video)]
+        else:
+            frames = (video.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)
+            if output_type == "np":
+                frames = frames.permute(0, 1, 3, 4, 2).cpu().numpy()
         if not return_dict:
             return (frames,)
         return I2VGenXLPipelineOutput(frames=frames)

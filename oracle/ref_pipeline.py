@@ -93,11 +93,15 @@ def load_reference_pipeline_module():
 
         @staticmethod
         def postprocess(x, output_type="pil"):
+            """[3P] diffusers 0.26 ``VaeImageProcessor.postprocess``: denormalise to [0, 1]; "pt" -> the tensor, "np" -> float32
+            [n, h, w, c] (``pt_to_numpy``), "pil" -> ``numpy_to_pil`` ((x * 255).round() as uint8)."""
             x = (x / 2 + 0.5).clamp(0, 1)
             if output_type == "pt":
                 return x
-            arr = (x.permute(0, 2, 3, 1).float().numpy() * 255).round().astype("uint8")
-            return arr if output_type == "np" else [PIL.Image.fromarray(a) for a in arr]
+            arr = x.cpu().permute(0, 2, 3, 1).float().numpy()
+            if output_type == "np":
+                return arr
+            return [PIL.Image.fromarray(a) for a in (arr * 255).round().astype("uint8")]
 
     m = ref_stubs._mod
     m("diffusers", DiffusionPipeline=DiffusionPipeline)

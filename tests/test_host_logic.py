@@ -278,6 +278,38 @@ def test_pipeline_input_checks():
     p._forward_sampler_options(0.5, None)          # (the reference's inverse scheduler takes no eta: dropped there too)
 
 
+def test_output_types_follow_the_references_tensor2vid():
+    """``output_type`` "pil" / "np" / "pt" / "latent" (``pipeline_i2vgen_xl.py:79-97,876-880``): the reference's own ``tensor2vid``
+    (its file imported verbatim) on the same decoded video vs ``I2VGenXLPipeline._finish``; anything else is refused as there."""
+    from oracle import ref_stubs
+    if not ref_stubs.reference_available():
+        pytest.skip("needs /root/reference")
+    from anyv2v_amd.encoders import SyntheticVAE
+    from anyv2v_amd.pipeline import I2VGenXLPipeline
+    from oracle import ref_pipeline
+    pm = ref_pipeline.load_reference_pipeline_module()[0]
+    pipe = I2VGenXLPipeline(vae=SyntheticVAE())
+    lat = torch.randn(1, 4, 3, 4, 6, generator=torch.Generator().manual_seed(0)).half()
+    video = pipe.decode_latents(lat, decode_chunk_size=1)
+    proc = pm.VaeImageProcessor(vae_scale_factor=8, do_resize=False)
+    want_np = pm.tensor2vid(video.float(), proc, "np")
+    got_np = pipe._finish(lat, "np", 1, True).frames
+    assert isinstance(got_np, np.ndarray) and got_np.dtype == np.float32 and got_np.shape == want_np.shape == (1, 3, 32, 48, 3)
+    assert np.allclose(got_np, want_np, atol=1e-6)
+    want_pt = pm.tensor2vid(video.float(), proc, "pt")
+    got_pt = pipe._finish(lat, "pt", 1, False)[0]
+    assert torch.is_tensor(got_pt) and got_pt.shape == want_pt.shape and torch.allclose(got_pt, want_pt, atol=1e-6)
+    want_pil = pm.tensor2vid(video.float(), proc, "pil")
+    got_pil = pipe._finish(lat, "pil", 1, True).frames
+    assert len(got_pil) == 1 and len(got_pil[0]) == 3
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got_pil[0], want_pil[0]))
+    assert pipe._finish(lat, "latent", 1, True).frames is lat
+    with pytest.raises(ValueError, match="does not exist"):
+        pipe._finish(lat, "mp4", 1, True)
+    with pytest.raises(ValueError, match="does not exist"):
+        pm.tensor2vid(video.float(), proc, "mp4")
+
+
 def test_native_vae_host_logic_and_state_dict(cpu_ops):
     """AutoencoderKL wiring over the token layout (CPU emulation of the ops): diffusers state-dict keys / shapes of the
     full SD-VAE, mini-config encode / decode vs the oracle, and the pipeline-facing adapter."""
