@@ -151,6 +151,32 @@ def camera_motion_frames(x: torch.Tensor, motion: str, num_frames: int, crop_wid
     return torch.stack(out)
 
 
+def pan_right(image, num_frames=16, crop_width=256):
+    """``pipeline_video_editing.py:63-73`` (and its three neighbours): the module-level names of the camera-motion helpers."""
+    return camera_motion_frames(image, "pan_right", num_frames, crop_width)
+
+
+def pan_left(image, num_frames=16, crop_width=256):
+    return camera_motion_frames(image, "pan_left", num_frames, crop_width)
+
+
+def zoom_in(image, num_frames=16, crop_width=256, ratio=1.5):
+    return camera_motion_frames(image, "zoom_in", num_frames, crop_width, ratio)
+
+
+def zoom_out(image, num_frames=16, crop_width=256, ratio=1.5):
+    return camera_motion_frames(image, "zoom_out", num_frames, crop_width, ratio)
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """``pipeline_video_editing.py:50-61`` on torch tensors (the loop applies the same formula to its fp32 copies, ``_denoise``): the
+    guided prediction rescaled to the standard deviation of the text branch, mixed back by ``guidance_rescale``."""
+    dims = list(range(1, noise_pred_text.ndim))
+    std_text = noise_pred_text.std(dim=dims, keepdim=True)
+    std_cfg = noise_cfg.std(dim=dims, keepdim=True)
+    return guidance_rescale * (noise_cfg * (std_text / std_cfg)) + (1 - guidance_rescale) * noise_cfg
+
+
 def frame_to_pixels(img: Image.Image, height: int, width: int, crop: bool) -> torch.Tensor:
     """[1, 3, height, width] in [-1, 1].  ``crop``: the ``Resize(height) + CenterCrop`` chain; else ``Resize((height, width))``."""
     x = _to_tensor(img)
@@ -277,6 +303,22 @@ class ConditionalVideoEditingPipeline:
         return iterable
 
     @torch.no_grad()
+    # memory savers of the reference pipeline (``pipeline_video_editing.py:229-245``): accepted, nothing to do on this device
+    def enable_vae_slicing(self):
+        self._vae_slicing = True
+
+    def disable_vae_slicing(self):
+        self._vae_slicing = False
+
+    def enable_sequential_cpu_offload(self, gpu_id=0):
+        logger.warning("enable_sequential_cpu_offload: the weights stay resident on the GPU (1250 M parameters of 288 GB)")
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """``:373-388``: ``eta`` / ``generator`` for a scheduler whose ``step`` takes them."""
+        import inspect
+        params = set(inspect.signature(self.scheduler.step).parameters)
+        return {k: v for k, v in (("eta", eta), ("generator", generator)) if k in params}
+
     def init_filter(self, video_length, height, width, filter_params):
         """``pipeline_video_editing.py:208-227``."""
         shape = [1, self.unet.config.in_channels, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor]
@@ -546,6 +588,12 @@ class ConditionalVideoEditingPipeline:
                                generator, noise_sampling_method, noise_alpha, use_frameinit, frameinit_noise_level, frame_stride,
                                guidance_scale_img, guidance_scale_txt, self._callback(callback, callback_steps), eta, guidance_rescale)
         return self._finish(latents, clean, output_type, return_dict)
+
+    def sample_with_saving_features(self, *args, ddim_inv_latents_path=None, ddim_inv_prompt=None, ddim_inv_1st_frame_path=None, **kwargs):
+        """``:971-1223``: ``__call__`` that also stamps the current timestep on the decoder's modules every step (for feature-saving
+        hooks that are not in the reference tree; nothing reads the stamps unless an injection schedule is registered, and then
+        ``sample_with_pnp`` is the entry point).  The three extra arguments of its signature are not used by its body either."""
+        return self.__call__(*args, **kwargs)
 
     # ------------------------------------------------------------------ ``invert`` (:715-968)
     @torch.no_grad()

@@ -64,12 +64,19 @@ def load_video_frames(frames_path, n_frames):
     return paths, [load_image(p) for p in paths]
 
 
-def frames_of_clip(config, save_dir=None):
-    """``run_ddim_inversion.py:101-111``: (frame list, path of the first frame)."""
+def frames_of_clip(config):
+    """``run_ddim_inversion.py:106-116``: (frame list, frame directory, path of the first frame).  From an mp4 the resized frames go to
+    ``<output_dir>/<video name>/`` (``save_dir=config.output_dir``); the first frame is read back from there, so ``save_frames: False``
+    with a video file fails here as it does in the reference (no ``00000.png``) -- said up front."""
     if config.get("video_path") and not str(config.video_path).startswith("<") and os.path.isfile(str(config.video_path)):
-        frame_list = convert_video_to_frames(config.video_path, tuple(config.image_size), save_frames=True)[: config.n_frames]
-        video_name, video_dir = Path(config.video_path).stem, Path(config.video_path).parent
-        return frame_list, f"{video_dir}/{video_name}", os.path.join(f"{video_dir}/{video_name}", "00000.png")
+        save = bool(config.get("save_frames", True))
+        if not save:
+            raise ValueError("save_frames: False with a video_path: the first frame is opened from <output_dir>/<video name>/00000.png "
+                             "(run_ddim_inversion.py:111) -- keep save_frames on, or give video_frames_path")
+        frame_list = convert_video_to_frames(config.video_path, tuple(config.image_size), save_frames=save,
+                                             save_dir=config.output_dir)[: config.n_frames]
+        frames_dir = os.path.join(str(config.output_dir), Path(config.video_path).stem)
+        return frame_list, frames_dir, os.path.join(frames_dir, "00000.png")
     if config.get("video_frames_path"):
         _, frame_list = load_video_frames(config.video_frames_path, config.n_frames)
         return frame_list, str(config.video_frames_path), os.path.join(config.video_frames_path, "00000.png")

@@ -371,6 +371,50 @@ class I2VGenXLPipeline:
             il = torch.cat([il] + planes, dim=2)
         return il
 
+    def prepare_image_latents(self, image, device, num_frames, num_videos_per_prompt=1):
+        """``pipeline_i2vgen_xl.py:532-562``: a pre-processed first frame [1, 3, H, W] in [-1, 1] -> sampled, scaled VAE latent, the
+        frame-position planes behind it, doubled under classifier-free guidance."""
+        if num_videos_per_prompt not in (None, 1):
+            raise ValueError("one clip per call (num_videos_per_prompt = 1)")
+        first = self._need("vae").encode_pixels(image, device)
+        il = self.prepare_image_latents_from_first_frame_latent(first, num_frames)
+        return torch.cat([il] * 2) if self.do_classifier_free_guidance else il
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """``:466-482``: ``eta`` / ``generator`` for a scheduler whose ``step`` takes them (the forward DDIM scheduler takes both, the
+        inverse one neither)."""
+        import inspect
+        params = set(inspect.signature(self.scheduler.step).parameters)
+        extra = {}
+        if "eta" in params:
+            extra["eta"] = eta
+        if "generator" in params:
+            extra["generator"] = generator
+        return extra
+
+    # memory savers of the reference pipeline (``:192-222``): decoding already runs ``decode_chunk_size`` frames at a time, and a 512^2
+    # frame is far below anything that needs tiles on this device -- both switches are accepted and change nothing (the reference's
+    # tiled decode blends tile seams, i.e. differs from its own untiled output; this build always gives the untiled one)
+    def enable_vae_slicing(self):
+        self._vae_slicing = True
+
+    def disable_vae_slicing(self):
+        self._vae_slicing = False
+
+    def enable_vae_tiling(self):
+        logger.warning("enable_vae_tiling: frames are decoded whole on this device; the output equals the reference's UNTILED decode")
+        self._vae_tiling = True
+
+    def disable_vae_tiling(self):
+        self._vae_tiling = False
+
+    def enable_freeu(self, s1, s2, b1, b2):
+        """``:623-648`` (FreeU re-weights the decoder's skip / backbone features): not built -- AnyV2V never enables it."""
+        raise NotImplementedError("FreeU is not supported by the native UNet")
+
+    def disable_freeu(self):
+        pass
+
     def encode_vae_video(self, video, device, height=576, width=1024):
         vae = self._need("vae")
         return vae.encode_video(video, device, height, width)
@@ -772,18 +816,28 @@ class I2VGenXLPipeline:
         if output_type not in ("pil", "np", "pt"):
             raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt', 'pil]")     # (``tensor2vid``, :94-95)
         video = self.decode_latents(latents, decode_chunk_size=decode_chunk_size)          # [1, 3, F, H, W] in [-1, 1]
-        # ``tensor2vid`` (``pipeline_i2vgen_xl.py:79-97``) over ``VaeImageProcessor.postprocess``: "pil" -- one list of PIL frames per
-        # video (the runners index ``.frames[0]``, ``run_group_ddim_inversion.py:77``); "pt" -- [b, f, c, h, w] in [0, 1]; "np" -- the
-        # same as float32 numpy [b, f, h, w, c]
-        if output_type == "pil":
-            frames = [self._need("vae").to_pil(video)]
-        else:
-            frames = (video.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)
-            if output_type == "np":
-                frames = frames.permute(0, 1, 3, 4, 2).cpu().numpy()
+        frames = tensor2vid(video, self._need("vae"), output_type)      # (the runners index ``.frames[0]``, ``run_group_ddim_inversion.py:77``)
         if not return_dict:
             return (frames,)
         return I2VGenXLPipelineOutput(frames=frames)
+
+
+def tensor2vid(video: torch.Tensor, processor=None, output_type: str = "np"):
+    """``pipeline_i2vgen_xl.py:79-97`` over ``VaeImageProcessor.postprocess``: [b, 3, f, H, W] in [-1, 1] -> "pil": one list of PIL frames
+    per video ((x / 2 + 0.5) * 255 rounded); "pt": [b, f, 3, H, W] in [0, 1]; "np": the same as float32 numpy [b, f, H, W, 3].
+    ``processor``: anything with ``to_pil(video[1, 3, f, H, W])`` (the VAE adapters quantise where the tensor lives) or None."""
+    if output_type == "pil":
+        def one(v):
+            if processor is not None and hasattr(processor, "to_pil"):
+                return processor.to_pil(v)
+            x = ((v[0].permute(1, 2, 3, 0).float() + 1.0) * 127.5).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+            from PIL import Image
+            return [Image.fromarray(fr) for fr in x]
+        return [one(video[b:b + 1]) for b in range(video.shape[0])]
+    if output_type not in ("np", "pt"):
+        raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt', 'pil]")
+    frames = (video.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)
+    return frames.permute(0, 1, 3, 4, 2).cpu().numpy() if output_type == "np" else frames
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -211,6 +211,11 @@ class DDIMInverseScheduler(_DDIMBase):
         ts = (np.arange(0, num_inference_steps) * r).round().copy().astype(np.int64) + self.config.steps_offset
         self.timesteps = torch.from_numpy(ts).to(device)
 
+    def step(self, model_output, timestep, sample, return_dict: bool = True):
+        """The vendored scheduler's surface (``consisti2v/ddim_inverse_scheduler.py:291-297``): no ``eta`` / ``generator`` -- a pipeline's
+        ``prepare_extra_step_kwargs`` therefore hands it neither."""
+        return super().step(model_output, timestep, sample, return_dict=return_dict)
+
     def coefficients(self, timestep: int):
         # the sample lives at level c = t - r (alpha 1.0 below 0); the step takes it to level t
         cur = min(timestep - self._ratio(), self.config.num_train_timesteps - 1)

@@ -56,6 +56,33 @@ def load_ddim_latents_at_T(ddim_latents_path):
     return torch.load(os.path.join(ddim_latents_path, f"ddim_latents_{noisest}.pt"), map_location="cpu")
 
 
+def save_video_as_frames(video_path, img_size=(512, 512)):
+    """``seine/pnp_utils.py:25-37``: the clip's frames, LANCZOS-resized to ``img_size`` (w, h), as ``<video dir>/<video name>/%05d.png``."""
+    from .utils import convert_video_to_frames
+    convert_video_to_frames(video_path, tuple(img_size), save_frames=True)
+
+
+def load_imgs(data_path, n_frames, device="cuda", pil=False):
+    """``seine/pnp_utils.py:90-103``: ``%05d.jpg`` (else ``.png``) frames as a float tensor [n, c, H, W] in [0, 1] (``ToTensor``)."""
+    pils = []
+    for i in range(n_frames):
+        path = os.path.join(data_path, "%05d.jpg" % i)
+        if not os.path.exists(path):
+            path = os.path.join(data_path, "%05d.png" % i)
+        pils.append(Image.open(path))
+    imgs = torch.stack([torch.from_numpy(np.array(im, dtype=np.uint8, copy=True)).permute(2, 0, 1).float() / 255.0 for im in pils]).to(device)
+    return (imgs, pils) if pil else imgs
+
+
+def save_video(raw_frames, save_path, fps=10, scaling_255=False):
+    """``seine/pnp_utils.py:106-118``: [f, c, h, w] (uint8 values, or [0, 1] with ``scaling_255``; truncated as ``.to(torch.uint8)`` does) ->
+    an H.264 mp4 (the reference encodes with libx264 at crf 18; there is no encoder library here: raw I_PCM pictures, ``anyv2v_amd.mp4``)."""
+    from .mp4 import write_mp4
+    x = (raw_frames * 255) if scaling_255 else raw_frames
+    x = x.to(torch.uint8).cpu().permute(0, 2, 3, 1).numpy()
+    return write_mp4([Image.fromarray(fr) for fr in x], save_path, fps=fps)
+
+
 def mask_generation_before(mask_type, shape, dtype, device):
     """``seine/seine_utils.py:5-29``: 0 = frame given, 1 = frame to generate."""
     b, f, c, h, w = shape
@@ -162,6 +189,14 @@ class _Base:
         encoded frame by frame; the mask at latent resolution."""
         dev = self.device
         video = torch.cat([first_frame_pixels] + [torch.zeros_like(first_frame_pixels)] * (n_frames - 1), dim=0).to(dev).unsqueeze(0)
+        return self._condition_from_video(video, latent_hw)
+
+    def _condition_from_video(self, video, latent_hw):
+        """[1, f, c, H, W] pixels -> (mask [1, 1, f, h, w], latents of the clip with every frame but the first zeroed [1, 4, f, h, w])."""
+        dev = self.device
+        if video.shape[0] != 1:
+            raise NotImplementedError(f"one clip per call: video batch {video.shape[0]}")
+        video = video.to(dev)
         mask = mask_generation_before("first1", video.shape, video.dtype, dev)                       # b f c h w
         masked = (video * (mask == 0)).to(torch.float16)
         mask = mask.to(torch.float16)
@@ -285,8 +320,12 @@ class SEINEPnPPipeline(_Base):
         sn.register_cross_attention_pnp(self, self.cross_attn_qk_injection_timesteps)
         sn.register_temp_attention_pnp(self, self.temp_attn_qk_injection_timesteps)
 
-    def compute_masked_video_latents_at_0(self, config, first_frame_pixels):
-        return self._first_frame_condition(first_frame_pixels, len(self.src_video_frames), (self.latent_h, self.latent_w))
+    def compute_masked_video_latents_at_0(self, config, video_input):
+        """``:256-277``.  ``video_input``: the reference's [b, f, c, H, W] clip (only its first frame survives the mask), or just that
+        first frame [1, c, H, W] (the clip is then completed with zero frames here instead of by the caller)."""
+        if video_input.dim() == 5:
+            return self._condition_from_video(video_input, (self.latent_h, self.latent_w))
+        return self._first_frame_condition(video_input, len(self.src_video_frames), (self.latent_h, self.latent_w))
 
     @torch.no_grad()
     def denoise_step(self, x, mask, masked_video, masked_src_video, t):

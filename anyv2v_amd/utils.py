@@ -182,9 +182,14 @@ def load_video_frames(frames_path, n_frames, image_size=(512, 512)):
     return paths, frames
 
 
-def convert_video_to_frames(video_path, img_size=(512, 512), save_frames=True):
-    """``i2vgen-xl/utils.py:43-67``: decode the clip, LANCZOS-resize every frame to ``img_size``, optionally save them as
-    ``<video dir>/<video name>/%05d.png``.  The reference decodes with torchvision / ffmpeg; this image has no codec library,
+def isinstance_str(x: object, cls_name: str):
+    """``consisti2v/utils.py:13-25`` / ``seine/utils.py``: does ``x`` have a class NAMED ``cls_name`` in its ancestry."""
+    return any(c.__name__ == cls_name for c in type(x).__mro__)
+
+
+def convert_video_to_frames(video_path, img_size=(512, 512), save_frames=True, save_dir=None):
+    """``i2vgen-xl/utils.py:43-67`` / ``consisti2v/utils.py:55-76`` (which adds ``save_dir``): decode the clip, LANCZOS-resize every frame
+    to ``img_size``, optionally save them as ``<save_dir or video dir>/<video name>/%05d.png``.  The reference decodes with torchvision / ffmpeg; this image has no codec library,
     so only mp4 files whose H.264 pictures are raw (I_PCM) macroblocks -- what ``export_to_video`` below writes -- can be read
     (``anyv2v_amd.mp4``); anything else raises with the reason and the frame-directory alternative."""
     from .mp4 import Mp4Unsupported, read_mp4
@@ -194,7 +199,8 @@ def convert_video_to_frames(video_path, img_size=(512, 512), save_frames=True):
         raise RuntimeError(f"cannot decode {video_path}: {e}; no video decoder library is available here (no torchvision / "
                            "ffmpeg / cv2) -- provide the frames as a directory of %05d.png files") from e
     if save_frames:
-        out_dir = os.path.join(os.path.dirname(video_path), os.path.splitext(os.path.basename(video_path))[0])
+        out_dir = os.path.join(str(save_dir) if save_dir is not None else os.path.dirname(video_path),
+                               os.path.splitext(os.path.basename(video_path))[0])
         os.makedirs(out_dir, exist_ok=True)
     frames = []
     for i, image in enumerate(video):

@@ -291,6 +291,32 @@ def test_consisti2v_cli_runners_end_to_end(monkeypatch, tmp_path):
     assert (a == b).all()
 
 
+def test_consisti2v_inversion_cli_from_a_video_file(monkeypatch, tmp_path):
+    """``run_ddim_inversion.py:106-112``: from ``video_path`` the resized frames are written to ``<output_dir>/<video name>/`` (``save_dir``,
+    ``consisti2v/utils.py:55-76``) and the first frame is opened from there; ``save_frames: False`` cannot work with a video file."""
+    from PIL import Image
+    from anyv2v_amd import consisti2v_run_ddim_inversion as s1
+    from anyv2v_amd.utils import export_to_video
+    emu.install(monkeypatch)
+    base = _consisti2v_workspace(tmp_path)
+    j = spec.PIPE_JOB
+    frames = [Image.open(os.path.join(base, "clip", f"{i:05d}.png")).convert("RGB") for i in range(j["frames"])]
+    big = [f.resize((j["width"] + 32, j["height"] + 16), resample=Image.Resampling.LANCZOS) for f in frames]     # (resized on the way in)
+    export_to_video(big, os.path.join(base, "movie.mp4"), fps=8)
+    args = ["--config", os.path.join(ROOT_DIR, "configs", "consisti2v", "pipeline_256", "ddim_inversion_256.yaml"), "device=cpu",
+            f"model_path={base}/model", "video_name=movie", f"video_path={base}/movie.mp4", f"image_size=[{j['width']},{j['height']}]",
+            f"n_frames={j['frames']}", f"output_dir={base}/inv/movie", f"inverse_config.output_dir={base}/outputs/movie",
+            f"inverse_config.n_steps={j['n_inv_steps']}", f"recon_config.n_steps={j['n_steps']}", f"recon_config.ddim_init_latents_t_idx={j['t_idx']}"]
+    s1.cli(args)
+    saved = sorted(os.listdir(os.path.join(base, "inv", "movie", "movie")))
+    assert saved == [f"{i:05d}.png" for i in range(j["frames"])]
+    assert Image.open(os.path.join(base, "inv", "movie", "movie", "00000.png")).size == (j["width"], j["height"])
+    assert not os.path.isdir(os.path.join(base, "movie"))            # (not next to the video: that is stage 2's habit, run_pnp_edit.py:70-74)
+    assert len(os.listdir(os.path.join(base, "outputs", "movie"))) == j["n_inv_steps"]
+    with pytest.raises(ValueError, match="save_frames"):
+        s1.cli(args + ["save_frames=False"])
+
+
 @pytest.mark.gpu
 def test_consisti2v_cli_runners_on_gpu(tmp_path):
     """The same two CLIs on the HIP library."""
@@ -580,7 +606,7 @@ def test_ddim_scheduler_step_with_eta_draws_from_the_generator(monkeypatch):
     assert torch.equal(sched.step(e, t, x).prev_sample, sched.step(e, t, x, eta=0.0).prev_sample)
     inv = DDIMInverseScheduler(**CONSISTI2V_SCHEDULER_CONFIG)
     inv.set_timesteps(10)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):          # (the vendored inverse scheduler's step has no eta)
         inv.step(e, int(inv.timesteps[2]), x, eta=0.5)
 
 

@@ -308,6 +308,27 @@ def test_output_types_follow_the_references_tensor2vid():
         pipe._finish(lat, "mp4", 1, True)
     with pytest.raises(ValueError, match="does not exist"):
         pm.tensor2vid(video.float(), proc, "mp4")
+    # the module-level function, with and without a processor
+    from anyv2v_amd.pipeline import tensor2vid
+    assert np.allclose(tensor2vid(video, None, "np"), want_np, atol=1e-6)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(tensor2vid(video, None, "pil")[0], want_pil[0]))
+    # the rest of the reference pipeline's public surface
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    pipe.scheduler = DDIMScheduler()
+    assert pipe.prepare_extra_step_kwargs("g", 0.3) == {"eta": 0.3, "generator": "g"}
+    pipe.scheduler = DDIMInverseScheduler()
+    assert pipe.prepare_extra_step_kwargs("g", 0.3) == {}          # (``consisti2v/ddim_inverse_scheduler.py:291-297`` takes neither)
+    for name in ("enable_vae_slicing", "disable_vae_slicing", "enable_vae_tiling", "disable_vae_tiling", "disable_freeu"):
+        getattr(pipe, name)()
+    with pytest.raises(NotImplementedError):
+        pipe.enable_freeu(0.9, 0.2, 1.2, 1.4)
+    pipe._guidance_scale = 9.0
+    x = torch.rand(1, 3, 32, 48, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    il = pipe.prepare_image_latents(x, "cpu", 4, 1)
+    assert tuple(il.shape) == (2, 4, 4, 4, 6) and torch.equal(il[0], il[1])
+    assert torch.allclose(il[0, :, 1].float(), torch.full((4, 4, 6), 1 / 3), atol=1e-3) and torch.allclose(il[0, :, 3].float(), torch.ones(4, 4, 6))
+    pipe._guidance_scale = 1.0
+    assert tuple(pipe.prepare_image_latents(x, "cpu", 4, 1).shape) == (1, 4, 4, 4, 6)
 
 
 def test_native_vae_host_logic_and_state_dict(cpu_ops):

@@ -188,7 +188,19 @@ def test_native_seine_runner_classes_vs_reference_fixture(monkeypatch, tmp_path,
     emu.install(monkeypatch)
     fx = torch.load(PIPE_FIXTURE)
     files = {t: fx["trajectory"][i] for i, t in enumerate(fx["inv_ts"])}
-    _check_job(spec.native_job("cpu", tmp_path, sm, trajectory_from=files), fx, sm)
+    job = spec.native_job("cpu", tmp_path, sm, trajectory_from=files)
+    _check_job(job, fx, sm)
+    if sm == "ddim":
+        # ``compute_masked_video_latents_at_0(config, video_input)`` with the reference's [b, f, c, H, W] argument (``run_pnp_edit.py:256``)
+        # and with the first frame alone: the same mask and latents (a toy VAE without posterior noise)
+        p2 = job["pipe"]
+        first = p2.src_video_frames[0].unsqueeze(0)
+        clip = torch.cat([first, torch.randn(len(p2.src_video_frames) - 1, *first.shape[1:])]).unsqueeze(0)     # (later frames are masked out)
+        m5, l5 = p2.compute_masked_video_latents_at_0(p2.config, clip)
+        m4, l4 = p2.compute_masked_video_latents_at_0(p2.config, first)
+        assert torch.equal(m5, m4) and torch.equal(l5, l4)
+        with pytest.raises(NotImplementedError):
+            p2.compute_masked_video_latents_at_0(p2.config, torch.cat([clip, clip]))
 
 
 @pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
@@ -349,3 +361,28 @@ def test_shipped_configs_resolve_to_the_references_values():
         mine = yaml.safe_load(open(os.path.join(root, "configs", "seine", name)))
         ref = yaml.safe_load(open(os.path.join(ref_stubs.REFERENCE_ROOT, "seine", "configs", name)))
         assert mine == ref, name
+
+
+def test_seine_helper_functions_of_the_references_pnp_utils(tmp_path):
+    """``save_video_as_frames`` / ``load_imgs`` / ``save_video`` / ``load_video_frames`` (``seine/pnp_utils.py:25-118``) under their own names."""
+    import numpy as np
+    from PIL import Image
+    from anyv2v_amd import seine_pipeline as sp
+    from anyv2v_amd.mp4 import read_mp4
+    yy, xx = np.mgrid[0:16, 0:24]
+    frames = torch.from_numpy(np.stack([np.stack([(xx * 8 + 20 * i) % 200, yy * 12, (xx + yy) * 5 + 10 * i]) for i in range(3)]).astype(np.uint8))
+    path = str(tmp_path / "clip.mp4")
+    sp.save_video(frames, path, fps=8)
+    vid, fps = read_mp4(path)
+    close = lambda img, t: np.abs(np.asarray(img).astype(int) - t.permute(1, 2, 0).numpy().astype(int)).mean() < 6      # (4:2:0 chroma)
+    assert fps == 8.0 and len(vid) == 3 and vid[0].size == (24, 16) and close(vid[1], frames[1])
+    sp.save_video(frames.float() / 255.0 + 1e-4, str(tmp_path / "clip01.mp4"), fps=10, scaling_255=True)
+    vid01, fps01 = read_mp4(str(tmp_path / "clip01.mp4"))
+    assert fps01 == 10.0 and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(vid, vid01))
+    sp.save_video_as_frames(path, img_size=(12, 8))
+    out = str(tmp_path / "clip")
+    assert sorted(os.listdir(out)) == ["00000.png", "00001.png", "00002.png"] and Image.open(os.path.join(out, "00000.png")).size == (12, 8)
+    imgs, pils = sp.load_imgs(out, 3, device="cpu", pil=True)
+    assert tuple(imgs.shape) == (3, 3, 8, 12) and imgs.dtype == torch.float32 and 0 <= float(imgs.min()) and float(imgs.max()) <= 1 and len(pils) == 3
+    paths, u8 = sp.load_video_frames(out, 3)
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (3, 3, 8, 12) and torch.equal((imgs * 255).round().to(torch.uint8), u8)
