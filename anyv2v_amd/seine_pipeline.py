@@ -114,6 +114,10 @@ def build_components(config, device, random_init_seed=None):
     (``run_ddim_inversion.py:65-88``), else -- there is no network -- random weights of the configured architecture
     (``random_init_seed`` / ANYV2V_RANDOM_INIT_SEED) with the synthetic VAE / text encoder."""
     import json
+    if not config.get("use_fp16", True):
+        # (``run_ddim_inversion.py:83-85`` keeps the model in fp32 then; ``enable_xformers_memory_efficient_attention`` only picks an
+        # attention implementation there and is accepted silently)
+        logger.warning("use_fp16: False -- the HIP kernels compute in fp16 with fp32 accumulation whatever this says")
     sd_path, ckpt = str(config.get("sd_path", "")), str(config.get("ckpt_path", ""))
     cfg = dict(SEINE_UNET_CONFIG)
     cj = os.path.join(sd_path, "unet", "config.json")
