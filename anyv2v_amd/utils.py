@@ -166,9 +166,19 @@ class LatentTrajectory:
         return tr
 
 
-def load_image(path) -> Image.Image:
-    img = Image.open(path)
-    return img.convert("RGB")
+def load_image(image) -> Image.Image:
+    """[3P] ``diffusers.utils.load_image`` (called at ``run_group_pnp_edit.py:120``, ``gradio_demo.py:151``): a path or a PIL image ->
+    EXIF orientation applied (a phone's JPEG of an edited first frame is stored rotated), RGB.  No URLs here (no network)."""
+    from PIL import ImageOps
+    if isinstance(image, (str, os.PathLike)):
+        if str(image).startswith(("http://", "https://")):
+            raise ValueError(f"load_image: {image} -- no network access here, give a local file")
+        if not os.path.isfile(image):
+            raise ValueError(f"Incorrect path or URL. URLs must start with `http://` or `https://`, and {image} is not a valid path.")
+        image = Image.open(image)
+    elif not isinstance(image, Image.Image):
+        raise ValueError("Incorrect format used for the image. Should be a URL linking to an image, a local path, or a PIL image.")
+    return ImageOps.exif_transpose(image).convert("RGB")
 
 
 def load_video_frames(frames_path, n_frames, image_size=(512, 512)):

@@ -331,6 +331,24 @@ def test_output_types_follow_the_references_tensor2vid():
     assert tuple(pipe.prepare_image_latents(x, "cpu", 4, 1).shape) == (1, 4, 4, 4, 6)
 
 
+def test_load_image_applies_exif_orientation_and_takes_pil_images(tmp_path):
+    """[3P] ``diffusers.utils.load_image``: path or PIL image, EXIF orientation applied, RGB."""
+    from PIL import Image
+    from anyv2v_amd.utils import load_image
+    img = Image.fromarray((np.arange(6 * 4 * 3) % 255).astype(np.uint8).reshape(6, 4, 3))      # 4 wide, 6 high
+    exif = Image.Exif()
+    exif[0x0112] = 6                                                                            # "rotate 90 CW to display"
+    p = str(tmp_path / "rot.jpg")
+    img.save(p, exif=exif, quality=100)
+    got = load_image(p)
+    assert got.mode == "RGB" and got.size == (6, 4)                                             # displayed orientation: 6 wide, 4 high
+    assert load_image(img.convert("L")).mode == "RGB" and load_image(img).size == (4, 6)
+    with pytest.raises(ValueError):
+        load_image(str(tmp_path / "missing.png"))
+    with pytest.raises(ValueError):
+        load_image(3)
+
+
 def test_native_vae_host_logic_and_state_dict(cpu_ops):
     """AutoencoderKL wiring over the token layout (CPU emulation of the ops): diffusers state-dict keys / shapes of the
     full SD-VAE, mini-config encode / decode vs the oracle, and the pipeline-facing adapter."""
