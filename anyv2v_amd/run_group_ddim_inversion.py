@@ -23,7 +23,7 @@ from .encoders import attach_synthetic_encoders
 from .parallel import FrameParallel, init_distributed, seed_for_entry, shard_entries
 from .pipeline import I2VGenXLPipeline
 from .schedulers import DDIMInverseScheduler, DDIMScheduler
-from .utils import (convert_video_to_frames, export_to_gif, inversion_is_complete, load_ddim_latents_at_t, load_video_frames,
+from .utils import (convert_video_to_frames, export_to_gif, export_to_video, inversion_is_complete, load_ddim_latents_at_t, load_video_frames,
                     seed_everything)
 
 MODEL_ID = "ali-vilab/i2vgen-xl"
@@ -180,7 +180,8 @@ class Stage1:
                 traj.wait()  # the latents directory is renamed into place when complete
                 os.makedirs(config.output_dir, exist_ok=True)
                 reconstructed_video = [f.resize((512, 512), resample=Image.LANCZOS) for f in reconstructed_video]
-                export_to_gif(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.gif"), fps=10)
+                export_to_video(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.mp4"), fps=10)   # (:183-187)
+                export_to_gif(reconstructed_video, os.path.join(config.output_dir, "ddim_reconstruction.gif"))             # (:188-191)
                 logger.info(f"Saved reconstructed video to {config.output_dir}")
         traj.wait()
 

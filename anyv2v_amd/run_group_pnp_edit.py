@@ -175,7 +175,7 @@ class Stage2:
         edited_video = [frame.resize(tuple(config.image_size), resample=Image.LANCZOS) for frame in edited_video]
         name = "video"
         export_to_video(edited_video, os.path.join(output_dir, f"{name}.mp4"), fps=config.target_fps)
-        export_to_gif(edited_video, os.path.join(output_dir, f"{name}.gif"), fps=config.target_fps)
+        export_to_gif(edited_video, os.path.join(output_dir, f"{name}.gif"))      # (no rate, as ``:179``: 100 ms per frame)
         logger.info(f"Saved video to: {os.path.join(output_dir, f'{name}.mp4')}")
         logger.info(f"Saved gif to: {os.path.join(output_dir, f'{name}.gif')}")
         for i, frame in enumerate(edited_video):

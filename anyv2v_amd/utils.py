@@ -229,6 +229,12 @@ def export_to_video(frames: List[Image.Image], path: str, fps: int = 8):
     return write_mp4(frames, path, fps=fps)
 
 
-def export_to_gif(frames: List[Image.Image], path: str, fps: int = 8):
-    frames[0].save(path, save_all=True, append_images=frames[1:], optimize=False, duration=int(1000 / fps), loop=0)
+def export_to_gif(frames: List[Image.Image], path: Optional[str] = None, fps: int = 10):
+    """[3P] ``diffusers.utils.export_to_gif`` (0.26: a fixed 100 ms per frame, endless loop, no palette optimisation; later releases
+    added ``fps`` with the same default) -- the reference's runners never pass a rate (``run_group_ddim_inversion.py:135,188``,
+    ``run_group_pnp_edit.py:179``), so their GIFs play at 10 frames per second whatever ``target_fps`` says."""
+    if path is None:
+        import tempfile
+        path = tempfile.NamedTemporaryFile(suffix=".gif", delete=False).name
+    frames[0].save(path, save_all=True, append_images=frames[1:], optimize=False, duration=1000 // fps, loop=0)
     return path

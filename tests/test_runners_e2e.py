@@ -243,10 +243,17 @@ def _check_file_formats(tmp_path, device):
     assert len(lat_files) == N_STEPS and all(f.startswith("ddim_latents_") and f.endswith(".pt") for f in lat_files)
     x = torch.load(os.path.join(inv_dir, "ddim_latents", lat_files[0]))
     assert tuple(x.shape) == (1, 4, N_FRAMES, SIZE // 8, SIZE // 8) and torch.isfinite(x.float()).all()
-    assert os.path.isfile(os.path.join(inv_dir, "ddim_reconstruction.gif"))
+    # reconstruction: 512 x 512 whatever the clip's size, mp4 at 10 fps and a GIF at diffusers' fixed 100 ms per frame (:181-191)
+    from anyv2v_amd.mp4 import read_mp4
+    rec, rec_fps = read_mp4(os.path.join(inv_dir, "ddim_reconstruction.mp4"))
+    assert len(rec) == N_FRAMES and rec[0].size == (512, 512) and rec_fps == 10.0
+    gif = Image.open(os.path.join(inv_dir, "ddim_reconstruction.gif"))
+    assert gif.n_frames == N_FRAMES and gif.size == (512, 512) and gif.info["duration"] == 100 and gif.info.get("loop") == 0
     assert "ddim_init_latents_t_idx_0_nsteps_4_cfg_9.0_pnpf0.25_pnps0.5_pnpt0.75" == os.path.basename(out_dir)
     names = sorted(os.listdir(out_dir))
-    assert "video.gif" in names and "edited_latents.pt" in names
+    assert "video.gif" in names and "video.mp4" in names and "edited_latents.pt" in names
+    assert Image.open(os.path.join(out_dir, "video.gif")).info["duration"] == 100        # (no rate given at run_group_pnp_edit.py:179)
+    assert read_mp4(os.path.join(out_dir, "video.mp4"))[1] == 8.0                         # (fps=config.target_fps at :178)
     assert [n for n in names if n.endswith(".png")] == [f"video_{i:05d}.png" for i in range(N_FRAMES)]
     lat = torch.load(os.path.join(out_dir, "edited_latents.pt"))
     assert tuple(lat.shape) == (1, 4, N_FRAMES, SIZE // 8, SIZE // 8) and torch.isfinite(lat.float()).all()
