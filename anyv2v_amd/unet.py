@@ -791,9 +791,7 @@ def _nearest_rows(n_img, H, W, Ho, Wo, device):
     with ``size=``: floor(o * H / Ho))."""
     key = (n_img, H, W, Ho, Wo, str(device))
     idx = _NEAREST_ROWS.get(key)
-    if idx is None:
-        if len(_NEAREST_ROWS) > 64:
-            _NEAREST_ROWS.clear()
+    if idx is None:   # (never evicted: a captured step graph reads the table it was captured with; one entry per geometry, <= 0.5 MB)
         yi = (torch.arange(Ho) * H) // Ho
         xi = (torch.arange(Wo) * W) // Wo
         one = (yi[:, None] * W + xi[None, :]).reshape(-1)
