@@ -650,7 +650,10 @@ def main():
                                     "`python -m anyv2v_amd.run_group_anyv2v` runs a multi-clip job on one GPU") if args.overlap
                        else "serial: inversion step, then edit step, one stream",
                        **({"pipelined_bit_equal_to_serial": check_overlap(),
-                           "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 3)} if args.overlap else {}),
+                           "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 3),
+                           # one clip on its own (no second clip to overlap with): the serial order's rate
+                           "single_clip_frames_per_s": None if serial_ms is None else round(FRAMES / STEPS_PER_STAGE / (serial_ms * 1e-3), 4)}
+                          if args.overlap else {}),
                        "excluded": "`value` is the steady-state loop rate: VAE encode/decode, CLIP encoders and file I/O are outside "
                                    "(SURVEY 8(f) F1/F2); the `clip` object times one whole clip including VAE and the trajectory files"},
         }
