@@ -4,6 +4,11 @@ A "step" here is ONE inversion denoise step (UNet B=1 + inverse-DDIM update + tr
 denoise step (source-latent read, UNet B=3 with conv / spatial / temporal feature injection, CFG 9.0 + DDIM update)
 on one synthetic 16-frame 512x512 clip, i.e. 1/50 of BASELINE config 3 (50-step inversion + 50-step edit);
 --steps 50 is exactly one clip.  frames/sec = 16 * (K / 50) * n_gpus / seconds.
+The timed region is the SERIAL single-clip order (inversion step, then edit step, one stream): BASELINE config 3 is ONE clip, and
+SURVEY 8(d) defines frames/s as 16 / wall-seconds for one clip, so `value` = 16 / 50 / ms_per_step.  The job-level two-clip software
+pipeline (next clip's inversion beside this clip's edit; run_group_anyv2v) is measured after the timed region and reported as
+`config.pipelined_ms_per_step` / `config.job_frames_per_s` (`--pipelined` times it instead).  `configs` adds BASELINE config 2
+(inversion alone) and config 5 (128 frames: one B=1 and one B=3 step at full size).
 Everything inside the step runs in the hand-written HIP kernels (anyv2v_amd/libanyv2v_hip.so); weights are random
 (seeded) with the exact I2VGen-XL architecture, inputs synthetic and HBM-resident; VAE/CLIP pre/post are outside.
 
@@ -461,6 +466,69 @@ def multi_edit(pipe, device, seed):
     return res
 
 
+def config5_steps(pipe, device, seed, frames=128):
+    """BASELINE config 5 (long-video mode: 1 clip x 128 frames x 512x512, one GPU): one inversion step (UNet B=1) and one PnP edit step
+    (UNet B=3, conv + spatial + temporal injection on) of the full UNet at full size, HIP-graph replays, median of 3 after the capture
+    step.  Temporal attention runs over all 128 frames (the strided flash kernel); the parity of this size is tests/gpu_checks.py
+    check_config5_full_size."""
+    from anyv2v_amd import pnp_utils
+    from anyv2v_amd.pipeline import _StepEngine
+    from anyv2v_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *sh: torch.randn(*sh, generator=g).to(torch.float16).to(device)
+    lat, ehs, ie, il = r(1, 4, frames, LAT, LAT), r(3, 77, 1024), r(3, 1, 1024), r(2, 4, frames, LAT, LAT)
+    ie[1].zero_()
+    for i in range(1, frames):
+        il[:, :, i] = i / (frames - 1)
+    il_all = torch.stack([il[0], il[1], il[1]]).contiguous()
+    inv, fwd = DDIMInverseScheduler(), DDIMScheduler()
+    inv.set_timesteps(STEPS_PER_STAGE)
+    fwd.set_timesteps(STEPS_PER_STAGE)
+    ts_inv, ts_pnp = [int(t) for t in inv.timesteps], [int(t) for t in fwd.timesteps]
+    pnp_utils.register_conv_injection(pipe, fwd.timesteps)
+    pnp_utils.register_spatial_attention_pnp(pipe, fwd.timesteps)
+    pnp_utils.register_temp_attention_pnp(pipe, fwd.timesteps)
+    s_inv, s_pnp = lat.clone(), lat.repeat(3, 1, 1, 1, 1).contiguous()
+    cond1 = dict(encoder_hidden_states=ehs[:1].contiguous(), fps=torch.tensor([8], device=device),
+                 image_latents=il_all[:1].contiguous(), image_embeddings=ie[:1].contiguous())
+    cond3 = dict(encoder_hidden_states=ehs, fps=torch.tensor([8, 8, 8], device=device), image_latents=il_all, image_embeddings=ie)
+    out = {}
+    for name, mk, tt, cf, key, reg, smp in (
+            ("inversion_step_B1_ms", lambda: _StepEngine(pipe, s_inv, cond1, b_unc=-1, b_cond=0, guidance=1.0, dup_slots=[]),
+             torch.tensor(ts_inv, dtype=torch.float32, device=device)[:, None].contiguous(), inv.coefficient_table(ts_inv, device),
+             ("inv",), None, s_inv),
+            ("pnp_edit_step_B3_ms", lambda: _StepEngine(pipe, s_pnp, cond3, b_unc=1, b_cond=2, guidance=9.0, dup_slots=[1],
+                                                        shared_stem=True),
+             torch.tensor(ts_pnp, dtype=torch.float32, device=device)[:, None].expand(-1, 3).contiguous(),
+             fwd.coefficient_table(ts_pnp, device), ("pnp",), ts_pnp, s_pnp)):
+        if reg is None:
+            pnp_utils.clear_time(pipe)
+        else:
+            pnp_utils.register_time(pipe, reg[0])
+        eng = mk()
+        if reg is not None:
+            eng.drop_src_tail = True
+        eng.step(tt[0], cf[0], key=key + (pnp_utils.injection_state(pipe) if reg is not None else ()))   # graph capture
+        torch.cuda.synchronize()
+        times = []
+        for j in (1, 2, 3):
+            t0 = time.perf_counter()
+            eng.step(tt[j], cf[j], key=key + (pnp_utils.injection_state(pipe) if reg is not None else ()))
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        out[name] = round(sorted(times)[1], 2)
+        out[name.replace("_ms", "_finite")] = bool(torch.isfinite(smp.float()).all())
+        del eng
+        torch.cuda.empty_cache()
+    pnp_utils.clear_time(pipe)
+    pair_ms = out["inversion_step_B1_ms"] + out["pnp_edit_step_B3_ms"]
+    out["frames_per_s"] = round(frames / STEPS_PER_STAGE / (pair_ms * 1e-3), 4)
+    out["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+    out["what"] = (f"BASELINE config 5: 1 clip x {frames} f x 512x512 on one GPU; one inversion step + one PnP edit step at full size (graph "
+                   f"replays, median of 3); frames_per_s = {frames} / (50 x their sum) -- the 50-step loops are not run in the bench")
+    return out
+
+
 def finish_distributed(dist, dt, latents, world, device):
     """The one collective of the sharded job -- all_gather of every rank's edited latents (512 KiB per rank at
     16f x 512^2; RCCL over xGMI on the GPU node, gloo in the CPU test) -- plus MAX over ranks of the timed region."""
@@ -481,13 +549,14 @@ def main():
     ap.add_argument("--no-clip", action="store_true", help="skip the end-to-end timing of one whole clip")
     ap.add_argument("--no-multi-edit", action="store_true", help="skip the several-edits-of-one-clip timing (source feature cache)")
     ap.add_argument("--seed", type=int, default=8888)
-    ap.add_argument("--serial", action="store_true",
-                    help="the inversion step and the edit step of a pair one after the other on one stream (rounds 1-3); default: the "
-                         "job's software pipeline -- the inversion step of the NEXT clip beside the edit step of the current clip, on "
-                         "two streams, as run_group_anyv2v runs a multi-clip job")
-    ap.add_argument("--overlap", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="time the job-level two-clip software pipeline (inversion step of the NEXT clip beside the edit step of the "
+                         "current clip, two streams, as run_group_anyv2v runs a multi-clip job) instead of the single-clip serial order; "
+                         "by default the pipelined rate is measured after the timed region and reported as config.pipelined_ms_per_step")
+    ap.add_argument("--serial", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 2 and 5)")
     args = ap.parse_args()
-    args.overlap = not args.serial
+    args.overlap = args.pipelined and not args.serial
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -550,7 +619,8 @@ def main():
         e_pnp.step(tt_pnp[j], cf_pnp[j], key=("pnp",) + pnp_utils.injection_state(pipe))
 
     pair_serial = pair
-    if args.overlap:
+
+    def make_pipelined():
         # software pipeline over the clips of a job: clip k + 1 is inverted while clip k is edited.  The edit reads the trajectory
         # of ITS clip (traj_prev, produced by an earlier inversion -- filled here, outside the timed region), the inversion writes
         # the next clip's; the two steps have no data in common and run on two streams.
@@ -566,7 +636,7 @@ def main():
 
         pacing = os.environ.get("ANYV2V_PIPELINE_PACING", "1") == "1"
 
-        def pair(i):  # noqa: F811
+        def pair_overlapped(i):
             j = i % STEPS_PER_STAGE
             # the edit step is enqueued first and paces the inversion step (run_group_anyv2v.main_pipelined): inversion step j does not
             # start before edit step j does, so the cheaper loop cannot race ahead and leave the edit alone on the chip
@@ -585,8 +655,6 @@ def main():
                 pnp_utils.clear_time(pipe)
                 e_inv.step(tt_inv[j], cf_inv[j], key=("inv",))
                 traj[j].copy_(s_inv[0])
-        pair_overlapped = pair
-
         def check_overlap(n=3):
             """The same n pairs once with the two streams side by side, once serialised: bit-equal latents."""
             outs = []
@@ -601,6 +669,11 @@ def main():
                 torch.cuda.synchronize()
                 outs.append((s_inv.clone(), s_pnp.clone()))
             return bool(torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]))
+        return pair_overlapped, check_overlap
+
+    check_overlap = None
+    if args.overlap:
+        pair, check_overlap = make_pipelined()
     for i in range(args.warmup):
         pair(i)
     torch.cuda.synchronize()
@@ -619,17 +692,45 @@ def main():
         dt, _gathered = finish_distributed(dist, dt, s_pnp[2:3].contiguous(), world, device)
     finite = bool(torch.isfinite(s_pnp.float()).all() and torch.isfinite(s_inv.float()).all())
     rccl_ranks = len(_gathered) if dist is not None else None
-    serial_ms = None
-    if args.overlap and world == 1:
-        # the same pairs one after the other on one stream (what rounds 1-3 reported), for comparison
+    serial_ms = pipelined_ms = None
+    bit_equal = None
+    if world == 1:
         n = min(args.steps, 20)
-        pair_serial(0)
+        if args.overlap:
+            # the same pairs one after the other on one stream (the single-clip order), for comparison
+            other = pair_serial
+        else:
+            # the job-level schedule (two clips on two streams), measured AFTER the timed region: it is not BASELINE config 3 (one clip
+            # cannot overlap its own inversion with its own edit) and is reported beside the headline, never as `value`
+            other, check_overlap = make_pipelined()
+        other(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
-            pair_serial(i)
+            other(i)
         torch.cuda.synchronize()
-        serial_ms = (time.perf_counter() - t0) / n * 1e3
+        other_ms = (time.perf_counter() - t0) / n * 1e3
+        serial_ms, pipelined_ms = (other_ms, dt / args.steps * 1e3) if args.overlap else (dt / args.steps * 1e3, other_ms)
+        bit_equal = check_overlap()
+
+    config2 = None
+    if world == 1 and not args.no_configs:
+        # BASELINE config 2: the 50-step DDIM inversion of one 16 f x 512^2 clip alone (UNet B=1, no hooks), timed as n steps of that loop
+        n = min(args.steps, 20)
+        s_inv.copy_(lat)
+        pnp_utils.clear_time(pipe)
+        e_inv.step(tt_inv[0], cf_inv[0], key=("inv",))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            e_inv.step(tt_inv[i], cf_inv[i], key=("inv",))
+            traj[i].copy_(s_inv[0])
+        torch.cuda.synchronize()
+        inv_ms = (time.perf_counter() - t0) / n * 1e3
+        config2 = {"inversion_step_B1_ms": round(inv_ms, 3), "steps_timed": n,
+                   "frames_per_s": round(FRAMES / STEPS_PER_STAGE / (inv_ms * 1e-3), 4),
+                   "what": "BASELINE config 2: DDIM inversion, 50 steps, 1 clip x 16 f x 512x512, fp16, one GPU; frames_per_s = 16 / (50 x "
+                           "the measured step of that loop, trajectory write included)"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -644,16 +745,17 @@ def main():
                                    "1 inversion step + 1 edit step = 1/50 clip; I2VGen-XL 3D-UNet 1.42B params, random init",
                        "steps_per_stage": STEPS_PER_STAGE, "frames": FRAMES, "latent": [4, FRAMES, LAT, LAT],
                        "hip_graphs": os.environ.get("ANYV2V_NO_GRAPH", "0") != "1", "finite": finite,
-                       "schedule": ("pipelined: the job's steady state -- the inversion step of clip k + 1 and the edit step of clip k "
-                                    "(which reads clip k's finished trajectory, resident in HBM) are enqueued on two HIP streams and "
-                                    "run side by side; same launches, same results as the serial order (checked below); this is how "
-                                    "`python -m anyv2v_amd.run_group_anyv2v` runs a multi-clip job on one GPU") if args.overlap
-                       else "serial: inversion step, then edit step, one stream",
-                       **({"pipelined_bit_equal_to_serial": check_overlap(),
-                           "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 3),
-                           # one clip on its own (no second clip to overlap with): the serial order's rate
-                           "single_clip_frames_per_s": None if serial_ms is None else round(FRAMES / STEPS_PER_STAGE / (serial_ms * 1e-3), 4)}
-                          if args.overlap else {}),
+                       "schedule": ("pipelined (--pipelined): the job's steady state -- the inversion step of clip k + 1 and the edit step of "
+                                    "clip k on two HIP streams; NOT BASELINE config 3 (which is one clip)") if args.overlap
+                       else ("serial: one clip -- inversion step, then edit step, one stream (SURVEY 8(d): frames/s = 16 / seconds for "
+                             "one clip; value = 16 / 50 / ms_per_step)"),
+                       # the job-level extra: a multi-clip job on one GPU runs the next clip's inversion beside the current clip's edit
+                       # (python -m anyv2v_amd.run_group_anyv2v); bit-equal to the serial order; no BASELINE config feeds two clips to a GPU
+                       "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 3),
+                       "single_clip_frames_per_s": None if serial_ms is None else round(FRAMES / STEPS_PER_STAGE / (serial_ms * 1e-3), 4),
+                       "pipelined_ms_per_step": None if pipelined_ms is None else round(pipelined_ms, 3),
+                       "job_frames_per_s": None if pipelined_ms is None else round(FRAMES / STEPS_PER_STAGE / (pipelined_ms * 1e-3), 4),
+                       "pipelined_bit_equal_to_serial": bit_equal,
                        "excluded": "`value` is the steady-state loop rate: VAE encode/decode, CLIP encoders and file I/O are outside "
                                    "(SURVEY 8(f) F1/F2); the `clip` object times one whole clip including VAE and the trajectory files"},
         }
@@ -699,6 +801,13 @@ def main():
             torch.cuda.empty_cache()
             pnp_utils.clear_time(pipe)
             line["multi_edit"] = multi_edit(pipe, device, args.seed)
+        if world == 1 and not args.no_configs:
+            e_inv = e_pnp = None
+            torch.cuda.empty_cache()
+            line["configs"] = {"config_2_inversion_only": config2, "config_5_long_video": config5_steps(pipe, device, args.seed),
+                               "config_3": "the headline (`value`, `ms_per_step`)",
+                               "config_1": "the CPU-runnable case: `cpu_baseline` times it; tests/ hold its parity",
+                               "config_4": "8 clips on 8 GPUs = this bench under torchrun --nproc-per-node 8 (one clip per rank + one all_gather)"}
         if world == 1 and not args.no_cpu_baseline:
             del pipe, e_inv, e_pnp
             torch.cuda.empty_cache()
