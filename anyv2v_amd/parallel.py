@@ -63,33 +63,41 @@ def seed_for_entry(base_seed: int, entry_index: int) -> int:
     return int(base_seed) + 1000003 * int(entry_index)
 
 
-def gather_latents(latents: Sequence[torch.Tensor], n_entries: int, like_shape, dtype, device) -> torch.Tensor:
+def gather_latents(latents: Sequence[torch.Tensor], n_entries: int, like_shape, dtype, device, indices: Sequence[int] = None) -> torch.Tensor:
     """The ONE collective of the sharded job: all_gather of every rank's edited latents (``[1,4,F,h,w]`` per entry,
     512 KiB at 16f x 512^2; RCCL over xGMI on the node, gloo in the CPU tests).
 
-    ``latents``: this rank's results in processing order (entry ``rank``, ``rank + world``, ...; ``shard_entries``).  A rank
-    may hold several entries (14 demo edits on 8 GPUs) or none: every rank contributes ``ceil(n_entries / world)`` slots
-    (zero-padded) in ONE message, and the result is re-ordered to entry order.  Returns ``[n_entries, 4, F, h, w]``."""
+    ``latents``: this rank's results; ``indices``: the entry index of each (any dealing: round-robin ``shard_entries``, clip-wise
+    ``shard_by_clip``, unbalanced).  Without ``indices`` the round-robin dealing is assumed (entry ``rank``, ``rank + world``, ...).
+    A rank may hold several entries (14 demo edits on 8 GPUs) or none: the ranks first exchange their index lists, every rank then
+    contributes ``max over ranks of its entry count`` slots (zero-padded) in ONE message, and the result is scattered to entry
+    order by index.  Returns ``[n_entries, 4, F, h, w]``."""
     import torch.distributed as dist
-    world = dist.get_world_size()
-    slots = max(1, -(-int(n_entries) // world))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_entries = int(n_entries)
     like_shape = tuple(like_shape)[-4:]
-    # Agree on validity BEFORE the collective: a rank that raised on its own (too many results, a clip with another geometry)
-    # would leave the others blocked in all_gather until the backend's timeout.  Every rank reports (ok, its geometry); all of
-    # them then raise together, or none does.
+    if indices is None:
+        indices = [rank + k * world for k in range(len(latents))]
+    indices = [int(i) for i in indices]
+    # Agree on validity BEFORE the collective: a rank that raised on its own (a clip with another geometry, an index out of range)
+    # would leave the others blocked in all_gather until the backend's timeout.  Every rank reports (ok, its indices, its geometry);
+    # all of them then raise together, or none does.
     mine = [tuple(x.shape[-4:]) for x in latents]
-    ok = len(latents) <= slots and all(sh == like_shape for sh in mine)
+    ok = len(indices) == len(latents) and all(sh == like_shape for sh in mine) and all(0 <= i < n_entries for i in indices)
     reports = [None] * world
-    dist.all_gather_object(reports, (bool(ok), len(latents), sorted(set(mine)), like_shape))
-    if not all(r[0] for r in reports) or len({r[3] for r in reports}) != 1:
-        raise ValueError(f"gather_latents: ranks disagree or hold invalid results (ok, n_results, geometries, expected) per rank: "
-                         f"{reports}; {n_entries} entries over {world} ranks = {slots} slots each; all entries must share one geometry")
+    dist.all_gather_object(reports, (bool(ok), indices, sorted(set(mine)), like_shape))
+    held = sorted(i for r in reports for i in r[1])
+    if not all(r[0] for r in reports) or len({r[3] for r in reports}) != 1 or held != list(range(n_entries)):
+        raise ValueError(f"gather_latents: ranks disagree or hold invalid results (ok, entry indices, geometries, expected) per rank: "
+                         f"{reports}; the {n_entries} entries must each be held by exactly one of the {world} ranks and share one geometry")
+    slots = max(1, max(len(r[1]) for r in reports))
     buf = torch.zeros((slots,) + like_shape, dtype=dtype, device=device)
     for k, x in enumerate(latents):
         buf[k].copy_(x.reshape(like_shape))
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
-    return torch.stack([out[i % world][i // world] for i in range(int(n_entries))])
+    where = {i: (r, k) for r, rep in enumerate(reports) for k, i in enumerate(rep[1])}
+    return torch.stack([out[where[i][0]][where[i][1]] for i in range(n_entries)])
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -184,7 +184,8 @@ class Stage2:
 
     def finish(self):
         template_config, device = self.template_config, self.device
-        my_latents = [self.my_latents[k] for k in sorted(self.my_latents)]   # entry order, whatever order they were run in
+        my_idx = sorted(self.my_latents)                                     # entry order, whatever order they were run in
+        my_latents = [self.my_latents[k] for k in my_idx]
         if self.fp_mode:
             import torch.distributed as dist
             dist.barrier()
@@ -192,7 +193,8 @@ class Stage2:
             import torch.distributed as dist
             shape = self.lat_shape or (1, 4, template_config.n_frames, template_config.image_size[1] // 8, template_config.image_size[0] // 8)
             # every entry's latents reach rank 0, in entry order (a rank may have run several entries, or none)
-            gathered = gather_latents(my_latents, len(self.all_active), shape, torch.float16, device)
+            # (the entry indices travel with the latents: clip-wise dealing -- run_group_anyv2v under torchrun -- is not round-robin)
+            gathered = gather_latents(my_latents, len(self.all_active), shape, torch.float16, device, indices=my_idx)
             if self.rank == 0:
                 out = os.path.join(template_config.get("data_dir", "."), "gathered_latents.pt")
                 torch.save(gathered.cpu(), out)

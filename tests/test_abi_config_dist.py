@@ -251,6 +251,42 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _clipwise_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from anyv2v_amd.parallel import gather_latents, init_distributed, shard_by_clip
+    r, lr, w = init_distributed("gloo")
+    res = {}
+    for tag, clips in (("AAB", "AAB"), ("AAAB", "AAAB"), ("ABA", "ABA")):
+        inv = [{"video_name": "A"}, {"video_name": "B"}]
+        edits = [{"video_name": c, "id": i} for i, c in enumerate(clips)]
+        _, mine = shard_by_clip(inv, edits, r, w)
+        idx = [e["id"] for e in mine]
+        lats = [torch.full((1, 4, 2, 3, 3), float(i), dtype=torch.float16) for i in idx]
+        got = gather_latents(lats, len(edits), (1, 4, 2, 3, 3), torch.float16, "cpu", indices=idx)
+        res[tag] = [float(g[0, 0, 0, 0]) for g in got]
+    # an entry held twice / not at all is refused on every rank together
+    try:
+        gather_latents([torch.zeros(1, 4, 2, 3, 3, dtype=torch.float16)], 2, (1, 4, 2, 3, 3), torch.float16, "cpu", indices=[0])
+        res["dup"] = "no error"
+    except ValueError as e:
+        res["dup"] = "ValueError" if "exactly one" in str(e) else str(e)
+    torch.save(res, os.path.join(out_dir, f"c{r}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_latents_scatters_by_entry_index_for_clipwise_dealing(tmp_path):
+    """``shard_by_clip`` is not round-robin -- edits [A, A, B] put entries 0, 1 on rank 0 and 2 on rank 1, [A, A, A, B]
+    three entries on rank 0 -- so the entry indices travel with the latents and the gathered tensor is scattered by index."""
+    import torch.multiprocessing as mp
+    mp.spawn(_clipwise_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "c0.pt"), torch.load(tmp_path / "c1.pt")
+    assert a == b
+    assert a["AAB"] == [0.0, 1.0, 2.0] and a["AAAB"] == [0.0, 1.0, 2.0, 3.0] and a["ABA"] == [0.0, 1.0, 2.0] and a["dup"] == "ValueError"
+
+
 def test_all_gather_of_edited_latents_world2_gloo(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()

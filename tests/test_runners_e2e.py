@@ -441,8 +441,9 @@ def test_gather_latents_raises_on_every_rank_together(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------- pipelined fused runner
-def _two_clip_job(base, tag):
-    """Two clips (the second: the first one's frames mirrored), three edits in an order that is NOT grouped by clip."""
+def _two_clip_job(base, tag, grouped=False):
+    """Two clips (the second: the first one's frames mirrored), three edits in an order that is NOT grouped by clip -- or, with
+    ``grouped``, the usual edit list grouped by clip ([clip, clip, clip2]: clip-wise dealing then differs from round-robin dealing)."""
     clip, clip2 = os.path.join(base, "demo", "clip"), os.path.join(base, "demo", "clip2")
     if not os.path.isdir(clip2):
         os.makedirs(os.path.join(clip2, "edited_first_frame"))
@@ -456,6 +457,8 @@ def _two_clip_job(base, tag):
     ed_list = [dict(e, edited_video_name="a"), dict(e, video_name="clip2", edited_first_frame_path="demo/clip2/edited_first_frame/e.png",
                                                       edited_video_name="b", editing_prompt="a cat"),
                dict(e, edited_video_name="c", editing_prompt="a dog", pnp_f_t=0.5)]
+    if grouped:
+        ed_list = [ed_list[0], ed_list[2], ed_list[1]]
     return inv, inv_list, ed, ed_list
 
 
@@ -544,7 +547,8 @@ def _clip_shard_worker(rank, world, port, base, tag, pipelined):
     os.environ["ANYV2V_NO_GRAPH"] = "1"
     torch.set_grad_enabled(False)
     from anyv2v_amd import run_group_anyv2v as fused
-    inv, inv_list, ed, ed_list = _two_clip_job(base, tag)
+    # edit list grouped by clip: rank 0 holds entries 0 and 1, rank 1 entry 2 -- not the round-robin pattern
+    inv, inv_list, ed, ed_list = _two_clip_job(base, tag, grouped=True)
     fused.main(inv, inv_list, ed, ed_list, torch.device("cpu"), logging.getLogger("e2e"), synthetic_encoders=True, pipelined=pipelined)
     import torch.distributed as dist
     dist.destroy_process_group()
@@ -563,6 +567,13 @@ def test_fused_runner_world2_deals_whole_clips_and_pipelines_them(tmp_path):
         os.replace(os.path.join(base, "gathered_latents.pt"), os.path.join(base, f"gathered_{tag}.pt"))
     a, b = torch.load(os.path.join(base, "gathered_w2s.pt")), torch.load(os.path.join(base, "gathered_w2p.pt"))
     assert tuple(a.shape) == (3, 4, N_FRAMES, SIZE // 8, SIZE // 8) and torch.equal(a, b)
+    # gathered_latents.pt is in ENTRY order under both dealings: entry k of the file is the edited_latents.pt of edit k
+    for k, name in enumerate(("a", "c", "b")):
+        roots = [r for r in _tree(os.path.join(base, "Results", "Prompt-Based-Editing", "mini-w2p")) if r.endswith("edited_latents.pt") and
+                 r.split(os.sep)[1] == name]
+        assert len(roots) == 1, roots
+        lat = torch.load(os.path.join(base, "Results", "Prompt-Based-Editing", "mini-w2p", roots[0]))
+        assert torch.equal(b[k], lat[0]), (k, name)
     for top in ("inversions", os.path.join("Results", "Prompt-Based-Editing")):
         x, y = _tree(os.path.join(base, top, "mini-w2s")), _tree(os.path.join(base, top, "mini-w2p"))
         assert sorted(x) == sorted(y) and len(x) > 0
