@@ -158,6 +158,9 @@ def ff_geglu(x: torch.Tensor, w1p: torch.Tensor, b1p: torch.Tensor, w2s: torch.T
     assert tuple(w1p.shape) == (2 * H, Cc) and tuple(w2s.shape) == (H // 32, Cc, 32) and b1p.numel() == 2 * H and b2.numel() == Cc
     if out is None:
         out = torch.empty((M, Cc), dtype=torch.float16, device=x.device)
+    for name, t in (("residual", residual), ("out", out)):   # the kernel reads / writes them as 8-byte vectors at row * ld + column
+        assert t is None or (tuple(t.shape) == (M, Cc) and t.dtype == torch.float16 and t.stride(1) == 1 and t.device == x.device), \
+            f"ff_geglu: {name} must be an fp16 [{M}, {Cc}] matrix with unit column stride on {x.device}"
     d = _lib.FFDesc()
     d.X, d.W1, d.b1, d.W2, d.b2, d.Y = _p(x), _p(w1p), _p(b1p), _p(w2s), _p(b2), _p(out)
     d.R = _p(residual) if residual is not None else None

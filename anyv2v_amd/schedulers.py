@@ -195,7 +195,8 @@ class DDIMScheduler(_DDIMBase):
         sigma = float(eta) * math.sqrt((1.0 - a_p) / (1.0 - a_t)) * math.sqrt(max(1.0 - a_t / a_p, 0.0))
         return (math.sqrt(a_t), math.sqrt(1.0 - a_t), math.sqrt(a_p), math.sqrt(max(1.0 - a_p - sigma * sigma, 0.0)), sigma)
 
-    noise_on_host = True    # eta > 0: the variance noise is drawn on the host (a seed means the same sample on any device)
+    noise_on_host = False   # eta > 0: the variance noise is drawn where diffusers' randn_tensor draws it (on the sample's device, or on the
+                            # host when the generator is a CPU generator); True forces the host draw (a seed then means the same sample on any device)
 
     def draw_noise(self, like: torch.Tensor, generator=None):
         if self.noise_on_host or (generator is not None and generator.device.type == "cpu"):

@@ -796,6 +796,8 @@ def _nearest_rows(n_img, H, W, Ho, Wo, device):
         xi = (torch.arange(Wo) * W) // Wo
         one = (yi[:, None] * W + xi[None, :]).reshape(-1)
         idx = (torch.arange(n_img)[:, None] * (H * W) + one[None, :]).reshape(-1).to(device=device, dtype=torch.int32).contiguous()
+        if idx.is_cuda:   # the table is shared by every stream of the process (clip pipeline: two loops, two streams): its H2D copy from
+            torch.cuda.current_stream(idx.device).synchronize()   # pageable memory is complete before another stream may read it
         _NEAREST_ROWS[key] = idx
     return idx
 

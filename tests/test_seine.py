@@ -387,134 +387,3 @@ def test_seine_helper_functions_of_the_references_pnp_utils(tmp_path):
     assert tuple(imgs.shape) == (3, 3, 8, 12) and imgs.dtype == torch.float32 and 0 <= float(imgs.min()) and float(imgs.max()) <= 1 and len(pils) == 3
     paths, u8 = sp.load_video_frames(out, 3)
     assert u8.dtype == torch.uint8 and tuple(u8.shape) == (3, 3, 8, 12) and torch.equal((imgs * 255).round().to(torch.uint8), u8)
-
-
-# ------------------------------------------------------------------------------------------------- SEINE's diffusion/ package (sampling side)
-def _load_reference_diffusion(tag):
-    import importlib.util
-    import sys
-    root = os.path.join(ref_stubs.REFERENCE_ROOT, "seine", "diffusion")
-    name = f"_ref_seine_diffusion_{tag}"
-    spec_ = importlib.util.spec_from_file_location(name, os.path.join(root, "__init__.py"), submodule_search_locations=[root])
-    mod = importlib.util.module_from_spec(spec_)
-    sys.modules[name] = mod
-    spec_.loader.exec_module(mod)
-    return mod, name
-
-
-@pytest.mark.skipif(not ref_stubs.reference_available(), reason="needs /root/reference")
-@pytest.mark.parametrize("respacing,kw", [("10", {}), ("ddim8", dict(sigma_small=True)), ("7", dict(predict_xstart=True, noise_schedule="squaredcos_cap_v2"))])
-def test_native_seine_diffusion_package_vs_the_references_own(monkeypatch, respacing, kw):
-    """``anyv2v_amd.seine_diffusion.create_diffusion`` vs ``seine/diffusion`` imported verbatim: the respaced tables, ``p_sample`` (same
-    global noise stream), ``ddim_sample`` with and without eta, ``ddim_reverse_sample`` and the two loops with mask / x_start /
-    use_concat, with and without clipping of the predicted x0 -- a toy model that sees the ORIGINAL timestep numbers."""
-    import sys
-    import warnings as w
-    w.filterwarnings("ignore")
-    from anyv2v_amd import seine_diffusion as sd
-    ref_mod, name = _load_reference_diffusion(respacing)
-    try:
-        ref = ref_mod.create_diffusion(respacing, **kw)
-        emu.install(monkeypatch)
-        nat = sd.create_diffusion(respacing, **kw)
-        assert nat.num_timesteps == ref.num_timesteps and nat.timestep_map == ref.timestep_map
-        for tab in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "posterior_variance", "posterior_mean_coef1",
-                    "posterior_mean_coef2", "posterior_log_variance_clipped"):
-            assert np.allclose(getattr(nat, tab), getattr(ref, tab), rtol=1e-12, atol=0), tab
-        g = torch.Generator().manual_seed(0)
-        B, C, F, H, W = 2, 4, 3, 5, 6
-        x = torch.randn(B, C, F, H, W, generator=g).half().float()
-        mask = (torch.rand(B, 1, F, H, W, generator=g) > 0.5).float()
-        x_start = torch.randn(B, C, F, H, W, generator=g).half().float()
-        seen = []
-
-        def model(inp, ts, scale=0.5):
-            seen.append([int(v) for v in ts])
-            base = inp[:, :C] if inp.shape[1] == C else inp[:, :C] + 0.25 * inp[:, C:C + 1] * inp[:, C + 1:]
-            return (scale * torch.tanh(base.float()) + 0.1 * torch.cos(ts.float() / 100.0).view(-1, 1, 1, 1, 1)).to(inp.dtype)
-        close = lambda a, b, tol=4e-3: float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6)) < tol
-        n = ref.num_timesteps
-        for i in (n - 1, n // 2, 1, 0):
-            t = torch.tensor([i] * B)
-            x0_scale = None
-            for clip in (False, True):
-                torch.manual_seed(5)
-                want = ref.p_sample(model, x, t, clip_denoised=clip, model_kwargs=dict(scale=0.7))
-                torch.manual_seed(5)
-                got = nat.p_sample(model, x.half(), t, clip_denoised=clip, model_kwargs=dict(scale=0.7))
-                if x0_scale is None:       # x0 = (x - sb eps) / sa: at the noisy end 1 / sa is in the hundreds, and so is the fp16 rounding of
-                    x0_scale = float(want["pred_xstart"].abs().max())     # x0 BEFORE the clamp -- the clipped values are compared on that scale
-                    close_x0 = lambda a, b: float((a.float() - b.float()).abs().max()) < 4e-3 * max(x0_scale, 1.0)
-                assert close(got["sample"], want["sample"]) and close_x0(got["pred_xstart"], want["pred_xstart"]), ("p_sample", i, clip)
-                assert seen[-1] == seen[-2] == [ref.timestep_map[i]] * B
-                for eta in (0.0, 0.6):
-                    torch.manual_seed(6)
-                    want = ref.ddim_sample(model, x, t, clip_denoised=clip, eta=eta, mask=mask, x_start=x_start, use_concat=True)
-                    torch.manual_seed(6)
-                    got = nat.ddim_sample(model, x.half(), t, clip_denoised=clip, eta=eta, mask=mask, x_start=x_start, use_concat=True)
-                    assert close(got["sample"], want["sample"]) and close_x0(got["pred_xstart"], want["pred_xstart"]), ("ddim_sample", i, clip, eta)
-                want = ref.ddim_reverse_sample(model, x, t, clip_denoised=clip)
-                got = nat.ddim_reverse_sample(model, x.half(), t, clip_denoised=clip)
-                assert close(got["sample"], want["sample"]), ("ddim_reverse_sample", i, clip)
-        torch.manual_seed(7)
-        want = ref.ddim_sample_loop(model, x.shape, x, clip_denoised=False, device="cpu", mask=mask, x_start=x_start, use_concat=True)
-        got = nat.ddim_sample_loop(model, x.shape, x.half(), clip_denoised=False, device="cpu", mask=mask, x_start=x_start, use_concat=True)
-        assert close(got, want, 1e-2)
-        torch.manual_seed(8)
-        want = ref.p_sample_loop(model, x.shape, x, clip_denoised=True, device="cpu")
-        torch.manual_seed(8)
-        got = nat.p_sample_loop(model, x.shape, x.half(), clip_denoised=True, device="cpu")
-        assert close(got, want, 1e-2)
-        tq = torch.tensor([n - 1, 2])
-        torch.manual_seed(9)
-        want = ref.q_sample(x, tq)
-        torch.manual_seed(9)
-        assert close(nat.q_sample(x, tq), want, 1e-5)
-        with pytest.raises(NotImplementedError):
-            nat.p_sample(model, x.half(), torch.tensor([1, 2]))
-        with pytest.raises(NotImplementedError):
-            nat.p_sample(model, x.half(), torch.tensor([1, 1]), cond_fn=lambda *a, **k: 0)
-        with pytest.raises(NotImplementedError):
-            sd.create_diffusion("10", learn_sigma=True)
-        assert sd.space_timesteps(300, [10, 15, 20]) == ref_mod.space_timesteps(300, [10, 15, 20]) and sd.space_timesteps(100, "3,4") == ref_mod.space_timesteps(100, "3,4")
-    finally:
-        for k in [k for k in sys.modules if k.startswith(name)]:
-            del sys.modules[k]
-
-
-@pytest.mark.gpu
-def test_seine_diffusion_package_on_gpu_matches_the_emulated_kernels(monkeypatch):
-    """The deterministic steps of ``anyv2v_amd.seine_diffusion`` (DDIM loop with mask / x_start / use_concat, reverse DDIM step, clipped and
-    unclipped) on the HIP kernel vs the same host code on the CPU emulation of the ops (which the CPU suite checks against SEINE's own
-    ``diffusion/`` package); the stochastic steps are checked for finiteness and for the noise scale."""
-    from anyv2v_amd import seine_diffusion as sd
-    assert torch.cuda.is_available()
-    nat = sd.create_diffusion("10")
-    g = torch.Generator().manual_seed(0)
-    B, C, F, H, W = 2, 4, 3, 5, 6
-    x = torch.randn(B, C, F, H, W, generator=g).half()
-    mask = (torch.rand(B, 1, F, H, W, generator=g) > 0.5).half()
-    x_start = torch.randn(B, C, F, H, W, generator=g).half()
-
-    def model(inp, ts):
-        base = inp[:, :C] if inp.shape[1] == C else inp[:, :C] + 0.25 * inp[:, C:C + 1] * inp[:, C + 1:]
-        return (0.5 * torch.tanh(base.float()) + 0.1 * torch.cos(ts.float() / 100.0).view(-1, 1, 1, 1, 1)).to(inp.dtype)
-
-    def run(dev):
-        d = lambda t: t.to(dev)
-        out = {"loop": nat.ddim_sample_loop(model, x.shape, d(x), clip_denoised=False, device=dev, mask=d(mask), x_start=d(x_start), use_concat=True)}
-        t = torch.tensor([4] * B, device=dev)
-        out["rev"] = nat.ddim_reverse_sample(model, d(x), t, clip_denoised=True)["sample"]
-        out["x0"] = nat.ddim_sample(model, d(x), t, clip_denoised=True)["pred_xstart"]
-        return {k: v.float().cpu() for k, v in out.items()}
-    gpu = run("cuda")
-    torch.manual_seed(3)
-    noisy = nat.p_sample(model, x.cuda(), torch.tensor([5] * B, device="cuda"), clip_denoised=False)["sample"].float().cpu()
-    torch.manual_seed(3)
-    quiet = nat.ddim_sample(model, x.cuda(), torch.tensor([5] * B, device="cuda"), clip_denoised=False, eta=0.0)["sample"].float().cpu()
-    assert torch.isfinite(noisy).all() and 0.01 < float((noisy - quiet).std()) < 5.0
-    emu.install(monkeypatch)
-    cpu = run("cpu")
-    for k in gpu:
-        err = float((gpu[k] - cpu[k]).abs().max() / cpu[k].abs().max())
-        assert err < 4e-3, (k, err)
