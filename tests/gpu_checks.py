@@ -1712,6 +1712,29 @@ def _calibrated(name, got, ref, eager, factor=2.0, floor=5e-4, key=None, gap_cap
                 err=e_h, l2=l2, tol=tol, tol_l2=tol_l2, ok=ok, eager=e_e, gap=e_g)
 
 
+def _emulated(fn):
+    """Runs ``fn`` with ``anyv2v_amd.ops`` replaced by tests/cpu_ops_emulation.py (plain torch on the CPU, fp32 arithmetic with the
+    kernels' fp16 storage points, no HIP graphs) and restores the kernels: an INDEPENDENT fp16-storage implementation of the same model
+    on the same weights -- the "eager fp16" arm of ``_calibrated`` for the sibling pipelines, whose reference classes do not exist on
+    the GPU box (the fixtures hold their fp32 outputs)."""
+    import cpu_ops_emulation as emu
+    names = ["gemm", "groupnorm", "layernorm", "softmax_rows", "attention", "silu", "add", "timestep_embedding", "ncfhw_to_tokens",
+             "tokens_to_ncfhw", "adaptive_avgpool", "copy_cols", "gather_rows", "rotary", "cfg_ddim_step", "ddim_step", "guided_step", "ff_geglu"]
+    saved = {n: getattr(ops, n) for n in names}
+    saved_env = os.environ.get("ANYV2V_NO_GRAPH")
+    os.environ["ANYV2V_NO_GRAPH"] = "1"
+    emu.install()
+    try:
+        return fn()
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)
+        if saved_env is None:
+            os.environ.pop("ANYV2V_NO_GRAPH", None)
+        else:
+            os.environ["ANYV2V_NO_GRAPH"] = saved_env
+
+
 def _cond_kw(inp16, device, dtype):
     return dict(fps=inp16["fps"].to(device), image_latents=inp16["image_latents"].to(device, dtype),
                 image_embeddings=inp16["image_embeddings"].to(device, dtype),
@@ -2294,7 +2317,7 @@ def check_consisti2v_pipeline():
     """ConsistI2V end to end, pipeline level: ``anyv2v_amd.consisti2v_pipeline.ConditionalVideoEditingPipeline`` on the kernels --
     ``encode_vae_video``, ``invert``, ``__call__`` (reconstruction), ``sample_with_pnp`` -- vs the fixture the REFERENCE's own pipeline
     class produced on the CPU in fp32 (``make_golden.py --consisti2v-pipeline``, ``oracle/ref_consisti2v_pipeline.py``); every stage
-    starts from the reference's own trajectory.  The edit's bound carries the factor 35 of the text guidance (tests/test_consisti2v.py)."""
+    starts from the reference's own trajectory.  The edit row (text guidance 35) is gated against an independent fp16-storage run, not a constant."""
     import consisti2v_spec as spec
     fx = torch.load(os.path.join(ROOT, "tests", "golden", "consisti2v_pipeline.pt"))
     files = {t: fx["trajectory"][i] for i, t in enumerate(fx["inv_ts"])}
@@ -2304,7 +2327,15 @@ def check_consisti2v_pipeline():
     for i, t in enumerate(fx["inv_ts"]):
         out.append(_res(f"consisti2v pipeline: invert, latents written at t={t}", nat["files"][t].float().cpu(), fx["trajectory"][i].float(), 2e-2))
     out.append(_res("consisti2v pipeline: __call__ reconstruction from t_idx 1", nat["rec_lat"].float().cpu(), fx["rec_lat"].float(), 2e-2))
-    out.append(_res("consisti2v pipeline: sample_with_pnp (text guidance 35)", nat["edit_lat"].float().cpu(), fx["edit_lat"].float(), 0.25))
+    # no fixed bound on the amplified row.  Text guidance 35 multiplies the difference of two branch predictions --
+    # and their fp16 rounding -- by 35; the bound is 2 x what an independent fp16-storage implementation (the torch op emulation, run
+    # here on the CPU on the same weights from the same trajectory) shows against the reference's fp32 output, and 3 x the recorded
+    # HIP figure; HIP-vs-emulation is printed.
+    emu = _emulated(lambda: spec.native_pipeline_job("cpu", trajectory_from=files))
+    out.append(_calibrated("consisti2v pipeline: sample_with_pnp (text guidance 35) vs the reference class's output; 'eager' = torch op emulation",
+                           nat["edit_lat"], fx["edit_lat"], emu["edit_lat"], key="consisti2v_pipeline_pnp_edit"))
+    out.append(_calibrated("consisti2v pipeline: __call__ reconstruction (calibrated)", nat["rec_lat"], fx["rec_lat"], emu["rec_lat"],
+                           key="consisti2v_pipeline_reconstruction"))
     dec = torch.from_numpy(nat["pipe"].decode_latents(fx["edit_lat"].to(DEV)))
     out.append(_res("consisti2v pipeline: decode_latents of the reference's edited latents", dec, fx["edit_video"].float(), 4e-3))
     return out
@@ -2383,7 +2414,10 @@ def check_seine_pipeline():
                 out.append(_res(f"seine runners: ddim_inversion, file at t={t}", nat["files"][t].float().cpu(), fx["trajectory"][i].float(), 1e-2))
             out.append(_res("seine runners: ddim_sample reconstruction", nat["recon_lat"].float().cpu(), fx["recon_lat"].float(), 2e-2))
         out.append(dict(name=f"seine runners: edit timesteps ({sm})", err=0.0, tol=0.0, ok=nat["edit_ts"] == fx[f"edit_ts_{sm}"]))
-        out.append(_res(f"seine runners: edit_video, {sm} sampler, cfg 4", nat["edit_lat"].float().cpu(), fx[f"edit_lat_{sm}"].float(), 6e-2))
+        with tempfile.TemporaryDirectory() as tmp2:   # (calibrated like the ConsistI2V edit row)
+            emu = _emulated(lambda: spec.native_job("cpu", tmp2, sm, trajectory_from=files))
+        out.append(_calibrated(f"seine runners: edit_video, {sm} sampler, cfg 4 vs the reference runner's output; 'eager' = torch op emulation",
+                               nat["edit_lat"], fx[f"edit_lat_{sm}"], emu["edit_lat"], key=f"seine_pipeline_edit_{sm}"))
         dec = nat["pipe"].decode_latents(fx[f"edit_lat_{sm}"].to(DEV))
         d = int((dec.int() - fx[f"edited_frames_{sm}"].int()).abs().max())
         out.append(dict(name=f"seine runners: decode_latents of the reference's latents ({sm}), max |uint8 diff|", err=float(d), tol=1.0, ok=d <= 1))
