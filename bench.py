@@ -493,6 +493,7 @@ def config5_steps(pipe, device, seed, frames=128):
                  image_latents=il_all[:1].contiguous(), image_embeddings=ie[:1].contiguous())
     cond3 = dict(encoder_hidden_states=ehs, fps=torch.tensor([8, 8, 8], device=device), image_latents=il_all, image_embeddings=ie)
     out = {}
+    torch.cuda.reset_peak_memory_stats()   # (the figure below is this function's peak: weights + the 128-frame activations and graphs)
     for name, mk, tt, cf, key, reg, smp in (
             ("inversion_step_B1_ms", lambda: _StepEngine(pipe, s_inv, cond1, b_unc=-1, b_cond=0, guidance=1.0, dup_slots=[]),
              torch.tensor(ts_inv, dtype=torch.float32, device=device)[:, None].contiguous(), inv.coefficient_table(ts_inv, device),
