@@ -4,9 +4,9 @@
 // (i2vgen-xl/pnp_utils.py:175,182-183,216), and the diffusers-0.26.3 Transformer2DModel / TransformerTemporalModel
 // proj_in / proj_out and FeedForward GEGLU up-projection behind pipeline_i2vgen_xl.py:1146 -- the layers where a row of
 // the token matrix is 640 bytes and the tile kernels of gemm.hip spend more time switching tiles than multiplying
-// (profiles/r02_shape_report_B3.txt: 447-642 TF/s).
+// (profiles/r02_shape_report_B3.txt: 447-642 TF/s, HISTORY.md section 9).
 //
-// Structure ("weight-stationary kernel"):
+// Structure:
 //   * a block owns ONE 160-column slab of W for its whole life: W[160][320] = 100 KB sits in LDS (five [160][64]
 //     K-tiles, 16-byte chunks XOR-swizzled by row & 7, filled once by LDS-DMA);
 //   * every wave is autonomous: it walks 32-row strips of its block's row range and keeps the next five K-steps of
