@@ -36,7 +36,7 @@ from PIL import Image
 from . import consisti2v as c2
 from . import ops
 from .schedulers import CONSISTI2V_SCHEDULER_CONFIG, DDIMInverseScheduler, DDIMScheduler
-from .utils import LatentTrajectory, load_ddim_latents_at_t
+from .utils import LatentTrajectory, capture_hip_graph, load_ddim_latents_at_t
 
 logger = logging.getLogger(__name__)
 
@@ -212,7 +212,7 @@ class _StepGraphs:
             self._forward()                               # warm-up outside the capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_hip_graph(g):
                 self.outs[key] = self._forward()
             self.graphs[key] = g
         self.graphs[key].replay()

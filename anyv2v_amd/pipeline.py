@@ -23,7 +23,7 @@ import torch
 from . import ops, pnp_utils
 from .schedulers import DDIMScheduler
 from .unet import I2VGenXLUNet, I2VGenXLUNetConfig
-from .utils import LatentTrajectory, load_ddim_latents_at_t
+from .utils import LatentTrajectory, capture_hip_graph, load_ddim_latents_at_t
 
 logger = logging.getLogger(__name__)
 
@@ -201,7 +201,7 @@ class _StepEngine:
                 self.unet._forward_core(self.ctx, self.sample, drop_source_tail=self.drop_src_tail)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_hip_graph(g):
                 self._body()
             self.graphs[key] = g
             # capture does not execute: fall through to the replay below

@@ -2,6 +2,7 @@
 (``i2vgen-xl/utils.py:17-79``; writer ``pipeline_i2vgen_xl.py:1424-1428``)."""
 from __future__ import annotations
 
+import contextlib
 import glob
 import logging
 import os
@@ -238,3 +239,22 @@ def export_to_gif(frames: List[Image.Image], path: Optional[str] = None, fps: in
         path = tempfile.NamedTemporaryFile(suffix=".gif", delete=False).name
     frames[0].save(path, save_all=True, append_images=frames[1:], optimize=False, duration=1000 // fps, loop=0)
     return path
+
+
+@contextlib.contextmanager
+def capture_hip_graph(graph):
+    """``with torch.cuda.graph(graph)`` made safe against the cyclic garbage collector: an unreachable ``CUDAGraph`` (a step engine dropped
+    by the LRU, a previous pipeline object) that Python's GC happens to free DURING a capture calls ``hipGraphExecDestroy`` on the capturing
+    thread -- "operation not permitted when stream is capturing", and the process aborts in the destructor.  torch >= 2.9 no longer
+    collects before a capture by default, so: collect first, keep the collector off while the stream captures."""
+    import gc
+    import torch
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()

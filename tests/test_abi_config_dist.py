@@ -357,3 +357,43 @@ def test_attention_v_tile_swizzle_is_bank_conflict_free():
     g16 += [[x + 32 for x in g] for g in g16]
     k_addr = lambda lane, ks, kb: (32 * kb + (lane & 31)) * 128 + (((2 * ks + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4)
     assert sum(extra_cycles(lambda l: k_addr(l, ks, kb), g16, 4) for kb in (0, 1) for ks in range(4)) == 0
+
+
+_RCCL_WORLD1 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from anyv2v_amd.parallel import FrameParallel, gather_latents
+import bench
+lats = [torch.full((1, 4, 2, 3, 3), float(i), dtype=torch.float16, device=dev) for i in (2, 0, 1)]
+got = gather_latents(lats, 3, (1, 4, 2, 3, 3), torch.float16, dev, indices=[2, 0, 1])      # held out of order: scattered by index
+assert got.is_cuda and [float(g[0, 0, 0, 0]) for g in got] == [0.0, 1.0, 2.0], got[:, 0, 0, 0, 0]
+dt, out = bench.finish_distributed(dist, 1.5, lats[0].contiguous(), 1, dev)
+assert dt == 1.5 and len(out) == 1 and torch.equal(out[0], lats[0])
+fp = FrameParallel()
+x = torch.randn(2 * 4 * 6, 8, device=dev).half()                                            # B = 2, 4 local frames, HW = 6
+y = fp.pixels_to_frames(fp.frames_to_pixels(x, 2, 4, 6), 2, 4, 6)
+assert torch.equal(x, y)
+s = torch.ones(5, device=dev)
+fp.all_reduce_sum(s)
+assert float(s.sum()) == 5.0
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+'''
+
+
+@pytest.mark.gpu
+def test_collectives_through_rccl_world_size_1():
+    """The N > 1 code paths on the backend they run on at round end ("nccl" = RCCL): a one-rank process group on the GPU box drives
+    ``gather_latents`` (device tensors, index scatter), ``bench.finish_distributed`` and the frame-parallel all-to-all / all-reduce
+    wrappers through RCCL itself.  (No multi-GPU lease exists here; rank counts > 1 are covered on gloo.)"""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1, ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

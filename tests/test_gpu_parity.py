@@ -66,6 +66,7 @@ def test_norms():
     _assert_all(gc.check_norms())
 
 
+
 def test_attention():
     _assert_all(gc.check_attention())
 
@@ -293,3 +294,49 @@ def test_pipeline_vs_the_reference_pipelines_own_output():
         print(f"{'ok  ' if r['ok'] else 'FAIL'} {r['name']}: {r['err']:.3e} (tol {r['tol']:.2e})")
     gc.release_models()
     _assert_all(res)
+
+
+def test_graph_capture_is_safe_against_the_cyclic_garbage_collector():
+    """A ``CUDAGraph`` freed by Python's cyclic GC while ANOTHER graph is being captured aborts the process on ROCm ("operation not
+    permitted when stream is capturing", raised in the destructor; seen in the round-5 suite when a collection happened to run inside
+    a step engine's capture, and torch >= 2.9 no longer collects before a capture).  ``utils.capture_hip_graph`` collects first and
+    keeps the collector off during the capture: here an old graph becomes cyclic garbage INSIDE the capture region with the GC
+    thresholds at 1, i.e. a collection would run at the next allocation."""
+    import gc
+
+    import torch
+
+    from anyv2v_amd.utils import capture_hip_graph
+    x = torch.ones(1024, device="cuda")
+    y = torch.zeros(1024, device="cuda")
+
+    def captured():
+        g = torch.cuda.CUDAGraph()
+        with capture_hip_graph(g):
+            y.add_(x)
+        return g
+
+    old_graph = captured()
+
+    class Holder:
+        pass
+
+    thresholds = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        g = torch.cuda.CUDAGraph()
+        with capture_hip_graph(g):
+            h = Holder()
+            h.graph, h.me = old_graph, h        # a reference cycle that owns the old graph ...
+            del h, old_graph                    # ... and is now unreachable
+            junk = [[i] for i in range(2000)]   # allocations: with the collector on, it would run here, inside the capture
+            y.add_(x)
+            del junk
+        assert gc.isenabled()
+    finally:
+        gc.set_threshold(*thresholds)
+    gc.collect()                                # the old graph dies here, outside any capture
+    y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 1024.0
