@@ -35,6 +35,7 @@ struct AttnK {
     int q_tiles;
     int head_dim;
     int causal;  // generic kernel only: key j is visible to query s iff j <= s (CLIP text tower)
+    int narrow_store;  // flash kernels: 8-byte epilogue stores (descriptor flag bit7; A/B of the widened epilogue)
 };
 
 __device__ __forceinline__ long long attn_row(long long i, int inner, long long so, long long si) {
@@ -357,7 +358,34 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flas
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (wave_active && qrow < p.Sq) {
+    if (wave_active && (p.ldo & 7) == 0 && !p.narrow_store) {
+        // Row-per-lane epilogue, widened (MI355X guide T21): a lane holds channels 8 k + 4 hi .. + 3 of its query row for the eight
+        // column groups k = 4 db + g, i.e. eight 8-byte pieces per row and half-wave.  One v_permlane32_swap per dword of a group
+        // pair (k, k + 1) hands the lower half-wave channels 8 k .. 8 k + 7 and the upper one 8 k + 8 .. 8 k + 15: four 16-byte
+        // stores per lane instead of eight 8-byte ones -- same bytes, same addresses, half the store instructions (the tail of a
+        // block is store-ISSUE bound).  All 64 lanes take part in the swaps; rows past Sq are not stored.
+        const float inv = 1.0f / l_tot;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+            half_t* op = p.O + (obase[b] + (long long)qrow * p.q_seq) * p.ldo + h * 64 + 8 * hi;
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {   // group pair (2 kp, 2 kp + 1): db = kp >> 1, g = 2 (kp & 1), + 1
+                unsigned w0[2], w1[2];
+#pragma unroll
+                for (int d2 = 0; d2 < 2; ++d2) {
+                    h2 a, c;
+                    a[0] = (half_t)(oacc[b][kp >> 1][8 * (kp & 1) + 2 * d2] * inv);
+                    a[1] = (half_t)(oacc[b][kp >> 1][8 * (kp & 1) + 2 * d2 + 1] * inv);
+                    c[0] = (half_t)(oacc[b][kp >> 1][8 * (kp & 1) + 4 + 2 * d2] * inv);
+                    c[1] = (half_t)(oacc[b][kp >> 1][8 * (kp & 1) + 4 + 2 * d2 + 1] * inv);
+                    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c), false, false);
+                    w0[d2] = r[0];
+                    w1[d2] = r[1];
+                }
+                if (qrow < p.Sq) *(u4*)(op + 16 * kp) = (u4){w0[0], w0[1], w1[0], w1[1]};
+            }
+        }
+    } else if (wave_active && qrow < p.Sq) {
         const float inv = 1.0f / l_tot;
 #pragma unroll
         for (int b = 0; b < NV; ++b) {
@@ -665,6 +693,7 @@ static int fill(const AnyV2VAttnDesc* d, AttnK& k, int head_dim) {
     k.q_tiles = (d->Sq + 127) / 128;
     k.head_dim = head_dim;
     k.causal = 0;
+    k.narrow_store = (d->flags & 128) ? 1 : 0;
     return ANYV2V_OK;
 }
 

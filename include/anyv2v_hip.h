@@ -170,7 +170,8 @@ typedef struct AnyV2VAttnDesc {
     float scale;
     int32_t flags;      /* bit0: force the naive reference kernel; bit1: no short-sequence kernel; bit2: never use the
                            8-wave (256-query) blocks; bit3: PnP launches (batch == 3 qk_mod) as per-branch aliasing on the
-                           plain kernel instead of the shared-softmax kernel.  All other bits are ignored. */
+                           plain kernel instead of the shared-softmax kernel; bit7 (128): 8-byte instead of 16-byte epilogue stores in
+                           the flash kernels (A/B of the widened epilogue; same bytes, same results).  All other bits are ignored. */
 } AnyV2VAttnDesc;
 
 int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream);
