@@ -111,7 +111,7 @@ __device__ __forceinline__ h8 join8(fp16x4v_t a, fp16x4v_t b) {
 // as this form, but costs a second fp16 rounding of Q (error 3e-4 -> 7e-4, growing with |s c|); one whole-tile softmax without
 // the 16-key steps needs 185 VGPRs (2 waves per SIMD) or spills.
 template <int STAGES, int NV, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NV == 1 ? 3 : 2)) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? (NV == 1 ? 4 : 2) : (NV == 1 ? 3 : 2)) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
     constexpr int TILE_BYTES = 8192, STAGE_BYTES = (1 + NV) * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
     constexpr int NT = 64 * NW, DI = 512 / NT;  // threads; LDS-DMA instructions per thread and 8-KiB tile matrix (512 chunks of 16 B)
     constexpr int LPT = DI * (1 + NV);          // LDS-DMA per thread per tile
@@ -727,6 +727,16 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     if (k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8)) {
         // PnP injection step: one softmax per source element, three V / O streams (flag bit3 forces the aliasing form)
         const long long nwg3 = (long long)k.qk_mod * k.heads * k.q_tiles;
+        // long KV loops with enough 256-query blocks to fill the chip (the 64x64 level: 16 x 5 x 16 = 1280): 8-wave blocks around a
+        // 3-stage ring -- two K / V tile sets in flight instead of one, half the LDS-DMA per query, one 96-KiB block per CU (the same
+        // two waves per SIMD as two 4-wave blocks).  0.6845 -> 0.6479 ms at (48, 5, 4096); 7 % slower at (48, 10, 1024), which stays
+        // on the 4-wave form (profiles/r05_attn_pnp_8wave_ab.txt); bit-equal.  Flag bit2: never (as for the plain kernel).
+        const long long n8 = (long long)k.qk_mod * k.heads * ((d->Sq + 255) / 256);
+        if (!(d->flags & 4) && d->Sk >= 2048 && d->Sq >= 2048 && n8 >= 1024) {
+            k.q_tiles = (d->Sq + 255) / 256;
+            hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 3, 8>), dim3((unsigned)n8), dim3(512), 0, s, k, zeros);
+            return av_launch_status("flash_attn_d64_v2<pnp3, 8 waves>");
+        }
         hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 3, 4>), dim3((unsigned)nwg3), dim3(256), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<pnp3>");
     }

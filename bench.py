@@ -102,7 +102,7 @@ def roofline_spatial_attention(device, pnp=False):
     FLOP == executed FLOP.  `traffic` is the HBM byte count per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) read from
     the newest profiles/r*_traffic.json (see measured_traffic), or null.
     pnp=True: the launch the edit loop actually issues on injection steps (Q/K of all three branches alias the source
-    branch) -- flash_attn_d64_v2_kernel<2,3> shares one S/softmax over three V streams, so it executes 2/3 of the
+    branch) -- flash_attn_d64_v2_kernel<3,3,8> shares one S/softmax over three V streams, so it executes 2/3 of the
     reference op's MFMA FLOP; `achieved` prices the reference op's algorithmic FLOP (as the contract defines it) and
     `executed_tflops` the MFMA work the kernel really issues."""
     from anyv2v_amd import ops
@@ -115,8 +115,8 @@ def roofline_spatial_attention(device, pnp=False):
     ms = measure_kernel(fn)
     flops = 4.0 * N * h * S * S * d
     ach = flops / (ms * 1e-3) / 1e12
-    traffic, src = measured_traffic("flash_attn_d64_v2_kernel<2, 3, 4>" if pnp else "flash_attn_d64_v2_kernel<3, 1, 8>")
-    r = {"bound": "mfma", "kernel": ("flash_attn_d64_v2_kernel<2,3,4> (spatial self-attn under PnP q/k injection, shared softmax, "
+    traffic, src = measured_traffic("flash_attn_d64_v2_kernel<3, 3, 8>" if pnp else "flash_attn_d64_v2_kernel<3, 1, 8>")
+    r = {"bound": "mfma", "kernel": ("flash_attn_d64_v2_kernel<3,3,8> (spatial self-attn under PnP q/k injection, shared softmax, 8-wave blocks, "
                                      if pnp else "flash_attn_d64_v2_kernel<3,1,8> (spatial self-attn, ") + "N=48 h=5 S=4096 d=64)",
          "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
          "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src}

@@ -715,6 +715,29 @@ def check_attention(naive_too=True):
                 finally:
                     ops.ATTN_FLAGS = saved
                 out.append(_res(f"attn PnP shared-softmax == aliasing form b{b} h{h} S{S}", o, o2.float(), 1e-6))
+        if not naive:
+            # the 64x64-level launch itself (48 x 5 x 4096: the 8-wave / 3-stage form of the shared-softmax kernel): against the
+            # aliasing form (plain kernel per branch) everywhere, against fp32 SDPA on one (source element, head)
+            b, h, S = 48, 5, 4096
+            C = 64 * h
+            qkv = rnd(b * S, 3 * C, scale=1.0, seed=77)
+            o = torch.zeros(b * S, C, dtype=torch.float16, device=DEV)
+            kw = dict(batch=b, heads=h, Sq=S, Sk=S, inner=1, q_strides=(S, 0, 1), kv_strides=(S, 0, 1), qk_mod=b // 3)
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, **kw)
+            o2 = torch.zeros_like(o)
+            saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | 8
+            try:
+                ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o2, **kw)
+            finally:
+                ops.ATTN_FLAGS = saved
+            out.append(_res(f"attn PnP shared-softmax == aliasing form b{b} h{h} S{S} (8-wave blocks)", o, o2.float(), 1e-6))
+            i0, hh = 5, 3
+            x = qkv.view(b, S, 3, h, 64)
+            q1, k1 = x[i0, :, 0, hh][None, None], x[i0, :, 1, hh][None, None]
+            for br in range(3):
+                v1 = x[i0 + br * (b // 3), :, 2, hh][None, None]
+                got = o.view(b, S, h, 64)[i0 + br * (b // 3), :, hh]
+                out.append(_res(f"attn PnP shared-softmax b{b} h{h} S{S}, element {i0} head {hh} branch {br} vs fp32 SDPA", got, _sdpa(q1, k1, v1)[0, 0], KTOL))
         # cross-attention: Sk=145, K/V shared by the F frames of a clip
         B_, Fr, S, h, Sk = 2, 3, 100, 2, 145
         C = 64 * h
