@@ -556,6 +556,8 @@ def main():
                          "by default the pipelined rate is measured after the timed region and reported as config.pipelined_ms_per_step")
     ap.add_argument("--serial", action="store_true", help="(default since round 5; kept for old command lines)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 2 and 5)")
+    ap.add_argument("--no-job-schedule", action="store_true",
+                    help="skip the measurement of the other schedule behind the timed region (profiling runs: the trace then holds the timed pairs only)")
     args = ap.parse_args()
     args.overlap = args.pipelined and not args.serial
 
@@ -695,7 +697,7 @@ def main():
     rccl_ranks = len(_gathered) if dist is not None else None
     serial_ms = pipelined_ms = None
     bit_equal = None
-    if world == 1:
+    if world == 1 and not args.no_job_schedule:
         n = min(args.steps, 20)
         if args.overlap:
             # the same pairs one after the other on one stream (the single-clip order), for comparison
