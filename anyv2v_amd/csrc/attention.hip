@@ -748,7 +748,10 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
         hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<8 waves>");
     }
-    hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 4>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
+    // 4-wave blocks on a 2-stage ring: 32 KiB of LDS per block = four blocks per CU (three with 3 stages); the short-KV launches
+    // (cross-attention, Sk = 145: three tiles per block, 7680 blocks) are bound by how many blocks are in flight -- 95.8 -> 82.6 us at
+    // (48, 5, 4096, 145), never slower up to Sk = 1024 (profiles/r05_attn_cross_2stage_ab.txt); bit-equal
+    hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 1, 4>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);
     return av_launch_status("flash_attn_d64_v2");
 }
 
