@@ -743,7 +743,8 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     // 8-wave blocks (256 query rows per K / V ring) for launches that still fill the chip with them and whose KV loop is long
     // enough to amortise the bigger block (measured: 1.19 -> 1.09 ms at 48 x 5 x 4096^2, equal at 1024^2, slower at Sk = 145)
     const long long nwg8 = (long long)k.batch * k.heads * ((d->Sq + 255) / 256);
-    if (!(d->flags & 4) && d->Sk >= 1024 && d->Sq >= 1024 && nwg8 >= 1024) {
+    // (round 5: from Sk = 2048 on -- at 48 x 10 x 1024^2 the 4-wave kernel on its 2-stage ring is 4 % faster, 146.4 vs 152.0 us)
+    if (!(d->flags & 4) && d->Sk >= 2048 && d->Sq >= 1024 && nwg8 >= 1024) {
         k.q_tiles = (d->Sq + 255) / 256;
         hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<8 waves>");
