@@ -32,6 +32,13 @@ def test_library_exports_every_symbol_the_header_declares():
     assert _lib.load().anyv2v_version() >= 103
 
 
+def test_graft_entry_build_runs_here():
+    """``__graft_entry__.build()`` is the driver's "does it build" check: make (a no-op when the objects are current) + the imports
+    it lists.  (Round 5: it still imported a module that had been removed; nothing in the CPU suite called it while the .so existed.)"""
+    import __graft_entry__ as g
+    g.build()
+
+
 def test_abi_argument_validation_without_gpu():
     """Host-side validation returns ANYV2V_EINVAL with a message before anything touches a device."""
     from anyv2v_amd import _lib
