@@ -731,6 +731,25 @@ def check_attention(naive_too=True):
             finally:
                 ops.ATTN_FLAGS = saved
             out.append(_res(f"attn PnP shared-softmax == aliasing form b{b} h{h} S{S} (8-wave blocks)", o, o2.float(), 1e-6))
+            # ... and with a ragged last block / last tile on both 8-wave kernels (2100 = 8 x 256 + 52 queries, 32 x 64 + 52 keys)
+            br, hr, Sr = 96, 4, 2100
+            Cr = 64 * hr
+            qkvr = rnd(br * Sr, 3 * Cr, scale=1.0, seed=78)
+            kwr = dict(batch=br, heads=hr, Sq=Sr, Sk=Sr, inner=1, q_strides=(Sr, 0, 1), kv_strides=(Sr, 0, 1), qk_mod=br // 3)
+            o_r = torch.zeros(br * Sr, Cr, dtype=torch.float16, device=DEV)
+            ops.attention(qkvr[:, :Cr], qkvr[:, Cr:2 * Cr], qkvr[:, 2 * Cr:], o_r, **kwr)
+            o_r2 = torch.zeros_like(o_r)
+            saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | 8
+            try:
+                ops.attention(qkvr[:, :Cr], qkvr[:, Cr:2 * Cr], qkvr[:, 2 * Cr:], o_r2, **kwr)
+            finally:
+                ops.ATTN_FLAGS = saved
+            out.append(_res(f"attn PnP shared-softmax == aliasing form b{br} h{hr} S{Sr} (8-wave blocks, ragged)", o_r, o_r2.float(), 1e-6))
+            xr = qkvr.view(br, Sr, 3, hr, 64)
+            out.append(_res(f"attn PnP shared-softmax b{br} h{hr} S{Sr}, element 7 head 1 branch 2 vs fp32 SDPA",
+                            o_r.view(br, Sr, hr, 64)[7 + 2 * (br // 3), :, 1],
+                            _sdpa(xr[7, :, 0, 1][None, None], xr[7, :, 1, 1][None, None], xr[7 + 2 * (br // 3), :, 2, 1][None, None])[0, 0], KTOL))
+            del qkvr, o_r, o_r2
             i0, hh = 5, 3
             x = qkv.view(b, S, 3, h, 64)
             q1, k1 = x[i0, :, 0, hh][None, None], x[i0, :, 1, hh][None, None]
