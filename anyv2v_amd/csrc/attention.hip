@@ -415,19 +415,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (NV == 1 ? 4 : 2) : (NV == 1 ? 3
 //                 V[4g + 0..3][d0 + i].
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
 
+// NB = 3: the PnP injection step (pnp_utils.py:295-302: the uncond / cond branches use the SOURCE branch's Q and K) as ONE wave per
+// (source element, head): Q, K are read and the softmax is taken once, then the three branches' V are applied one after the other --
+// the same products in the same order per branch as the aliasing form (bit-equal), 8 instead of 12 tensor passes over HBM.
+template <int NB>
 __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
     __shared__ __attribute__((aligned(16))) half_t vs[4][16 * 64];
     __shared__ __attribute__((aligned(16))) half_t os[4][16 * 72];  // output tile, rows padded to 144 bytes
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long unit = (long long)blockIdx.x * 4 + w;  // (batch element, head)
-    if (unit >= (long long)p.batch * p.heads) return;      // wave-uniform; no block-level sync in this kernel
+    const long long unit = (long long)blockIdx.x * 4 + w;  // (batch element, head); NB = 3: (source element, head)
+    if (unit >= (long long)(NB == 1 ? p.batch : p.qk_mod) * p.heads) return;      // wave-uniform; no block-level sync in this kernel
     const int h = (int)(unit % p.heads);
     const long long i = unit / p.heads;
-    const long long iq = p.qk_mod > 0 ? i % p.qk_mod : i;
+    const long long iq = (NB == 1 && p.qk_mod > 0) ? i % p.qk_mod : i;
     const long long qbase = attn_row(iq, p.inner, p.q_outer, p.q_inner);
-    const long long obase = attn_row(i, p.inner, p.q_outer, p.q_inner);
     const long long kbase = attn_row(iq / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
-    const long long vbase = attn_row(i / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
     const int l15 = lane & 15, g = lane >> 4;
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -444,16 +446,16 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
             kf[ks] = kok ? *(const h8*)(kp + 32 * ks) : zero8;
         }
     }
-    // V -> LDS row-major [16 keys][64 d]: 8 lanes fetch one full 128-byte key row per instruction
-    {
-        h8 vv[2];
+    // V rows of every branch: requested up front (8 lanes fetch one full 128-byte key row per instruction)
+    h8 vv[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const long long vbase = attn_row((i + b * (NB == 1 ? 0 : p.qk_mod)) / p.kv_div, p.inner, p.kv_outer, p.kv_inner);
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int key = 8 * ps + (lane >> 3);
-            vv[ps] = key < p.Sk ? *(const h8*)(p.V + (vbase + (long long)key * p.kv_seq) * p.ldv + h * 64 + (lane & 7) * 8) : zero8;
+            vv[b][ps] = key < p.Sk ? *(const h8*)(p.V + (vbase + (long long)key * p.kv_seq) * p.ldv + h * 64 + (lane & 7) * 8) : zero8;
         }
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) *(h8*)(&vs[w][(8 * ps + (lane >> 3)) * 64 + (lane & 7) * 8]) = vv[ps];
     }
     // S^T = K Q^T: D[key = 4 g + r][q = l15]
     f4 s = {0.f, 0.f, 0.f, 0.f};
@@ -479,32 +481,41 @@ __global__ __launch_bounds__(256) void short_attn_d64_kernel(const AttnK p) {
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; same-wave LDS write -> read is ordered (in-order DS queue)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // The MFMA leaves lane (q = l15, g) with 4 of every 16 output channels: stored directly that is 32-byte pieces of 16
-    // different rows per instruction.  Turn the tile through LDS (row stride 144 bytes) so that 8 lanes write one
-    // full 128-byte row segment: two 1-KiB store instructions instead of four scattered 512-byte ones.
     half_t* const ow = os[w];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
-        const half_t* src = &vs[w][(4 * g + (l15 >> 2)) * 64 + 16 * db + 4 * (l15 & 3)];
-        const fp16x4_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)src);
-        h4 vf;
+    for (int b = 0; b < NB; ++b) {
+        const long long obase = attn_row(i + b * (NB == 1 ? 0 : p.qk_mod), p.inner, p.q_outer, p.q_inner);
+        // V -> LDS row-major [16 keys][64 d]; same-wave LDS traffic is ordered (in-order DS queue), the fences keep hipcc from
+        // moving the accesses of one branch across those of the next
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vf[j] = (half_t)vt[j];
-        f4 o = {0.f, 0.f, 0.f, 0.f};
-        o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o, 0, 0, 0);
-        h4 ov;
+        for (int ps = 0; ps < 2; ++ps) *(h8*)(&vs[w][(8 * ps + (lane >> 3)) * 64 + (lane & 7) * 8]) = vv[b][ps];
+        // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // The MFMA leaves lane (q = l15, g) with 4 of every 16 output channels: stored directly that is 32-byte pieces of 16
+        // different rows per instruction.  Turn the tile through LDS (row stride 144 bytes) so that 8 lanes write one
+        // full 128-byte row segment: two 1-KiB store instructions instead of four scattered 512-byte ones.
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[r] * inv);
-        *(h4*)(ow + l15 * 72 + 16 * db + 4 * g) = ov;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int db = 0; db < 4; ++db) {
+            const half_t* src = &vs[w][(4 * g + (l15 >> 2)) * 64 + 16 * db + 4 * (l15 & 3)];
+            const fp16x4_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)src);
+            h4 vf;
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int q = 8 * ps + (lane >> 3), ch = lane & 7;
-        const h8 ov = *(const h8*)(ow + q * 72 + ch * 8);
-        if (q < p.Sq) *(h8*)(p.O + (obase + (long long)q * p.q_seq) * p.ldo + h * 64 + ch * 8) = ov;
+            for (int j = 0; j < 4; ++j) vf[j] = (half_t)vt[j];
+            f4 o = {0.f, 0.f, 0.f, 0.f};
+            o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o, 0, 0, 0);
+            h4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[r] * inv);
+            *(h4*)(ow + l15 * 72 + 16 * db + 4 * g) = ov;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int q = 8 * ps + (lane >> 3), ch = lane & 7;
+            const h8 ov = *(const h8*)(ow + q * 72 + ch * 8);
+            if (q < p.Sq) *(h8*)(p.O + (obase + (long long)q * p.q_seq) * p.ldo + h * 64 + ch * 8) = ov;
+        }
+        if (NB > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next branch overwrites vs / os
     }
 }
 
@@ -712,8 +723,14 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
                       av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) && av_aligned16(d->O);
     if (!fast) return launch_naive(k, s);
     if (k.Sq <= 16 && k.Sk <= 16 && d->ldo % 8 == 0 && !(d->flags & 2)) {  // temporal attention at <= 16 frames: one wave per sequence
+        if (k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8)) {
+            // PnP injection step: one wave per (source element, head), one softmax, three V / O streams (flag bit3: aliasing form)
+            const long long units3 = (long long)k.qk_mod * k.heads;
+            hipLaunchKernelGGL(short_attn_d64_kernel<3>, dim3((unsigned)((units3 + 3) / 4)), dim3(256), 0, s, k);
+            return av_launch_status("short_attn_d64<pnp3>");
+        }
         const long long units = (long long)k.batch * k.heads;
-        hipLaunchKernelGGL(short_attn_d64_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(short_attn_d64_kernel<1>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, k);
         return av_launch_status("short_attn_d64");
     }
     const long long nwg = (long long)k.batch * k.heads * k.q_tiles;

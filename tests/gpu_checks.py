@@ -788,6 +788,15 @@ def check_attention(naive_too=True):
                     q[c3:2 * c3], k[c3:2 * c3], q[2 * c3:], k[2 * c3:] = q[:c3], k[:c3], q[:c3], k[:c3]
                 ref = _sdpa(q, k, v).reshape(B_, HW, h, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B_ * Fr * HW, C)
                 out.append(_res(f"attn[{tag}] temporal F{Fr} inject={inj}", o, ref, KTOL))
+                if inj and not naive:   # the shared-softmax forms (one wave / block per source sequence) == per-branch aliasing, bit for bit
+                    o2 = torch.zeros_like(o)
+                    saved, ops.ATTN_FLAGS = ops.ATTN_FLAGS, ops.ATTN_FLAGS | 8
+                    try:
+                        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o2, batch=B_ * HW, heads=h, Sq=Fr, Sk=Fr,
+                                      inner=HW, q_strides=st, kv_strides=st, qk_mod=HW)
+                    finally:
+                        ops.ATTN_FLAGS = saved
+                    out.append(_res(f"attn temporal F{Fr} PnP shared-softmax == aliasing form", o, o2.float(), 1e-6 if Fr > 16 else 0.0))
     # deferred rescale (the running maximum only advances when a probability would exceed 2^8): wide score ranges, and
     # keys whose scores grow along the sequence so that the maximum keeps jumping by more than the threshold
     for name, qs, ramp in (("wide scores (|s c| up to ~60)", 3.0, False), ("ramped keys (max jumps every tile)", 1.0, True)):
