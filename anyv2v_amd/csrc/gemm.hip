@@ -1173,6 +1173,8 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         return av_launch_status("gemm_naive");
     }
     const bool glds = (d->flags & 2) != 0;
+    // One-wave-per-SIMD persistent kernel (gemm_sw.hip): flags bit21 takes it wherever the shape allows, bit22 forbids it.
+    if (glds && (d->flags & (1 << 21)) && !(d->flags & (1 << 22)) && av_gemm_sw_eligible(d)) return av_gemm_sw_launch(k, d, s);
     // 128-row kernel tile width: 160 columns (NF = 5) where N allows it, except where 128-column tiles (NF = 4) quantise better onto
     // the 256 CUs x 2 resident blocks -- more CUs busy when there is less than one tile per CU, or the same number of rounds with
     // 20 % smaller tiles (flags bit11 / bit12 force NF = 4 / 5: A/B in tools/gemm_nf_ab.py).  Same arithmetic per output either way.

@@ -110,3 +110,7 @@ struct WsPlan {
 };
 bool av_gemm_ws_eligible(const AnyV2VGemmDesc* d);
 int av_gemm_ws_launch(const GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s);
+
+// ---- one-wave-per-SIMD persistent kernel (gemm_sw.hip): 192 x 320 tiles, 4 waves, direct 16-byte stores ----
+bool av_gemm_sw_eligible(const AnyV2VGemmDesc* d);
+int av_gemm_sw_launch(GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s);

@@ -41,6 +41,14 @@ def test_gemm_pingpong_kernel(rows):
     _assert_all(gc.check_gemm_big((1 << 17) | ((1 << 19) if rows == 192 else (1 << 20)), tag=f"pp{rows}"))
 
 
+def test_gemm_single_wave_per_simd_kernel():
+    """gemm_sw_kernel (round 6: four waves = one per SIMD, 96 x 160 wave tiles with the accumulators in AGPRs, barrier inside the MFMA
+    stream, outputs stored straight from the registers through a permuted W row order), forced onto every eligible case of the
+    persistent-kernel check: torch fp32 references, the naive kernel, BIT-equality with the 128-row kernel (same MFMA shape and K order),
+    every tile order of the rastered launches, launches with more tiles than CUs, ragged M, GEGLU, two-source K loops."""
+    _assert_all(gc.check_gemm_big(1 << 21, tag="sw"))
+
+
 def test_fused_feed_forward_c320():
     _assert_all(gc.check_ff_fused())
 
