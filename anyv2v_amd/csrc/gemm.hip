@@ -1173,6 +1173,14 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         return av_launch_status("gemm_naive");
     }
     const bool glds = (d->flags & 2) != 0;
+    // Stream-K form of the one-wave-per-SIMD kernel (gemm_sw.hip): flags bit26 allows it where av_gemm_sw_sk_blocks says it pays,
+    // bit27 forces it; never for a batch-hinted launch (its K ranges depend on the launch's own tile count, i.e. they fix the
+    // arithmetic, and a hinted launch has to reproduce the arithmetic of the launch it stands for).
+    if (glds && (d->flags & ((1 << 26) | (1 << 27))) && !(d->flags & (1 << 22)) && av_gemm_sw_eligible(d) && av_hint_rows(d->M) == d->M &&
+        d->workspace != nullptr) {
+        const int blocks = av_gemm_sw_sk_blocks(d, (d->flags & (1 << 27)) != 0);
+        if (blocks > 0 && av_gemm_sw_sk_workspace(blocks) <= (size_t)d->workspace_bytes) return av_gemm_sw_sk_launch(k, d, blocks, s);
+    }
     // One-wave-per-SIMD persistent kernel (gemm_sw.hip): flags bit21 takes it wherever the shape allows, bit22 forbids it.
     if (glds && (d->flags & (1 << 21)) && !(d->flags & (1 << 22)) && av_gemm_sw_eligible(d)) return av_gemm_sw_launch(k, d, s);
     // 128-row kernel tile width: 160 columns (NF = 5) where N allows it, except where 128-column tiles (NF = 4) quantise better onto
@@ -1212,6 +1220,9 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
     // (the workspace test uses the PLANNED row count as well: a batch-hinted launch must reproduce the decision of the launch it
     //  stands for -- its own, smaller partial tiles could fit where the reference launch's do not, and the two would then split
     //  differently: seen at 16 f x 256^2, tests/test_gpu_parity.py::test_two_branch_steps_bit_equal_at_a_mid_size_full_width)
+    // (the split-K rules below see at most the 64 MiB the workspace had when they were tuned: a larger buffer -- the stream-K form
+    //  wants 126 MB -- must not change which launches split, i.e. their arithmetic)
+    const size_t split_ws_bytes = (size_t)d->workspace_bytes < ((size_t)64 << 20) ? (size_t)d->workspace_bytes : ((size_t)64 << 20);
     struct Plan { int big, splits; };
     auto plan = [&](int rows, int nf_rows) -> Plan {
         const bool ws_ok = d->workspace != nullptr && d->N % 8 == 0;
@@ -1223,7 +1234,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
                 int sp = 256 / tb;
                 if (sp > 8) sp = 8;
                 if (sp > nk_all / 12) sp = nk_all / 12;
-                if (sp >= 2 && tb * sp >= 224 && (size_t)sp * rows * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {1, sp};
+                if (sp >= 2 && tb * sp >= 224 && (size_t)sp * rows * d->N * sizeof(float) <= split_ws_bytes) return {1, sp};
             }
             if (fills || (d->flags & 8)) return {1, 1};
         }
@@ -1233,7 +1244,7 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
             int sp = (512 + tm - 1) / tm;
             if (sp > 8) sp = 8;
             if (sp > nk_all / 8) sp = nk_all / 8;
-            if (sp >= 2 && (size_t)sp * rows * d->N * sizeof(float) <= (size_t)d->workspace_bytes) return {0, sp};
+            if (sp >= 2 && (size_t)sp * rows * d->N * sizeof(float) <= split_ws_bytes) return {0, sp};
         }
         return {0, 1};
     };

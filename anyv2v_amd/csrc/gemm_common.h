@@ -114,3 +114,7 @@ int av_gemm_ws_launch(const GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s);
 // ---- one-wave-per-SIMD persistent kernel (gemm_sw.hip): 192 x 320 tiles, 4 waves, direct 16-byte stores ----
 bool av_gemm_sw_eligible(const AnyV2VGemmDesc* d);
 int av_gemm_sw_launch(GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s);
+// stream-K form (flags bit26 allows it, bit27 forces it): blocks to launch (0 = do not take it), its workspace need, the launch
+int av_gemm_sw_sk_blocks(const AnyV2VGemmDesc* d, bool force);
+size_t av_gemm_sw_sk_workspace(int blocks);
+int av_gemm_sw_sk_launch(GemmK& k, const AnyV2VGemmDesc* d, int blocks, hipStream_t s);

@@ -26,7 +26,10 @@
 
 namespace {
 
-constexpr int SW_MF = 6;                 // 16-row fragments per wave (96 rows), two wave rows -> 192-row block tile
+#ifndef SW_MF_
+#define SW_MF_ 6
+#endif
+constexpr int SW_MF = SW_MF_;          // 16-row fragments per wave (6: 96 rows, two wave rows -> 192-row block tile)
 constexpr int SW_BM = 32 * SW_MF, SW_BN = 320;
 constexpr int SW_A_BYTES = SW_BM * 128, SW_B_BYTES = SW_BN * 128;   // one K-tile (64 deep): 24 KiB of A, 40 KiB of W
 #ifndef SW_ALA
@@ -67,7 +70,10 @@ __device__ __forceinline__ float sw_acc(const float& a) {
 
 // gather addressing of the six A rows a thread stages per K-tile (rows srow0 + 32 i): inside one (tap, source) run consecutive
 // K-tiles only advance the channel offset; the row -> shifted-row math is redone when the tap or the source changes
-template <int MODE>
+// ORD (conv2d): 0 = tap-major K order (tap, channel slice) as gemm_big_kernel; 1 = slice-major (channel slice, dy, dx): the three dx taps
+// of one (slice, dy) are consecutive K-tiles and touch the same A lines shifted by one pixel -- L1 (TCP) hits when nothing else
+// allocates there in between (the W pieces then go past L1, `sc1`)
+template <int MODE, int ORD = 0>
 struct SwGen {
     const half_t* ap[SW_MF];
     int astep[SW_MF];
@@ -81,12 +87,20 @@ struct SwGen {
             astep[i] = sr < 0 ? 0 : 64;
         }
     }
-    __device__ __forceinline__ void start(const GemmK& p, const RowInfo (&ri)[SW_MF], int kc) {
-        tap = 0;
-        ktc = 0;
+    __device__ __forceinline__ void start(const GemmK& p, const RowInfo (&ri)[SW_MF], int kc, int kt0 = 0, int ntap = 1) {
+        tap = kt0 / ntap;          // (tap-major order; ORD 1 launches always start at K-tile 0)
+        ktc = kt0 - tap * ntap;
         recompute(p, ri, kc);
     }
     __device__ __forceinline__ void next(const GemmK& p, const RowInfo (&ri)[SW_MF], int kc, int ntap) {
+        if constexpr (ORD == 1) {
+            if (++tap == p.taps) {
+                tap = 0;
+                ++ktc;
+            }
+            recompute(p, ri, kc);
+            return;
+        }
         if (++ktc == ntap) {
             ktc = 0;
             ++tap;
@@ -99,6 +113,11 @@ struct SwGen {
         }
     }
 };
+
+__device__ __forceinline__ void glds16_sc1(const half_t* g, char* lds_wave_base) {   // the same piece past L1 (sc1): L2-served, no TCP line
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 16);
+}
 
 // W row (relative to the wave slab's first row) that LDS row `s + 32 * piece` of the slab holds, as  row = wrow_thread(s) + wrow_piece(piece):
 //  plain : LDS rows of a fragment pair (32 rows) hold W rows 8 (i / 4) + 4 f + i % 4  (f = fragment of the pair, i = row in it)
@@ -124,8 +143,13 @@ __device__ __forceinline__ constexpr int sw_wrow_piece(int pl) {   // pl: piece 
 
 // EPI: 0 = bias (+ temb row vector), 1 = bias + residual, 2 = GEGLU
 // KO (probe builds, tools/gemm_sw_ko.py): 1 = the K loop issues no LDS-DMA piece, 2 = no fragment reads either, 3 = pieces but no MFMAs,
-// 4 = W pieces only, 5 = A pieces from the zero line (issued, but always cache hits)
-template <int MODE, int EPI, int KO = 0>
+// 4 = W pieces only, 5 = A pieces from the zero line (issued, but always cache hits), 6 = A pieces in every third K-tile only;
+// conv2d: 7 = slice-major K order (slice, dy, dx) with the W pieces past L1 (sc1), 8 = that order with plain W pieces
+// SK (stream-K): the block owns a contiguous range of the launch's (tile, K-tile) units instead of whole tiles -- for launches whose
+// tiles cannot fill 256 CUs for a whole number of rounds.  Tiles cut by a range boundary leave their raw fp32 accumulators in a
+// workspace slab ([2 x blocks][192][320] fp32, columns in W-row order); gemm_sw_fixup_kernel sums a tile's slabs in K order and
+// finishes them (bias / temb / GEGLU / residual).  Tiles a block covers alone take the normal epilogue.
+template <int MODE, int EPI, int KO = 0, bool SK = false>
 __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
     constexpr bool GEGLU = EPI == 2;
     constexpr int MF = SW_MF, BM = SW_BM, BN = SW_BN, A_BYTES = SW_A_BYTES, B_BYTES = SW_B_BYTES;
@@ -144,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int G = gridDim.x;
     // tile order: as gemm_big_kernel (classic = N-fastest in XCD-contiguous runs; rastered = rast_gm x rast_gn super-tiles per XCD round)
-    const bool rast = p.rast_gm > 0;
+    const bool rast = !SK && p.rast_gm > 0;
     const int b0 = rast ? (int)blockIdx.x : (((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x);
     const int tilesM = (p.M + BM - 1) / BM;
     const int ntiles = rast ? G * ((p.rast_sm * p.rast_sn + 7) >> 3) : tilesM * p.tilesN;
@@ -180,51 +204,83 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
     const int ntap = p.nt0 + p.nt1;
     const int nk = p.taps * ntap;
     RowInfo ri[MF];
-    SwGen<MODE> gen;
+    constexpr int ORD = (MODE == MODE_CONV2D && (KO == 7 || KO == 8)) ? 1 : 0;   // (probe builds: slice-major conv K order)
+    constexpr bool WSC1 = KO == 7;                                                // (probe builds: W pieces past L1)
+    SwGen<MODE, ORD> gen;
+    int w_tap = 0, w_slice = 0;   // ORD 1: position of the W stream inside the tile
     int a_tile, a_kt;      // A stream position (a_tile >= ntiles: past the end, its pieces read the zero line)
     const half_t* bptr;    // W row of LDS row srow0 of wave slab 0 (pieces: + sw_wrow_piece rows, slab 1: + 160 rows)
     const half_t* bptr4;   // GEGLU: the natural-order fifth block
     int w_tile, w_kt;      // W stream position
-    auto a_start = [&](int item) {
+    // SK: units [u0, u1) of the flattened (tile, K-tile) space; a_left / w_left = units of the range the streams have not requested yet
+    const long long U = (long long)ntiles * nk;
+    const int u0 = SK ? (int)(U * b0 / G) : 0, u1 = SK ? (int)(U * (b0 + 1) / G) : 0;
+    int a_left = u1 - u0, w_left = u1 - u0;
+    auto a_start = [&](int item, int kt0 = 0) {
         a_tile = item;
-        a_kt = 0;
+        a_kt = kt0;
         if (item < ntiles) {
             int mt, nt;
             decode(item, mt, nt);
 #pragma unroll
             for (int i = 0; i < MF; ++i) ri[i] = make_row<MODE>(p, mt * BM + srow0 + 32 * i);
-            gen.start(p, ri, kc);
+            gen.start(p, ri, kc, kt0, ntap);
         }
     };
     auto a_step = [&]() {
         if (a_tile >= ntiles) return;
+        if constexpr (SK) {
+            if (--a_left <= 0) {
+                a_tile = ntiles;
+                return;
+            }
+        }
         if (++a_kt == nk)
-            a_start(next_valid(a_tile + G));
+            a_start(SK ? a_tile + 1 : next_valid(a_tile + G));
         else
             gen.next(p, ri, kc, ntap);
     };
-    auto w_start = [&](int item) {
+    auto w_start = [&](int item, int kt0 = 0) {
         w_tile = item;
-        w_kt = 0;
+        w_kt = kt0;
         if (item < ntiles) {
             int mt, nt;
             decode(item, mt, nt);
-            bptr = p.W + (size_t)(nt * BN + sw_wrow_thread<GEGLU>(srow0)) * p.Ktot + kc * 8;
-            bptr4 = p.W + (size_t)(nt * BN + srow0) * p.Ktot + kc * 8;
+            bptr = p.W + (size_t)(nt * BN + sw_wrow_thread<GEGLU>(srow0)) * p.Ktot + kc * 8 + (size_t)kt0 * 64;
+            bptr4 = p.W + (size_t)(nt * BN + srow0) * p.Ktot + kc * 8 + (size_t)kt0 * 64;
+            w_tap = w_slice = 0;
         }
     };
     auto w_step = [&]() {
         if (w_tile >= ntiles) return;
+        if constexpr (SK) {
+            if (--w_left <= 0) {
+                w_tile = ntiles;
+                return;
+            }
+        }
         if (++w_kt == nk) {
-            w_start(next_valid(w_tile + G));
+            w_start(SK ? w_tile + 1 : next_valid(w_tile + G));
         } else {
-            bptr += 64;
-            bptr4 += 64;
+            if constexpr (ORD == 1) {   // W column block of K-tile (slice, tap): tap * ntap + slice
+                const int prev = w_tap * ntap + w_slice;
+                if (++w_tap == p.taps) {
+                    w_tap = 0;
+                    ++w_slice;
+                }
+                bptr += (w_tap * ntap + w_slice - prev) * 64;
+            } else {
+                bptr += 64;
+                bptr4 += 64;
+            }
         }
     };
     auto a_piece = [&](int i, int slot, bool fetch) {   // i: constant after unrolling
         if constexpr (KO == 1 || KO == 2 || KO == 4) return;
         if constexpr (KO == 5) fetch = false;           // (probe: A pieces issued, all from the 256-byte zero line)
+        if constexpr (KO == 6) {                        // (probe: A pieces in one K-tile of three -- what a 3x-reused patch would request)
+            if (a_kt % 3 != 0) return;
+        }
         glds16(fetch ? gen.ap[i] : p.zeros, smem + slot * A_BYTES + (i * 256 + w * 64) * 16);
     };
     auto w_piece = [&](int j, int slot, bool fetch) {   // j: constant after unrolling
@@ -232,7 +288,10 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
         const int ws = j / 5, pl = j % 5;
         const half_t* src = (GEGLU && pl == 4) ? bptr4 + (size_t)(ws * 160 + 128) * p.Ktot
                                                : bptr + (size_t)(ws * 160 + sw_wrow_piece<GEGLU>(pl)) * p.Ktot;
-        glds16(fetch ? src : p.zeros, smem + W_BASE + slot * B_BYTES + (j * 256 + w * 64) * 16);
+        if constexpr (WSC1)
+            glds16_sc1(fetch ? src : p.zeros, smem + W_BASE + slot * B_BYTES + (j * 256 + w * 64) * 16);
+        else
+            glds16(fetch ? src : p.zeros, smem + W_BASE + slot * B_BYTES + (j * 256 + w * 64) * 16);
     };
 
     // ---- consumer: fragment addresses ----
@@ -292,11 +351,23 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
                 wq[t & 3] = sw_frag<KO != 2>(bbase[t / 10], (t % 10) * 2048);
                 w_seq[t] = ++seq;
             }
-            if (g < 5) {
-                w_piece(2 * g, sw ^ 1, fetch_w);
-                w_piece(2 * g + 1, sw ^ 1, fetch_w);
-            } else if (g < 5 + MF) {
-                a_piece(g - 5, sa2, fetch_a);
+            if constexpr (ALA == 2) {   // W first: the A pieces must be the youngest loads at the counted wait
+                if (g < 5) {
+                    w_piece(2 * g, sw ^ 1, fetch_w);
+                    w_piece(2 * g + 1, sw ^ 1, fetch_w);
+                } else if (g < 5 + MF) {
+                    a_piece(g - 5, sa2, fetch_a);
+                }
+            } else {                    // A first (the operand that misses gets the longest run-up; measured: W first costs 15-20 %)
+                if (2 * g + 1 < MF) {
+                    a_piece(2 * g, sa2, fetch_a);
+                    a_piece(2 * g + 1, sa2, fetch_a);
+                } else if (g == MF / 2) {
+                    w_piece(0, sw ^ 1, fetch_w);
+                    w_piece(1, sw ^ 1, fetch_w);
+                } else if (g > MF / 2 && g - MF / 2 + 1 < 10) {
+                    w_piece(g - MF / 2 + 1, sw ^ 1, fetch_w);
+                }
             }
             if (g == 17) {
                 if constexpr (ALA == 2) {
@@ -319,11 +390,18 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    int tile = next_valid(b0);
-    if (tile >= ntiles) return;
+    int tile, kb = 0;   // the segment being multiplied: K-tiles [kb, ke) of `tile` (kb = 0, ke = nk unless SK)
+    if constexpr (SK) {
+        if (u1 <= u0) return;
+        tile = u0 / nk;
+        kb = u0 - tile * nk;
+    } else {
+        tile = next_valid(b0);
+        if (tile >= ntiles) return;
+    }
     // prologue: A(0) -> A slot 0, W(0) -> W slot 0 (ring form: A(1) -> A slot 1, which may stay in flight)
-    a_start(tile);
-    w_start(tile);
+    a_start(tile, kb);
+    w_start(tile, kb);
 #pragma unroll
     for (int i = 0; i < MF; ++i) a_piece(i, 0, true);
     a_step();
@@ -358,23 +436,48 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
         sw ^= 1;
     };
 
+    int u_done = u0;          // SK: first unit of the range not multiplied yet
+    bool first_seg = true;    // SK: the segment in hand is the block's first (its partial result goes to slab 2 b, a later one to 2 b + 1)
     while (true) {
         int mt, nt;
         decode(tile, mt, nt);
-        const int next_tile = next_valid(tile + G);
+        const int next_tile = SK ? 0 : next_valid(tile + G);
         const bool has_next = next_tile < ntiles;
         // (K-tile 0 is peeled: its first K-step starts the accumulators from the constant 0, so there is one straight-line definition
         //  of the accumulators per tile and no zeroing pass; dispatch guarantees nk >= 2)
+        const int ke = SK ? (nk - kb < u1 - u_done ? nk : kb + (u1 - u_done)) : nk;
         ktile(std::true_type{}, sa, sw, w_tile < ntiles, a_tile < ntiles);
         body_done();
-        for (int kt = 1; kt < nk; ++kt) {
+        for (int kt = kb + 1; kt < ke; ++kt) {
             ktile(std::false_type{}, sa, sw, w_tile < ntiles, a_tile < ntiles);
             body_done();
         }
 
-        // ---------------- epilogue: straight from the accumulators, 16-byte stores (see the W row permutation above) ----------------
         const int m_wave = mt * BM + wr * MF * 16;
         const int n_wave = nt * BN + wc * 160;
+        if (SK && !(kb == 0 && ke == nk)) {
+            // ---------------- stream-K: this block holds only K-tiles [kb, ke) of the tile -> raw fp32 accumulators to its slab ----------------
+            // slab [192][320] fp32, column = W row inside the N-tile (the order bias / temb / GEGLU pairing are defined in)
+            float* slab = p.partial + (size_t)(2 * b0 + (first_seg ? 0 : 1)) * (BM * BN);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                float* srow = slab + (size_t)(wr * MF * 16 + mf * 16 + l15) * BN + wc * 160;
+#pragma unroll
+                for (int nf = 0; nf < 10; ++nf) {
+                    int col;
+                    if constexpr (GEGLU)
+                        col = nf < 8 ? 64 * (nf >> 2) + 32 * (lq >> 1) + 16 * (nf & 1) + 8 * (lq & 1) + 4 * ((nf >> 1) & 1) : 128 + 16 * (nf - 8) + 4 * lq;
+                    else
+                        col = 32 * (nf >> 1) + 8 * lq + 4 * (nf & 1);
+                    f4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sw_acc(acc[mf][nf][e]);
+                    *(f4*)(srow + col) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+        // ---------------- epilogue: straight from the accumulators, 16-byte stores (see the W row permutation above) ----------------
         if constexpr (!GEGLU) {
             h8 bias8[5];
 #pragma unroll
@@ -467,8 +570,86 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (!has_next) break;
-        tile = next_tile;
+        if constexpr (SK) {
+            u_done += ke - kb;
+            if (u_done >= u1) break;
+            ++tile;
+            kb = 0;
+            first_seg = false;
+        } else {
+            if (!has_next) break;
+            tile = next_tile;
+        }
+    }
+}
+
+// stream-K second pass: one block per output tile; tiles a single range covers were finished by the main kernel (nothing to do),
+// the others are the sum of their contributors' slabs in block (= K) order, then the usual epilogue.  `G` = blocks of the main launch.
+template <bool GEGLU>
+__global__ __launch_bounds__(256) void gemm_sw_fixup_kernel(const GemmK p, int G, int nk) {
+    constexpr int BM = SW_BM, BN = SW_BN;
+    const int t = blockIdx.x;
+    const int tilesM = (p.M + BM - 1) / BM;
+    const long long U = (long long)tilesM * p.tilesN * nk;
+    auto u_of = [&](int b) { return (int)(U * b / G); };
+    auto block_of = [&](int u) {   // the b with u_of(b) <= u < u_of(b + 1)
+        int b = (int)(((long long)(u + 1) * G - 1) / U);
+        while (b > 0 && u_of(b) > u) --b;
+        while (b + 1 < G && u_of(b + 1) <= u) ++b;
+        return b;
+    };
+    const int bf = block_of(t * nk), bl = block_of((t + 1) * nk - 1);
+    if (bf == bl) return;
+    const int mt = t / p.tilesN, nt = t - mt * p.tilesN;
+    const int NO = GEGLU ? BN / 2 : BN;          // output columns of the tile
+    const int Nout = GEGLU ? p.N / 2 : p.N;
+    for (int id = threadIdx.x; id < BM * (NO / 8); id += 256) {
+        const int r = id / (NO / 8), c8 = (id - r * (NO / 8)) * 8;
+        const int m = mt * BM + r;
+        if (m >= p.M) continue;
+        // W-row columns of the 8 outputs: plain = c8 .. c8 + 7; GEGLU: output j <- h column 32 (j / 16) + j % 16, gate column + 16
+        const int ch = GEGLU ? 32 * (c8 >> 4) + (c8 & 15) : c8;
+        float vh[8], vg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vh[e] = vg[e] = 0.f;
+        for (int b = bf; b <= bl; ++b) {
+            const int first_tile = u_of(b) / nk;
+            const float* slab = p.partial + (size_t)(2 * b + (t == first_tile ? 0 : 1)) * (BM * BN) + (size_t)r * BN;
+            const f4 a0 = *(const f4*)(slab + ch), a1 = *(const f4*)(slab + ch + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vh[e] += a0[e];
+                vh[4 + e] += a1[e];
+            }
+            if constexpr (GEGLU) {
+                const f4 g0 = *(const f4*)(slab + ch + 16), g1 = *(const f4*)(slab + ch + 20);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vg[e] += g0[e];
+                    vg[4 + e] += g1[e];
+                }
+            }
+        }
+        const int n_w = nt * BN + ch;            // W row / bias index of the first value
+        h8 o;
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float hv = vh[e] + (p.bias != nullptr ? (float)p.bias[n_w + e] : 0.f);
+                const float gv = vg[e] + (p.bias != nullptr ? (float)p.bias[n_w + 16 + e] : 0.f);
+                o[e] = (half_t)(hv * av_gelu(gv));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = vh[e] + (p.bias != nullptr ? (float)p.bias[n_w + e] : 0.f);
+                if (p.rowvec != nullptr) v += (float)p.rowvec[(size_t)(m / p.rowvec_div) * p.ldrv + n_w + e];
+                o[e] = (half_t)v;
+            }
+            if (p.R != nullptr) o = o + *(const h8*)(p.R + (size_t)m * p.ldr + n_w);
+        }
+        const int n_out = (GEGLU ? nt * (BN / 2) : nt * BN) + c8;
+        if (n_out < Nout) *(h8*)(p.C + (size_t)m * p.ldc + n_out) = o;
     }
 }
 
@@ -490,6 +671,11 @@ static void sw_launch_mode(const GemmK& k, const AnyV2VGemmDesc* d, dim3 grid, h
         }
     }
 #ifdef ANYV2V_EXPERIMENTS
+    if constexpr (MODE == MODE_CONV2D) {
+        const int ko = (d->flags >> 23) & 15;
+        if (ko == 7 && d->R == nullptr) { hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 7>), grid, dim3(256), 0, s, k); return; }
+        if (ko == 8 && d->R == nullptr) { hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 8>), grid, dim3(256), 0, s, k); return; }
+    }
     if constexpr (MODE == MODE_LINEAR) {
         const int ko = (d->flags >> 23) & 7;
         if (ko == 1) { hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 1>), grid, dim3(256), 0, s, k); return; }
@@ -497,6 +683,7 @@ static void sw_launch_mode(const GemmK& k, const AnyV2VGemmDesc* d, dim3 grid, h
         if (ko == 3) { hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 3>), grid, dim3(256), 0, s, k); return; }
         if (ko == 4) { hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 4>), grid, dim3(256), 0, s, k); return; }
         if (ko == 5) { hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 5>), grid, dim3(256), 0, s, k); return; }
+        if (ko == 6) { hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 6>), grid, dim3(256), 0, s, k); return; }
     }
 #endif
     if (d->R != nullptr)
@@ -531,4 +718,55 @@ int av_gemm_sw_launch(GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s) {
     else
         sw_launch_mode<MODE_LINEAR>(k, d, grid, s);
     return av_launch_status("gemm_sw");
+}
+
+// ---- stream-K form -------------------------------------------------------------------------------------
+// Workspace: two fp32 slabs of 192 x 320 per block of the main launch.
+size_t av_gemm_sw_sk_workspace(int blocks) { return (size_t)2 * blocks * SW_BM * SW_BN * sizeof(float); }
+
+// Blocks the stream-K form would use, or 0 when it should not be taken: the launch's (tile, K-tile) units are dealt evenly to
+// min(256, units / 4) blocks.  It pays where whole tiles quantise badly onto 256 CUs (tiles / (rounds x 256) below ~0.9) and every
+// block still gets a few K-tiles.
+int av_gemm_sw_sk_blocks(const AnyV2VGemmDesc* d, bool force) {
+    const int tiles = ((d->M + SW_BM - 1) / SW_BM) * (d->N / 320);
+    const int nk = (d->mode == MODE_LINEAR ? 1 : (d->mode == MODE_CONV2D ? 9 : 3)) * ((d->C0 + d->C1) / 64);
+    const long long U = (long long)tiles * nk;
+    if (U < 256 * 4 || U > (1ll << 22)) return force && U >= 8 ? (int)(U / 4 < 256 ? U / 4 : 256) : 0;
+    if (force) return 256;
+    const int rounds = (tiles + 255) / 256;
+    const double eff = (double)tiles / (rounds * 256.0);
+    return eff < 0.9 ? 256 : 0;
+}
+
+template <int MODE>
+static void sw_sk_launch_mode(const GemmK& k, const AnyV2VGemmDesc* d, dim3 grid, hipStream_t s) {
+    if constexpr (MODE == MODE_LINEAR) {
+        if (d->act == ACT_GEGLU) {
+            hipLaunchKernelGGL((gemm_sw_kernel<MODE_LINEAR, 2, 0, true>), grid, dim3(256), 0, s, k);
+            return;
+        }
+    }
+    if (d->R != nullptr)
+        hipLaunchKernelGGL((gemm_sw_kernel<MODE, 1, 0, true>), grid, dim3(256), 0, s, k);
+    else
+        hipLaunchKernelGGL((gemm_sw_kernel<MODE, 0, 0, true>), grid, dim3(256), 0, s, k);
+}
+
+int av_gemm_sw_sk_launch(GemmK& k, const AnyV2VGemmDesc* d, int blocks, hipStream_t s) {
+    const int tiles = ((d->M + SW_BM - 1) / SW_BM) * (d->N / 320);
+    const int nk = k.taps * (k.nt0 + k.nt1);
+    k.tilesN = d->N / 320;
+    k.partial = (float*)d->workspace;
+    const dim3 grid(blocks);
+    if (d->mode == MODE_CONV2D)
+        sw_sk_launch_mode<MODE_CONV2D>(k, d, grid, s);
+    else if (d->mode == MODE_TEMPORAL)
+        sw_sk_launch_mode<MODE_TEMPORAL>(k, d, grid, s);
+    else
+        sw_sk_launch_mode<MODE_LINEAR>(k, d, grid, s);
+    if (d->act == ACT_GEGLU)
+        hipLaunchKernelGGL((gemm_sw_fixup_kernel<true>), dim3(tiles), dim3(256), 0, s, k, blocks, nk);
+    else
+        hipLaunchKernelGGL((gemm_sw_fixup_kernel<false>), dim3(tiles), dim3(256), 0, s, k, blocks, nk);
+    return av_launch_status("gemm_sw<stream-K>");
 }

@@ -56,11 +56,12 @@ class workspace_slot:
 
 
 def _workspace(device) -> torch.Tensor:
-    """Persistent fp32 scratch for split-K partial tiles (64 MiB per device and slot; allocated once, outside any graph capture
-    because the first GEMM of a process always runs eagerly during warm-up)."""
+    """Persistent fp32 scratch for split-K partial tiles and stream-K slabs (128 MiB per device and slot -- the split-K rules keep
+    planning against 64 MiB, the stream-K form needs 126 MB; allocated once, outside any graph capture because the first GEMM of a
+    process always runs eagerly during warm-up)."""
     key = f"{device}:{WS_SLOT}"
     if key not in _WS:
-        _WS[key] = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)
+        _WS[key] = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=device)
     return _WS[key]
 
 

@@ -164,10 +164,11 @@ def check_gemm(variants=("reg", "glds", "naive")):
     return out
 
 
-def check_gemm_big(extra=0, tag="big"):
+def check_gemm_big(extra=0, tag="big", exact=True):
     """Persistent 256x320 kernel (gemm_big_kernel), forced with flag bit3 on shapes small enough for the references:
     single / multiple rounds per block, every mode, two-source K loop, bias / temb / residual / GEGLU epilogues.
-    ``extra``: further AnyV2VGemmDesc.flags bits, e.g. bit17 (| bit19 / bit20) = the ping-pong kernel gemm_pp_kernel (192- / 256-row
+    ``exact`` = False: the forced kernel sums K in a different order (stream-K: fp32 partial slabs) -- the bit-equality rows become
+    5e-4 rows.  ``extra``: further AnyV2VGemmDesc.flags bits, e.g. bit17 (| bit19 / bit20) = the ping-pong kernel gemm_pp_kernel (192- / 256-row
     tiles) on every non-GEGLU case -- same references, same bit-equality with the 128-row kernel."""
     out = []
     saved = ops.GEMM_FLAGS
@@ -187,7 +188,7 @@ def check_gemm_big(extra=0, tag="big"):
             ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
             ys = ops.gemm(a, w, bias=bias, rowvec=rv, rowvec_div=rvd, residual=r)
             ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
-            out.append(_res(f"gemm[{tag}] bit-equal to the 128-row kernel M{M} N{N} K{K}", y, ys.float(), 0.0))
+            out.append(_res(f"gemm[{tag}] bit-equal to the 128-row kernel M{M} N{N} K{K}", y, ys.float(), 0.0 if exact else 5e-4))
         # two-source K loop (skip concat)
         a0, a1 = rnd(768, 128), rnd(768, 64)
         w = rnd(320, 192, scale=0.1)
@@ -218,7 +219,7 @@ def check_gemm_big(extra=0, tag="big"):
                 ops.GEMM_FLAGS = ((saved & ~4) | 8 | extra) | (code << 13) | (nfast << 16)
                 y = ops.gemm(a, w, bias=bias, act=act)
                 out.append(_res(f"gemm[{tag}] raster code {code} nfast {nfast} bit-equal to the classic order M{M} N{N} geglu={geglu}", y,
-                                y0.float(), 0.0))
+                                y0.float(), 0.0 if exact else 5e-4))
             ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
         # conv 3x3 (stride 1, stride 2, folded upsample) with temb row vector / residual
         n, ci, co, H, W = 8, 64, 320, 16, 16
@@ -232,7 +233,7 @@ def check_gemm_big(extra=0, tag="big"):
         ys = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=2 * H * W, residual=res, mode=ops.MODE_CONV2D,
                       conv=(H, W, H, W, 1, 0))
         ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
-        out.append(_res(f"conv3x3[{tag}] bit-equal to the 128-row kernel", y, ys.float(), 0.0))
+        out.append(_res(f"conv3x3[{tag}] bit-equal to the 128-row kernel", y, ys.float(), 0.0 if exact else 5e-4))
         y = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, mode=ops.MODE_CONV2D, conv=(H, W, H // 2, W // 2, 2, 0),
                      M=n * (H // 2) * (W // 2))
         out.append(_res(f"conv3x3[{tag}] stride 2", y, _to_tokens(F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1)), KTOL))
@@ -270,7 +271,7 @@ def check_gemm_big(extra=0, tag="big"):
             ys = ops.gemm(_to_tokens(x), _pack_conv(w), bias=b, rowvec=temb, rowvec_div=8 * H * W, residual=r_, mode=ops.MODE_CONV2D,
                           conv=(H, W, H, W, 1, 0))
             ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
-            out.append(_res(f"conv3x3[{tag}] 288+ tiles bit-equal to the 128-row kernel res={r_ is not None}", y, ys.float(), 0.0))
+            out.append(_res(f"conv3x3[{tag}] 288+ tiles bit-equal to the 128-row kernel res={r_ is not None}", y, ys.float(), 0.0 if exact else 5e-4))
         B_, Fr, HW, C = 3, 16, 1600, 128
         xt = rnd(B_ * Fr * HW, C)
         wt, bt, rt = rnd(320, C, 3, scale=1 / math.sqrt(3 * C)), rnd(320), rnd(B_ * Fr * HW, 320)
@@ -285,7 +286,7 @@ def check_gemm_big(extra=0, tag="big"):
         ops.GEMM_FLAGS = (saved & ~8) | 4 | 16
         ys = ops.gemm(a, w2, bias=bb, residual=r2)
         ops.GEMM_FLAGS = (saved & ~4) | 8 | extra
-        out.append(_res(f"gemm[{tag}] FF-down shape bit-equal to the 128-row kernel", y, ys.float(), 0.0))
+        out.append(_res(f"gemm[{tag}] FF-down shape bit-equal to the 128-row kernel", y, ys.float(), 0.0 if exact else 5e-4))
     finally:
         ops.GEMM_FLAGS = saved
     return out

@@ -49,6 +49,14 @@ def test_gemm_single_wave_per_simd_kernel():
     _assert_all(gc.check_gemm_big(1 << 21, tag="sw"))
 
 
+def test_gemm_single_wave_kernel_stream_k():
+    """The stream-K form of gemm_sw_kernel (blocks own contiguous ranges of (tile, K-tile) units; tiles cut by a range boundary are
+    summed from fp32 slabs by gemm_sw_fixup_kernel), forced (flags bit27) onto every eligible case of the persistent-kernel check:
+    torch fp32 references and the naive kernel at the usual tolerance; against the unsplit kernels 5e-4 (a different fp32 summation
+    order, not bit-equal by construction)."""
+    _assert_all(gc.check_gemm_big(1 << 27, tag="sk", exact=False))
+
+
 def test_fused_feed_forward_c320():
     _assert_all(gc.check_ff_fused())
 

@@ -15,10 +15,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--tag", default="r06_gemm_sw_ab")
 ap.add_argument("--quick", action="store_true")
+ap.add_argument("--sk", action="store_true", help="second arm = the stream-K form (flags bit27) instead of the whole-tile form (bit21)")
+ap.add_argument("--batches", default="3,1")
 args = ap.parse_args()
 dev = "cuda"
 lines = []
-ARMS = (("default", 0), ("sw", 1 << 21))
+ARMS = (("default", 0), ("sw", 1 << 27 if args.sk else 1 << 21))
 
 
 def case(tag, M, N, K, mode=0, act=0, conv=None, temporal=None, res=False, rv=0, a_rows=None, c1=0):
@@ -52,13 +54,14 @@ def case(tag, M, N, K, mode=0, act=0, conv=None, temporal=None, res=False, rv=0,
     ops.GEMM_FLAGS = 0
     med = [sorted(t)[len(t) // 2] for t in times]
     eq = bool(torch.equal(outs[0], outs[1]))
+    err = float((outs[0].float() - outs[1].float()).abs().max() / outs[0].float().abs().max())
     fl = 2.0 * M * N * K
     lines.append(f"{tag:<30s} M={M:6d} N={N:5d} K={K:5d}: default {med[0]:7.1f} us ({fl / med[0] / 1e6:6.0f} TF) | sw {med[1]:7.1f} us "
-                 f"({fl / med[1] / 1e6:6.0f} TF) | sw/default {med[1] / med[0]:5.3f} | bit-equal {eq}")
+                 f"({fl / med[1] / 1e6:6.0f} TF) | sw/default {med[1] / med[0]:5.3f} | bit-equal {eq} (max diff {err:.1e})")
     print(lines[-1], flush=True)
 
 
-for B, tagB in ((3, "B3"), (1, "B1")):
+for B, tagB in [(int(b), f"B{b}") for b in args.batches.split(",")]:
     T0, T1, T2, T3 = B * 65536, B * 16384, B * 4096, B * 1024
     if not args.quick:
         case(f"{tagB} L0 conv3x3 +res", T0, 320, 2880, mode=1, conv=(64, 64, 64, 64, 1, 0), res=True)
@@ -79,8 +82,14 @@ for B, tagB in ((3, "B3"), (1, "B1")):
     case(f"{tagB} L2 conv3x3 +res", T2, 1280, 11520, mode=1, conv=(16, 16, 16, 16, 1, 0), res=True)
     case(f"{tagB} L2 temporal conv", T2, 1280, 3840, mode=2, temporal=(16, 256))
     if not args.quick:
+        case(f"{tagB} L3 out-proj +res", T3, 1280, 1280, res=True)
         case(f"{tagB} L3 QKV", T3, 3840, 1280)
         case(f"{tagB} L3 GEGLU", T3, 10240, 1280, act=3)
+        case(f"{tagB} L3 FF down +res", T3, 1280, 5120, res=True)
         case(f"{tagB} L3 conv3x3 +res", T3, 1280, 11520, mode=1, conv=(8, 8, 8, 8, 1, 0), res=True)
+        case(f"{tagB} L3 conv3x3 2560->1280 +temb", T3, 1280, 23040, mode=1, conv=(8, 8, 8, 8, 1, 0), rv=64, c1=1280)
+        case(f"{tagB} L3 temporal conv", T3, 1280, 3840, mode=2, temporal=(16, 64))
+        case(f"{tagB} L2 conv3x3 2560->1280 +temb", T2, 1280, 23040, mode=1, conv=(16, 16, 16, 16, 1, 0), rv=256, c1=1280)
+        case(f"{tagB} L1 conv3x3 1280->640 +temb", T1, 640, 11520, mode=1, conv=(32, 32, 32, 32, 1, 0), rv=1024, c1=640)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", args.tag + ".txt"), "w").write("\n".join(lines) + "\n")

@@ -16,7 +16,8 @@ from anyv2v_amd import ops  # noqa: E402
 dev = "cuda"
 lines = []
 ARMS = (("gemm_big (default)", 8), ("sw", 1 << 21), ("sw no DMA", (1 << 21) | (1 << 23)), ("sw no DMA no reads", (1 << 21) | (2 << 23)),
-        ("sw no MFMA", (1 << 21) | (3 << 23)), ("sw W pieces only", (1 << 21) | (4 << 23)), ("sw A from zero line", (1 << 21) | (5 << 23)))
+        ("sw no MFMA", (1 << 21) | (3 << 23)), ("sw W pieces only", (1 << 21) | (4 << 23)), ("sw A from zero line", (1 << 21) | (5 << 23)),
+        ("sw A pieces every 3rd K-tile", (1 << 21) | (6 << 23)))
 for (M, N, K) in [(12288, 1280, 11520), (12288, 1280, 5120), (49152, 640, 5760), (196608, 320, 2880), (49152, 1920, 640)]:
     a = torch.randn(M, K, device=dev).half()
     w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
