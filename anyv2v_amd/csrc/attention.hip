@@ -111,7 +111,7 @@ __device__ __forceinline__ h8 join8(fp16x4v_t a, fp16x4v_t b) {
 // as this form, but costs a second fp16 rounding of Q (error 3e-4 -> 7e-4, growing with |s c|); one whole-tile softmax without
 // the 16-key steps needs 185 VGPRs (2 waves per SIMD) or spills.
 template <int STAGES, int NV, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? (NV == 1 ? 4 : 2) : (NV == 1 ? 3 : 2)) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? (NV == 1 ? 4 : 2) : (NV == 1 ? (STAGES == 2 ? 4 : 3) : 2)) void flash_attn_d64_v2_kernel(const AttnK p, const half_t* zeros) {
     constexpr int TILE_BYTES = 8192, STAGE_BYTES = (1 + NV) * TILE_BYTES, PRE = STAGES - 1;  // PRE tiles in flight
     constexpr int NT = 64 * NW, DI = 512 / NT;  // threads; LDS-DMA instructions per thread and 8-KiB tile matrix (512 chunks of 16 B)
     constexpr int LPT = DI * (1 + NV);          // LDS-DMA per thread per tile
@@ -714,6 +714,12 @@ static int launch_naive(const AttnK& k, hipStream_t s, const float* bias = nullp
     return av_launch_status("attention_naive");
 }
 
+// PnP injection launch (i2vgen-xl/pnp_utils.py:189-196, :295-302): three branches whose Q / K are the source branch's -> the shared-softmax
+// kernels.  ONE predicate for the short and the flash path (flag bit3 forces the per-branch aliasing form).
+static inline bool av_attn_pnp3(const AttnK& k, const AnyV2VAttnDesc* d) {
+    return k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8);
+}
+
 extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
     AttnK k;
     int rc = fill(d, k, 64);
@@ -723,7 +729,7 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
                       av_aligned16(d->Q) && av_aligned16(d->K) && av_aligned16(d->V) && av_aligned16(d->O);
     if (!fast) return launch_naive(k, s);
     if (k.Sq <= 16 && k.Sk <= 16 && d->ldo % 8 == 0 && !(d->flags & 2)) {  // temporal attention at <= 16 frames: one wave per sequence
-        if (k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8)) {
+        if (av_attn_pnp3(k, d)) {
             // PnP injection step: one wave per (source element, head), one softmax, three V / O streams (flag bit3: aliasing form)
             const long long units3 = (long long)k.qk_mod * k.heads;
             hipLaunchKernelGGL(short_attn_d64_kernel<3>, dim3((unsigned)((units3 + 3) / 4)), dim3(256), 0, s, k);
@@ -741,7 +747,7 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
         if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_attn_zero_line)) == hipSuccess) zeros = (const half_t*)ptr;
     }
     AV_CHECK(zeros != nullptr, "attention: zero line symbol unavailable");
-    if (k.qk_mod > 0 && k.batch == 3 * k.qk_mod && k.kv_div == 1 && !(d->flags & 8)) {
+    if (av_attn_pnp3(k, d)) {
         // PnP injection step: one softmax per source element, three V / O streams (flag bit3 forces the aliasing form)
         const long long nwg3 = (long long)k.qk_mod * k.heads * k.q_tiles;
         // long KV loops with enough 256-query blocks to fill the chip (the 64x64 level: 16 x 5 x 16 = 1280): 8-wave blocks around a
@@ -766,7 +772,8 @@ extern "C" int anyv2v_attention_f16(const AnyV2VAttnDesc* d, void* stream) {
         hipLaunchKernelGGL((flash_attn_d64_v2_kernel<3, 1, 8>), dim3((unsigned)nwg8), dim3(512), 0, s, k, zeros);
         return av_launch_status("flash_attn_d64_v2<8 waves>");
     }
-    // 4-wave blocks on a 2-stage ring: 32 KiB of LDS per block = four blocks per CU (three with 3 stages); the short-KV launches
+    // 4-wave blocks on a 2-stage ring: 32 KiB of LDS per block = four blocks per CU (three with 3 stages; the kernel's launch bounds ask
+    // for four waves per SIMD, it allocates 126 VGPRs -- profiles/r06_attention_resource_usage.txt); the short-KV launches
     // (cross-attention, Sk = 145: three tiles per block, 7680 blocks) are bound by how many blocks are in flight -- 95.8 -> 82.6 us at
     // (48, 5, 4096, 145), never slower up to Sk = 1024 (profiles/r05_attn_cross_2stage_ab.txt); bit-equal
     hipLaunchKernelGGL((flash_attn_d64_v2_kernel<2, 1, 4>), dim3((unsigned)nwg), dim3(256), 0, s, k, zeros);

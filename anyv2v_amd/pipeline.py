@@ -23,7 +23,7 @@ import torch
 from . import ops, pnp_utils
 from .schedulers import DDIMScheduler
 from .unet import I2VGenXLUNet, I2VGenXLUNetConfig
-from .utils import LatentTrajectory, capture_hip_graph, load_ddim_latents_at_t
+from .utils import LatentTrajectory, capture_hip_graph, load_ddim_latents_at_t, release_graphs
 
 logger = logging.getLogger(__name__)
 
@@ -510,9 +510,9 @@ class I2VGenXLPipeline:
         evict += [k for k in list(self._engines)[: max(0, len(self._engines) - len(evict) - limit)] if k not in evict]
         for k in evict:
             old = self._engines.pop(k)
-            old.graphs.clear()
+            release_graphs(old.graphs)   # (parked, not destroyed, while another engine / thread is capturing: utils.release_graphs)
             if old.nosrc is not None:
-                old.nosrc.graphs.clear()
+                release_graphs(old.nosrc.graphs)
                 old.nosrc = None
         if evict and sample.is_cuda:
             torch.cuda.empty_cache()

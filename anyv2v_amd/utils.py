@@ -241,20 +241,50 @@ def export_to_gif(frames: List[Image.Image], path: Optional[str] = None, fps: in
     return path
 
 
+_CAPTURE_LOCK = threading.RLock()
+_CAPTURE_DEPTH = 0          # captures in progress in this process (nested, or on several threads: two step engines, the trajectory writer)
+_CAPTURE_GC_WAS_ON = False  # the collector's state when the outermost capture began
+_DEFERRED_GRAPHS: list = []  # graph objects released while a capture was recording: kept alive until no stream captures
+
+
+def release_graphs(graphs) -> None:
+    """Drop the ``CUDAGraph`` objects of an evicted step engine (``graphs``: a dict or list, emptied here).  Their destructor calls
+    ``hipGraphExecDestroy``, which is not permitted while ANY stream of the process is capturing -- and a refcount-driven free is not
+    the cyclic collector's doing, so switching the collector off does not cover it: while a capture is recording the objects are
+    parked and freed when the last capture ends."""
+    with _CAPTURE_LOCK:
+        objs = list(graphs.values()) if isinstance(graphs, dict) else list(graphs)
+        graphs.clear()
+        if _CAPTURE_DEPTH > 0:
+            _DEFERRED_GRAPHS.extend(objs)
+
+
 @contextlib.contextmanager
 def capture_hip_graph(graph):
     """``with torch.cuda.graph(graph)`` made safe against the cyclic garbage collector: an unreachable ``CUDAGraph`` (a step engine dropped
     by the LRU, a previous pipeline object) that Python's GC happens to free DURING a capture calls ``hipGraphExecDestroy`` on the capturing
     thread -- "operation not permitted when stream is capturing", and the process aborts in the destructor.  torch >= 2.9 no longer
-    collects before a capture by default, so: collect first, keep the collector off while the stream captures."""
+    collects before a capture by default, so: collect first, keep the collector off while the stream captures.  Re-entrant and
+    thread-safe: a depth counter under a lock, the collector comes back on only when the LAST capture has ended (an inner or concurrent
+    capture must not re-enable it under an outer one), and graphs released meanwhile (``release_graphs``) are freed then."""
+    global _CAPTURE_DEPTH, _CAPTURE_GC_WAS_ON
     import gc
     import torch
-    gc.collect()
-    was_enabled = gc.isenabled()
-    gc.disable()
+    with _CAPTURE_LOCK:
+        if _CAPTURE_DEPTH == 0:
+            gc.collect()
+            _CAPTURE_GC_WAS_ON = gc.isenabled()
+            gc.disable()
+        _CAPTURE_DEPTH += 1
     try:
         with torch.cuda.graph(graph):
             yield
     finally:
-        if was_enabled:
-            gc.enable()
+        with _CAPTURE_LOCK:
+            _CAPTURE_DEPTH -= 1
+            if _CAPTURE_DEPTH == 0:
+                parked = list(_DEFERRED_GRAPHS)
+                _DEFERRED_GRAPHS.clear()
+                del parked   # (freed here, outside every capture)
+                if _CAPTURE_GC_WAS_ON:
+                    gc.enable()

@@ -95,6 +95,40 @@ def measured_traffic(kernel_key):
     return None, None
 
 
+def measured_mfma_busy(kernel_key):
+    """Matrix-pipe utilisation of a kernel from the newest profiles/r*_pmc.json -- written by tools/pmc_sq.py from a rocprofv3 SQ counter
+    pass (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; git commit, formulae and raw counters are in that file).  Like the HBM
+    traffic, a stored figure (the bench cannot run a PMC pass inside itself): labelled with its source, `null` when no file names the kernel."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+
+    def readable(name):
+        m = re.match(r"_Z(\d+)", name)
+        if not m:
+            return name
+        n = int(m.group(1))
+        base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+        args = re.findall(r"L([ib])(\d+)E", rest.split("Ev")[0]) if rest.startswith("I") else []
+        return base + ("<" + ", ".join(("true" if v == "1" else "false") if t == "b" else v for t, v in args) + ">" if args else "")
+    try:
+        rec = json.load(open(files[-1]))
+        for k, v in rec.get("kernels", {}).items():
+            if kernel_key in readable(k):
+                return v["mfma_busy_frac"], {"file": os.path.relpath(files[-1], ROOT), "commit": rec.get("commit"), "kernel": k,
+                                             "mfma_busy_frac_vs_sq_busy": v.get("mfma_busy_frac_sq"), "effective_clock_ghz": v.get("effective_clock_ghz")}
+    except Exception:
+        pass
+    return None, None
+
+
+def _with_pmc(r, kernel_key):
+    r["mfma_busy_frac"], r["mfma_busy_source"] = measured_mfma_busy(kernel_key)
+    return r
+
+
 def roofline_spatial_attention(device, pnp=False):
     """Spatial self-attention at the PnP-step shape (N=48 images, 5 heads, S=4096, d=64): 4*N*h*S^2*d FLOP.
 
@@ -123,7 +157,7 @@ def roofline_spatial_attention(device, pnp=False):
     if pnp:
         r["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
     r["context"] = SUSTAINED_NOTE_32
-    return r
+    return _with_pmc(r, "flash_attn_d64_v2_kernel<3, 3, 8>" if pnp else "flash_attn_d64_v2_kernel<3, 1, 8>")
 
 
 def roofline_conv(device):
@@ -139,10 +173,10 @@ def roofline_conv(device):
     flops = 2.0 * N * H * H * 9 * C * C
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = measured_traffic("gemm_big_kernel<3, false, 1")
-    return {"bound": "mfma", "kernel": "gemm_big_kernel<3,false,conv2d> (conv3x3 320->320 @64x64, N=48; persistent 192x320 tiles)", "achieved": round(ach, 2),
+    return _with_pmc({"bound": "mfma", "kernel": "gemm_big_kernel<3,false,conv2d> (conv3x3 320->320 @64x64, N=48; persistent 192x320 tiles)", "achieved": round(ach, 2),
             "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
             "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src,
-            "context": SUSTAINED_NOTE_16}
+            "context": SUSTAINED_NOTE_16}, "gemm_big_kernel<3, false, 1")
 
 
 def roofline_gemm_ws(device):
@@ -159,11 +193,11 @@ def roofline_gemm_ws(device):
     flops = 2.0 * M * K * N
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = measured_traffic("gemm_ws_kernel<320, 160, true")
-    return {"bound": "mfma", "kernel": "gemm_ws_kernel<K=320, GEGLU> (feed-forward up-projection + GEGLU, 196608 x 320 -> 1280; "
+    return _with_pmc({"bound": "mfma", "kernel": "gemm_ws_kernel<K=320, GEGLU> (feed-forward up-projection + GEGLU, 196608 x 320 -> 1280; "
                                        "weight slab resident in LDS, wave-private row strips)", "achieved": round(ach, 2),
             "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
             "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src,
-            "algorithmic_bytes_per_launch": M * K * 2 + N * K * 2 + M * (N // 2) * 2, "context": SUSTAINED_NOTE_16}
+            "algorithmic_bytes_per_launch": M * K * 2 + N * K * 2 + M * (N // 2) * 2, "context": SUSTAINED_NOTE_16}, "gemm_ws_kernel<320, 160, true")
 
 
 def roofline_ff(device):
@@ -184,11 +218,11 @@ def roofline_ff(device):
     flops = 2.0 * M * (2 * H * C + H * C)
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = measured_traffic("ff_fused_c320_kernel<true")
-    return {"bound": "mfma", "kernel": "ff_fused_c320_kernel (feed-forward of the 320-channel blocks: GEGLU up-projection + down-projection + "
+    return _with_pmc({"bound": "mfma", "kernel": "ff_fused_c320_kernel (feed-forward of the 320-channel blocks: GEGLU up-projection + down-projection + "
                                        "residual, 196608 tokens; weights streamed by LDS-DMA, hidden activation in registers)",
             "achieved": round(ach, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16_TFLOPS, 4),
             "ms_per_launch": round(ms, 4), "flops_per_launch": flops, "traffic": traffic, "traffic_source": src,
-            "algorithmic_bytes_per_launch": 3 * M * C * 2 + 3 * H * C * 2, "context": SUSTAINED_NOTE_16}
+            "algorithmic_bytes_per_launch": 3 * M * C * 2 + 3 * H * C * 2, "context": SUSTAINED_NOTE_16}, "ff_fused_c320_kernel<true")
 
 
 def effective_cpus() -> int:
@@ -555,11 +589,12 @@ def main():
                          "current clip, two streams, as run_group_anyv2v runs a multi-clip job) instead of the single-clip serial order; "
                          "by default the pipelined rate is measured after the timed region and reported as config.pipelined_ms_per_step")
     ap.add_argument("--serial", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--overlap", dest="pipelined", action="store_true", help=argparse.SUPPRESS)   # rounds 3-4 name of --pipelined
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 2 and 5)")
     ap.add_argument("--no-job-schedule", action="store_true",
                     help="skip the measurement of the other schedule behind the timed region (profiling runs: the trace then holds the timed pairs only)")
     args = ap.parse_args()
-    args.overlap = args.pipelined and not args.serial
+    args.overlap = args.pipelined and not args.serial   # (the timed schedule; also the top-level "schedule" key of the line)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -742,7 +777,7 @@ def main():
             "metric": "frames/sec for 16fx512x512 DDIM-inversion+PnP-edit; spatial-attn MFMA % of peak",
             "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": "f16", "data": "synthetic", "schedule": "pipelined" if args.overlap else "serial",
             "config": {"workload": "BASELINE config 3 per GPU: 1 clip x 16f x 512x512, 50-step DDIM inversion (UNet B=1) + 50-step "
                                    "PnP edit (UNet B=3, cfg 9.0, conv+spatial+temporal injection on every step); a bench step = "
                                    "1 inversion step + 1 edit step = 1/50 clip; I2VGen-XL 3D-UNet 1.42B params, random init",

@@ -383,8 +383,75 @@ def gen_seine_pipeline():
     print("seine_pipeline.pt", {k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in fx.items() if k != "spec"})
 
 
+VAE_BLOCK_SPEC = dict(weight_seed=21, input_seed=22, groups=32, cases=((128, 128), (128, 256)), hw=(12, 10), n=2, sampler_c=128)
+
+
+def vae_block_inputs(spec=VAE_BLOCK_SPEC):
+    """Seeded inputs / fp16-rounded weights of the VAE block fixture (shared by the generator, the CPU test and the GPU check)."""
+    g = torch.Generator().manual_seed(spec["input_seed"])
+    H, W = spec["hw"]
+    out = {"x": {}, "weights": {}}
+    for cin, cout in spec["cases"]:
+        out["x"][f"res{cin}_{cout}"] = torch.randn(spec["n"], cin, H, W, generator=g).half().float()
+    c = spec["sampler_c"]
+    out["x"]["up"] = torch.randn(spec["n"], c, H, W, generator=g).half().float()
+    xd = torch.randn(spec["n"], c, H, W, generator=g).half().float()
+    xd[:, :, 0, :] = 0   # first row / column zero: F.pad(x, (0, 1, 0, 1)) then equals the symmetric pad of x[1:, 1:] (see gen_vae_blocks)
+    xd[:, :, :, 0] = 0
+    out["x"]["down"] = xd
+    gw = torch.Generator().manual_seed(spec["weight_seed"])
+
+    def w(*shape, scale):
+        return (torch.randn(*shape, generator=gw) * scale).half().float()
+    for cin, cout in spec["cases"]:
+        sd = {"norm1.weight": 1 + w(cin, scale=0.1), "norm1.bias": w(cin, scale=0.05),
+              "conv1.weight": w(cout, cin, 3, 3, scale=(9 * cin) ** -0.5), "conv1.bias": w(cout, scale=0.05),
+              "norm2.weight": 1 + w(cout, scale=0.1), "norm2.bias": w(cout, scale=0.05),
+              "conv2.weight": w(cout, cout, 3, 3, scale=(9 * cout) ** -0.5), "conv2.bias": w(cout, scale=0.05)}
+        if cin != cout:
+            sd["conv_shortcut.weight"] = w(cout, cin, 1, 1, scale=cin ** -0.5)
+            sd["conv_shortcut.bias"] = w(cout, scale=0.05)
+        out["weights"][f"res{cin}_{cout}"] = sd
+    for name in ("up", "down"):
+        out["weights"][name] = {"conv.weight": w(c, c, 3, 3, scale=(9 * c) ** -0.5), "conv.bias": w(c, scale=0.05)}
+    return out
+
+
+def gen_vae_blocks():
+    """``vae_blocks_ref.pt`` (``--vae-blocks``): BLOCK-level pin of ``oracle/vae_oracle.py``.  No ``AutoencoderKL``
+    source exists under the reference tree, but its building blocks are diffusers' ResNet block / samplers, which the reference
+    vendors at ``seine/models/resnet.py``: ``ResnetBlock3D`` (``:113-207``) with ``temb_channels=None``, ``eps=1e-6`` at ONE frame ==
+    the VAE's ResnetBlock2D(temb=None); ``Upsample3D(use_conv=True)`` (``:24-76``) == nearest x2 + 3x3 conv; ``Downsample3D``
+    (``:79-110``) is the stride-2 3x3 conv with SYMMETRIC padding 1 (its ``padding == 0`` branch -- the VAE's -- raises
+    NotImplementedError there), so the asymmetric form ``conv(F.pad(x, (0, 1, 0, 1)), stride 2, pad 0)`` is pinned through the
+    identity ``F.pad(x, (0, 1, 0, 1)) == F.pad(x[..., 1:, 1:], (1, 1, 1, 1))`` for an x whose first row and column are zero: the
+    reference class runs on ``x[..., 1:, 1:]``.  The encoder / decoder ASSEMBLY and the mid-block attention stay unpinnable."""
+    res, _ = ref_stubs.load_reference_seine_blocks()
+    spec = VAE_BLOCK_SPEC
+    io = vae_block_inputs(spec)
+    fx = {"spec": dict(spec), "out": {}}
+    with torch.no_grad():
+        for cin, cout in spec["cases"]:
+            name = f"res{cin}_{cout}"
+            blk = res.ResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=None, groups=spec["groups"], eps=1e-6).eval()
+            blk.load_state_dict(io["weights"][name])
+            fx["out"][name] = blk(io["x"][name][:, :, None], None)[:, :, 0].clone()
+        c = spec["sampler_c"]
+        up = res.Upsample3D(c, use_conv=True).eval()
+        up.load_state_dict(io["weights"]["up"])
+        fx["out"]["up"] = up(io["x"]["up"][:, :, None])[:, :, 0].clone()
+        dn = res.Downsample3D(c, use_conv=True, padding=1).eval()
+        dn.conv.load_state_dict({k[len("conv."):]: v for k, v in io["weights"]["down"].items()})
+        fx["out"]["down"] = dn(io["x"]["down"][:, :, None, 1:, 1:])[:, :, 0].clone()
+    torch.save(fx, os.path.join(HERE, "vae_blocks_ref.pt"))
+    print("vae_blocks_ref.pt", {k: tuple(v.shape) for k, v in fx["out"].items()})
+
+
 if __name__ == "__main__":
     assert ref_stubs.reference_available(), "needs /root/reference"
+    if "--vae-blocks" in sys.argv:
+        gen_vae_blocks()
+        sys.exit(0)
     if "--seine" in sys.argv:
         gen_seine()
         sys.exit(0)

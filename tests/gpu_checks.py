@@ -1733,12 +1733,13 @@ def _recorded_caps():
 _RECORD = {}
 
 
-def _calibrated(name, got, ref, eager, factor=2.0, floor=5e-4, key=None, gap_cap=None):
+def _calibrated(name, got, ref, eager, factor=2.0, floor=5e-4, key=None, gap_cap=None, max_tol=None):
     """SURVEY.md 8(c) tolerance policy: |HIP fp16 - fp32 oracle| <= 2 x |torch-eager fp16 oracle - fp32 oracle| (+ a floor
     for the cases where both are at rounding level), all three on the same inputs in the same test -- for the max-abs metric AND
     for relative L2 -- and, with ``key``, additionally <= 3 x the HIP error recorded for this check (``_recorded_caps``).
     Every row also reports |HIP - eager fp16| (same normalisation): when both fp16 paths sit far from the fp32 checker but close to
-    each other, the CHECKER is the outlier (VERDICT r3 weak #1); ``gap_cap`` bounds that distance."""
+    each other, the CHECKER is the outlier; ``gap_cap`` bounds that distance.  ``max_tol``: a fixed bound the
+    calibrated one may not exceed (a calibration arm that shares the model code must not LOOSEN an older fixed bound)."""
     got, ref, eager = got.float().cpu(), ref.float().cpu(), eager.float().cpu()
     if not torch.isfinite(got).all():
         return dict(name=name, err=float("nan"), l2=float("nan"), tol=0.0, ok=False)
@@ -1747,6 +1748,8 @@ def _calibrated(name, got, ref, eager, factor=2.0, floor=5e-4, key=None, gap_cap
     e_g, l2_g = _rel(got, eager)
     tol = factor * e_e + floor
     tol_l2 = factor * l2_e + floor
+    if max_tol is not None:
+        tol, tol_l2 = min(tol, max_tol), min(tol_l2, max_tol)
     cap = None
     if key is not None:
         _RECORD[key] = {"err": e_h, "l2": l2, "eager": e_e, "eager_l2": l2_e, "hip_vs_eager": e_g, "hip_vs_eager_l2": l2_g}
@@ -2294,6 +2297,52 @@ def check_vae(full: bool = True):
     return out
 
 
+def check_vae_blocks_vs_reference_fixture():
+    """The NATIVE VAE blocks (``anyv2v_amd/vae.py``: ``VAEResnetBlock``, the folded nearest-x2 up-sampler, the one-sided-pad stride-2
+    down-sampler) on the HIP kernels against ``tests/golden/vae_blocks_ref.pt`` -- outputs of the reference's vendored copies of those
+    diffusers blocks (``seine/models/resnet.py:24-207``, ``make_golden.py --vae-blocks``).  Row F1's pinnable part."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from anyv2v_amd import vae as nv
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "vae_blocks_ref.pt"))
+    spec = fx["spec"]
+    io = mg.vae_block_inputs(spec)
+    H, W = spec["hw"]
+    sc = nv._Scratch()
+    out = []
+
+    def back(t, n, h, w):
+        return t.float().view(n, h, w, -1).permute(0, 3, 1, 2).cpu()
+    for cin, cout in spec["cases"]:
+        name = f"res{cin}_{cout}"
+        blk = nv.VAEResnetBlock(cin, cout, spec["groups"])
+        blk.load_state_dict(io["weights"][name])
+        blk = blk.to(DEV).half()
+        for m in blk.modules():
+            if hasattr(m, "pack"):
+                m.pack()
+        y = blk.run(sc, _to_tokens(io["x"][name].to(DEV).half()), H, W)
+        out.append(_res(f"vae block {name} (native) vs the reference's ResnetBlock3D(temb=None) fixture", back(y, spec["n"], H, W), fx["out"][name], 3e-3))
+    c = spec["sampler_c"]
+    for name, stride in (("up", 1), ("down", 2)):
+        smp = nv._Sampler(c, stride)
+        smp.load_state_dict(io["weights"][name])
+        smp = smp.to(DEV).half()
+        for m in smp.modules():
+            if hasattr(m, "pack"):
+                m.pack()
+        x = _to_tokens(io["x"][name].to(DEV).half())
+        if name == "up":
+            y = smp.conv.tokens(x, H, W, up=True)
+            out.append(_res("vae up-sampler (native, nearest x2 folded) vs the reference's Upsample3D fixture", back(y, spec["n"], 2 * H, 2 * W), fx["out"]["up"], 3e-3))
+        else:
+            y = smp.conv.tokens(x, H, W, asym=True)
+            out.append(_res("vae down-sampler (native, pad (0,1,0,1) stride 2) vs the reference's Downsample3D fixture (shifted-input identity)",
+                            back(y, spec["n"], H // 2, W // 2), fx["out"]["down"], 3e-3))
+    return out
+
+
 def check_consisti2v_hooks():
     """the ConsistI2V hook family (``anyv2v_amd/consisti2v.py``) on the kernels vs the fixture the REFERENCE's
     own ``VideoLDMCrossAttnUpBlock`` + ``consisti2v/pnp_utils.py`` produced on the CPU in fp32 (``make_golden.py --consisti2v``):
@@ -2384,8 +2433,11 @@ def check_consisti2v_pipeline():
     # here on the CPU on the same weights from the same trajectory) shows against the reference's fp32 output, and 3 x the recorded
     # HIP figure; HIP-vs-emulation is printed.
     emu = _emulated(lambda: spec.native_pipeline_job("cpu", trajectory_from=files))
-    out.append(_calibrated("consisti2v pipeline: sample_with_pnp (text guidance 35) vs the reference class's output; 'eager' = torch op emulation",
-                           nat["edit_lat"], fx["edit_lat"], emu["edit_lat"], key="consisti2v_pipeline_pnp_edit"))
+    # (the emulation arm runs the repo's own model / pipeline code -- it is independent at KERNEL level only -- so it may
+    #  tighten but never loosen the former fixed bound of 0.25, and the HIP-vs-emulation distance is capped at 1.5 x its recorded 0.19)
+    out.append(_calibrated("consisti2v pipeline: sample_with_pnp (text guidance 35) vs the reference class's output; 'eager' = torch op emulation "
+                           "(kernel-independent only)", nat["edit_lat"], fx["edit_lat"], emu["edit_lat"], key="consisti2v_pipeline_pnp_edit",
+                           max_tol=0.25, gap_cap=0.29))
     out.append(_calibrated("consisti2v pipeline: __call__ reconstruction (calibrated)", nat["rec_lat"], fx["rec_lat"], emu["rec_lat"],
                            key="consisti2v_pipeline_reconstruction"))
     dec = torch.from_numpy(nat["pipe"].decode_latents(fx["edit_lat"].to(DEV)))
@@ -2468,8 +2520,9 @@ def check_seine_pipeline():
         out.append(dict(name=f"seine runners: edit timesteps ({sm})", err=0.0, tol=0.0, ok=nat["edit_ts"] == fx[f"edit_ts_{sm}"]))
         with tempfile.TemporaryDirectory() as tmp2:   # (calibrated like the ConsistI2V edit row)
             emu = _emulated(lambda: spec.native_job("cpu", tmp2, sm, trajectory_from=files))
-        out.append(_calibrated(f"seine runners: edit_video, {sm} sampler, cfg 4 vs the reference runner's output; 'eager' = torch op emulation",
-                               nat["edit_lat"], fx[f"edit_lat_{sm}"], emu["edit_lat"], key=f"seine_pipeline_edit_{sm}"))
+        out.append(_calibrated(f"seine runners: edit_video, {sm} sampler, cfg 4 vs the reference runner's output; 'eager' = torch op emulation "
+                               "(kernel-independent only)", nat["edit_lat"], fx[f"edit_lat_{sm}"], emu["edit_lat"], key=f"seine_pipeline_edit_{sm}",
+                               max_tol=5e-2, gap_cap=4.5e-2))
         dec = nat["pipe"].decode_latents(fx[f"edit_lat_{sm}"].to(DEV))
         d = int((dec.int() - fx[f"edited_frames_{sm}"].int()).abs().max())
         out.append(dict(name=f"seine runners: decode_latents of the reference's latents ({sm}), max |uint8 diff|", err=float(d), tol=1.0, ok=d <= 1))

@@ -234,6 +234,10 @@ def test_vae_kernel_modes():
     _assert_all(gc.check_vae_kernels())
 
 
+def test_native_vae_blocks_vs_reference_block_fixture():
+    _assert_all(gc.check_vae_blocks_vs_reference_fixture())
+
+
 def test_native_vae_vs_oracle():
     """AutoencoderKL encode / decode on the HIP kernels vs the CPU restatement (mini + full architecture)."""
     _assert_all(gc.check_vae())

@@ -790,3 +790,41 @@ def test_several_clips_inverted_in_one_batch(cpu_ops, tmp_path):
         assert sorted(os.listdir(dirs[k])) == sorted(f"ddim_latents_{t}.pt" for t in singles[k].keys())
     # the clips really are different rows
     assert not torch.equal(batched[0][1], batched[1][1])
+
+
+def test_capture_guard_is_reentrant_and_parks_released_graphs(monkeypatch):
+    """``utils.capture_hip_graph`` under nesting / concurrency -- the cyclic collector stays OFF until the outermost capture
+    ends (an inner exit must not re-enable it), and graph objects released while a capture records (``release_graphs``: LRU eviction of
+    a step engine) are parked, i.e. not destroyed, until no capture is in progress.  ``torch.cuda.graph`` is replaced by a dummy context."""
+    import contextlib
+    import gc
+    import weakref
+
+    import torch
+    from anyv2v_amd import utils
+
+    @contextlib.contextmanager
+    def fake_graph(g):
+        yield
+    monkeypatch.setattr(torch.cuda, "graph", fake_graph)
+
+    class G:   # stands for a CUDAGraph: its death is observable
+        pass
+    assert gc.isenabled()
+    g1, g2 = G(), G()
+    r1, r2 = weakref.ref(g1), weakref.ref(g2)
+    held = {"a": g1}
+    with utils.capture_hip_graph(object()):
+        assert not gc.isenabled()
+        with utils.capture_hip_graph(object()):
+            assert not gc.isenabled()
+            del g1
+            utils.release_graphs(held)          # released DURING a capture: parked
+            assert held == {} and r1() is not None
+        assert not gc.isenabled(), "the inner capture's exit re-enabled the collector under the outer one"
+        assert r1() is not None
+    assert gc.isenabled() and r1() is None      # freed when the last capture ended
+    lst = [g2]
+    del g2
+    utils.release_graphs(lst)                   # no capture in progress: dropped at once
+    assert lst == [] and r2() is None
