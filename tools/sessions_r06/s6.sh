@@ -3,7 +3,7 @@
 # the default bench line, kernel trace summary, per-shape reports.
 set -u
 TAG=r06
-export GIT_COMMIT=d9cebcd
+export GIT_COMMIT=d3f1b22
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
