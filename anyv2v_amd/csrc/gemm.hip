@@ -1181,6 +1181,8 @@ static int dispatch(GemmK& k, const AnyV2VGemmDesc* d, bool fast, hipStream_t s)
         const int blocks = av_gemm_sw_sk_blocks(d, (d->flags & (1 << 27)) != 0);
         if (blocks > 0 && av_gemm_sw_sk_workspace(blocks) <= (size_t)d->workspace_bytes) return av_gemm_sw_sk_launch(k, d, blocks, s);
     }
+    // 3x3 convolution with LDS reuse of the A operand across the dx taps (gemm_swh.hip): flags bit28 takes it where eligible.
+    if (glds && (d->flags & (1 << 28)) && !(d->flags & (1 << 22)) && av_gemm_swh_eligible(d)) return av_gemm_swh_launch(k, d, s);
     // One-wave-per-SIMD persistent kernel (gemm_sw.hip): flags bit21 takes it wherever the shape allows, bit22 forbids it.
     if (glds && (d->flags & (1 << 21)) && !(d->flags & (1 << 22)) && av_gemm_sw_eligible(d)) return av_gemm_sw_launch(k, d, s);
     // 128-row kernel tile width: 160 columns (NF = 5) where N allows it, except where 128-column tiles (NF = 4) quantise better onto

@@ -118,3 +118,7 @@ int av_gemm_sw_launch(GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s);
 int av_gemm_sw_sk_blocks(const AnyV2VGemmDesc* d, bool force);
 size_t av_gemm_sw_sk_workspace(int blocks);
 int av_gemm_sw_sk_launch(GemmK& k, const AnyV2VGemmDesc* d, int blocks, hipStream_t s);
+
+// ---- 3x3 convolution with the A operand reused from LDS across the dx taps (gemm_swh.hip): flags bit28 takes it where eligible ----
+bool av_gemm_swh_eligible(const AnyV2VGemmDesc* d);
+int av_gemm_swh_launch(GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s);

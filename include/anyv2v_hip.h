@@ -70,8 +70,13 @@ typedef struct AnyV2VGemmDesc {
                             wide-N launches (0 auto, 1 classic N-fastest, 2..6 super-tiles of 4 / 8 / 16 / 32 / 2 M-tiles per XCD
                             round), bit16: super-tiles walked N-fastest -- every order gives bit-identical results; bit17: take the
                             ping-pong persistent kernel wherever the shape allows (N % 320 = 0, no GEGLU), bit18: never take it,
-                            bit19 / bit20: its 192- / 256-row tile (bit-identical to the other tile kernels).  All other bits are
-                            ignored by the product library. */
+                            bit19 / bit20: its 192- / 256-row tile (bit-identical to the other tile kernels); round 6, all OFF by
+                            default (A/B switches and tests): bit21: take the one-wave-per-SIMD persistent kernel (gemm_sw.hip:
+                            N % 320 = 0, >= 2 K-tiles; bit-identical to the other tile kernels), bit22: never take any of the round-6
+                            kernels, bit26 / bit27: allow / force its stream-K form (un-hinted launches, needs a workspace of 126 MB;
+                            a different fp32 summation order), bit28: 3x3 stride-1 "same" convolutions at image width 16 / 32 / 64 on
+                            the LDS-patch kernel (gemm_swh.hip: K order (dy, slice, dx), a different summation order).  All other
+                            bits are ignored by the product library. */
     void* workspace;     /* optional fp32 scratch for split-K partial tiles (small-M, long-K launches) or NULL */
     int64_t workspace_bytes;
     /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock.norm1/2/3 -> attn.to_q/k/v / ff.net[0].proj,

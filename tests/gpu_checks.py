@@ -292,6 +292,43 @@ def check_gemm_big(extra=0, tag="big", exact=True):
     return out
 
 
+def check_conv_halo():
+    """gemm_swh_kernel (round 6: 3x3 stride-1 convolution whose A operand is staged ONCE per (dy, channel slice) as an LDS patch and
+    read three times with a one-pixel address shift, K order (dy, slice, dx)), forced with flags bit28 on every image width it
+    takes (16 / 32 / 64): one / two sources, bias / temb row vector / residual epilogues, tile counts below and above the CU count,
+    row counts that are not a multiple of the 192-row tile (images cut by a tile boundary), against F.conv2d in fp32 (kernel tolerance)
+    and against the tap-gather kernels' result (5e-4: the same products in another summation order)."""
+    out = []
+    saved = ops.GEMM_FLAGS
+    try:
+        for (n, H, c0, c1, co, res, rvd) in [(3, 64, 64, 0, 320, False, 0), (2, 64, 128, 64, 320, True, 0), (6, 32, 128, 0, 640, False, 2),
+                                             (70, 32, 64, 0, 320, True, 0), (5, 16, 192, 0, 320, False, 0), (13, 16, 64, 64, 640, True, 0),
+                                             (300, 16, 64, 0, 320, False, 100)]:
+            x0 = rnd(n, c0, H, H)
+            x1 = rnd(n, c1, H, H) if c1 else None
+            ci = c0 + c1
+            w, b = rnd(co, ci, 3, 3, scale=1 / math.sqrt(9 * ci)), rnd(co)
+            r = rnd(n * H * H, co) if res else None
+            temb = rnd(n // rvd, co) if rvd else None
+            kw = dict(bias=b, a1=None if x1 is None else _to_tokens(x1), rowvec=temb, rowvec_div=rvd * H * H if rvd else 0, residual=r,
+                      mode=ops.MODE_CONV2D, conv=(H, H, H, H, 1, 0))
+            ops.GEMM_FLAGS = saved | (1 << 28)
+            y = ops.gemm(_to_tokens(x0), _pack_conv(w), **kw)
+            ops.GEMM_FLAGS = saved
+            yd = ops.gemm(_to_tokens(x0), _pack_conv(w), **kw)
+            xx = x0 if x1 is None else torch.cat([x0, x1], 1)
+            ref = F.conv2d(xx.float(), w.float(), b.float(), padding=1)
+            if rvd:
+                ref = ref + temb.float().repeat_interleave(rvd, 0)[:, :, None, None]
+            ref = _to_tokens(ref) + (r.float() if res else 0.0)
+            tag = f"{n} x {H}x{H}, {c0}+{c1} -> {co}, res={res} temb={bool(rvd)}"
+            out.append(_res(f"conv3x3[halo] {tag} vs F.conv2d fp32", y, ref, KTOL))
+            out.append(_res(f"conv3x3[halo] {tag} vs the tap-gather kernels", y, yd.float(), 5e-4))
+    finally:
+        ops.GEMM_FLAGS = saved
+    return out
+
+
 def _geglu_pack(wfull, bfull, inner):
     dim = wfull.shape[1]
     wh, wg = wfull[:inner].view(inner // 16, 16, dim), wfull[inner:].view(inner // 16, 16, dim)

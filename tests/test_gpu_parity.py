@@ -49,6 +49,10 @@ def test_gemm_single_wave_per_simd_kernel():
     _assert_all(gc.check_gemm_big(1 << 21, tag="sw"))
 
 
+def test_conv3x3_lds_patch_reuse_kernel():
+    _assert_all(gc.check_conv_halo())
+
+
 def test_gemm_single_wave_kernel_stream_k():
     """The stream-K form of gemm_sw_kernel (blocks own contiguous ranges of (tile, K-tile) units; tiles cut by a range boundary are
     summed from fp32 slabs by gemm_sw_fixup_kernel), forced (flags bit27) onto every eligible case of the persistent-kernel check:

@@ -11,14 +11,18 @@ import torch  # noqa: E402
 
 from anyv2v_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "libanyv2v_hip_experiments.so")
+if "--product" not in sys.argv:
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "libanyv2v_hip_experiments.so")
 from anyv2v_amd import ops  # noqa: E402
 
 dev = "cuda"
 lines = []
 ARMS = (("gemm_big", 8), ("sw tap-major", 1 << 21), ("sw slice-major", (1 << 21) | (8 << 23)), ("sw slice-major + W sc1", (1 << 21) | (7 << 23)))
+if "--product" in sys.argv:   # the LDS-patch kernel (gemm_swh.hip, flags bit28) against the default dispatch and the plain one-wave kernel
+    ARMS = (("default", 0), ("sw tap-major", 1 << 21), ("swh LDS patch (dy, slice, dx)", 1 << 28))
 for (tag, n_img, H, cin, cout) in [("B3 64x64 320->320", 48, 64, 320, 320), ("B3 64x64 640->320", 48, 64, 640, 320), ("B3 32x32 640->640", 48, 32, 640, 640),
-                                   ("B3 16x16 1280->1280", 48, 16, 1280, 1280), ("B1 64x64 320->320", 16, 64, 320, 320), ("B3 32x32 1280->640", 48, 32, 1280, 640)]:
+                                   ("B3 16x16 1280->1280", 48, 16, 1280, 1280), ("B1 64x64 320->320", 16, 64, 320, 320), ("B3 32x32 1280->640", 48, 32, 1280, 640),
+                                   ("B3 64x64 960->320", 48, 64, 960, 320), ("B3 16x16 2560->1280", 48, 16, 2560, 1280)]:
     M, K = n_img * H * H, 9 * cin
     x = torch.randn(M, cin, device=dev).half()
     w = (torch.randn(cout, K, device=dev) / K ** 0.5).half()
@@ -49,4 +53,4 @@ for (tag, n_img, H, cin, cout) in [("B3 64x64 320->320", 48, 64, 320, 320), ("B3
     lines.append(row)
     print(row, flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-open(os.path.join(ROOT, "gpurun_out", "r06_conv_korder_l1.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(ROOT, "gpurun_out", "r06_conv_halo_ab.txt" if "--product" in sys.argv else "r06_conv_korder_l1.txt"), "w").write("\n".join(lines) + "\n")
