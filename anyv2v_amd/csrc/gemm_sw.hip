@@ -20,6 +20,7 @@
 // Replaces (reference = TIGER-AI-Lab/AnyV2V): i2vgen-xl/pnp_utils.py conv1/conv2 :78,:107, conv_shortcut :117-122, residual :124,
 // attn.to_q/to_k/to_v :175,:182-183, attn.to_out[0] :216, and the diffusers-0.26.3 FeedForward (GEGLU up / down projections) and
 // TemporalConvLayer behind pipeline_i2vgen_xl.py:1146.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -696,7 +697,11 @@ static void sw_launch_mode(const GemmK& k, const AnyV2VGemmDesc* d, dim3 grid, h
 int av_gemm_sw_launch(GemmK& k, const AnyV2VGemmDesc* d, hipStream_t s) {
     const int tiles = ((d->M + SW_BM - 1) / SW_BM) * (d->N / 320);
     k.tilesN = d->N / 320;
-    const dim3 grid(tiles < 256 ? tiles : 256);
+    int gmax = 256;
+#ifdef ANYV2V_EXPERIMENTS   // probe (tools/gemm_sw_grid_probe.py): fewer persistent blocks = fewer CUs share the L2 / fabric
+    if (const char* e = getenv("ANYV2V_SW_GRID")) gmax = atoi(e) > 0 ? atoi(e) : 256;
+#endif
+    const dim3 grid(tiles < gmax ? tiles : gmax);
     {   // tile order of wide-N launches: as gemm_big_kernel's dispatch (flags bits 13-16)
         const int code = (d->flags >> 13) & 7;
         static const int gm_of[8] = {0, 0, 4, 8, 16, 32, 2, 0};
