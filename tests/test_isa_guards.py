@@ -36,7 +36,7 @@ def _regs(operand):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 @pytest.mark.parametrize("src,extra", [("gemm.hip", ()), ("attention.hip", ("-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize")),
-                                       ("ff_fused.hip", ("-fno-slp-vectorize",))])
+                                       ("ff_fused.hip", ("-fno-slp-vectorize",)), ("gemm_sw.hip", ()), ("gemm_swh.hip", ())])
 def test_no_spill_or_copy_of_a_pending_asm_lds_read(src, extra):
     asm = _asm(src, extra)
     kernels = re.findall(r"^(_Z\w+):.*?s_endpgm", asm, re.S | re.M)
