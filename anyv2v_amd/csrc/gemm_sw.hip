@@ -113,6 +113,20 @@ struct SwGen {
             for (int i = 0; i < SW_MF; ++i) ap[i] += astep[i];
         }
     }
+    // The same step in two parts (ORD 0): `bump` = the pointer adds, UNCONDITIONAL, issued inside the K-tile body as fillers between
+    // MFMAs; `count` = the counters and -- when the tap or the source changes -- the recomputation that overwrites the bumped pointers,
+    // between two bodies.  With one wave per SIMD every VALU instruction between two bodies is matrix-pipe idle time.
+    __device__ __forceinline__ void bump() {
+#pragma unroll
+        for (int i = 0; i < SW_MF; ++i) ap[i] += astep[i];
+    }
+    __device__ __forceinline__ void count(const GemmK& p, const RowInfo (&ri)[SW_MF], int kc, int ntap) {
+        if (++ktc == ntap) {
+            ktc = 0;
+            ++tap;
+        }
+        if (ktc == 0 || ktc == p.nt0) recompute(p, ri, kc);
+    }
 };
 
 __device__ __forceinline__ void glds16_sc1(const half_t* g, char* lds_wave_base) {   // the same piece past L1 (sc1): L2-served, no TCP line
@@ -236,10 +250,14 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
                 return;
             }
         }
-        if (++a_kt == nk)
+        if (++a_kt == nk) {
             a_start(SK ? a_tile + 1 : next_valid(a_tile + G));
-        else
-            gen.next(p, ri, kc, ntap);
+        } else {
+            if constexpr (ORD == 0 && ALA == 1)
+                gen.count(p, ri, kc, ntap);   // (its pointer adds were issued inside the body: stream_bump)
+            else
+                gen.next(p, ri, kc, ntap);
+        }
     };
     auto w_start = [&](int item, int kt0 = 0) {
         w_tile = item;
@@ -270,10 +288,19 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
                     ++w_slice;
                 }
                 bptr += (w_tap * ntap + w_slice - prev) * 64;
-            } else {
+            } else if constexpr (ALA != 1) {
                 bptr += 64;
                 bptr4 += 64;
-            }
+            }   // (ORD 0, ALA 1: bptr / bptr4 were advanced inside the body: stream_bump)
+        }
+    };
+    // the unconditional part of both streams' step, issued inside the K-tile body (behind MFMA group 13; ALA 1 only): harmless when the
+    // step then turns out to be a tile switch or a recomputation, which overwrite every pointer
+    auto stream_bump = [&]() {
+        if constexpr (ORD == 0 && ALA == 1) {
+            gen.bump();
+            bptr += 64;
+            bptr4 += 64;
         }
     };
     auto a_piece = [&](int i, int slot, bool fetch) {   // i: constant after unrolling
@@ -370,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
                     w_piece(g - MF / 2 + 1, sw ^ 1, fetch_w);
                 }
             }
+            if (g == 13) stream_bump();
             if (g == 17) {
                 if constexpr (ALA == 2) {
                     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
@@ -405,9 +433,10 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmK p) {
     w_start(tile, kb);
 #pragma unroll
     for (int i = 0; i < MF; ++i) a_piece(i, 0, true);
-    a_step();
 #pragma unroll
     for (int j = 0; j < 10; ++j) w_piece(j, 0, true);
+    stream_bump();
+    a_step();
     w_step();
     if constexpr (ALA == 2) {
 #pragma unroll
