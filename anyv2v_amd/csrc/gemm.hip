@@ -684,15 +684,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK p) {
             __builtin_amdgcn_s_barrier();  // K-tile kt landed for everyone; everyone is done with the other stage
             if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 3 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             const bool last = kt + 1 == nk;
-            if (last && has_next) producer_start(next_tile);  // the pieces below then fetch K-tile 0 of the next tile
+            // the pieces below then fetch K-tile 0 of the next tile -- or, when the block has none, K-tile 0 of THIS tile again into the idle
+            // stage (never read): the producer always addresses data that exists, so no piece needs a per-lane "fetch ? pointer : zero
+            // line" select (16 v_cndmask per wave and K-tile out of the MFMA stream)
+            if (last) producer_start(has_next ? next_tile : tile);
             const bool fetch = !last || has_next;
             const char* as = smem + stage * STAGE_BYTES;
             char* st = smem + (stage ^ 1) * STAGE_BYTES;
             mma_tile_big<MF>(acc, as, as + A_BYTES, wr, wc, lane, [&](int i) {
                 if (i < MF)
-                    glds16(fetch ? gen.ap[i] : p.zeros, st + (i * 512 + w * 64) * 16);
+                    glds16(gen.ap[i], st + (i * 512 + w * 64) * 16);
                 else
-                    glds16(fetch ? bptr + (i - MF) * brow : p.zeros, st + A_BYTES + ((i - MF) * 512 + w * 64) * 16);
+                    glds16(bptr + (i - MF) * brow, st + A_BYTES + ((i - MF) * 512 + w * 64) * 16);
             });
             if constexpr (TRACE) if (tid == 0 && tile == b0 + AV_TRACE_TILE * G && kt < 8) p.trace[(size_t)blockIdx.x * 32 + 4 + 3 * kt] = (long long)__builtin_amdgcn_s_memtime();
             if (fetch) advance();
