@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 final validation at HEAD: whole -m gpu suite, smoke, default bench line.
 set -u
-export GIT_COMMIT=d39fba4
+export GIT_COMMIT=1e57236
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/r06_gputest_final_log.txt 2>&1
